@@ -1,0 +1,415 @@
+"""ctypes front-end of the CPU ORACLE (oracle/tw_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(), and the
+cpu_baseline leg of bench.py.  The product package (twisterl_amd/) must never import this.
+
+The oracle restates the reference algorithm (file:line citations live in tw_oracle.c); this
+module only marshals numpy arrays in and out of it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libtw_oracle.so")
+
+ARITH_REF = 0    # reference order: un-fused multiply/add, k-ordered, bias last
+ARITH_CHAIN = 1  # fused-multiply-add chain (what an f32 MFMA computes), bias last
+
+MAX_CELLS = 64
+MAX_LAYERS = 8
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc via oracle/Makefile (idempotent)."""
+    src = [os.path.join(_HERE, f) for f in ("tw_oracle.c", "tw_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+class _Puzzle(C.Structure):
+    _fields_ = [("state", C.c_int64 * MAX_CELLS), ("zx", C.c_int64), ("zy", C.c_int64),
+                ("depth", C.c_int64), ("width", C.c_int64), ("height", C.c_int64),
+                ("difficulty", C.c_int64), ("depth_slope", C.c_int64), ("max_depth", C.c_int64)]
+
+
+class _Linear(C.Structure):
+    _fields_ = [("in_", C.c_int), ("out", C.c_int), ("w", C.POINTER(C.c_float)),
+                ("b", C.POINTER(C.c_float)), ("relu", C.c_int)]
+
+
+class _EmbBag(C.Structure):
+    _fields_ = [("n_vectors", C.c_int), ("vec_len", C.c_int), ("vectors", C.POINTER(C.c_float)),
+                ("bias", C.POINTER(C.c_float)), ("bias_len", C.c_int), ("relu", C.c_int),
+                ("obs_shape", C.c_int * 2), ("obs_ndim", C.c_int), ("conv_dim", C.c_int)]
+
+
+class _Policy(C.Structure):
+    _fields_ = [("emb", _EmbBag),
+                ("common", _Linear * MAX_LAYERS), ("n_common", C.c_int),
+                ("action", _Linear * MAX_LAYERS), ("n_action", C.c_int),
+                ("value", _Linear * MAX_LAYERS), ("n_value", C.c_int),
+                ("n_perms", C.c_int), ("obs_size", C.c_int), ("n_actions", C.c_int),
+                ("obs_perms", C.POINTER(C.c_int32)), ("act_perms", C.POINTER(C.c_int32))]
+
+
+class _Collected(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_cells", C.c_int), ("n_actions", C.c_int),
+                ("obs", C.POINTER(C.c_int64)), ("logits", C.POINTER(C.c_float)),
+                ("perms", C.POINTER(C.c_int32)), ("values", C.POINTER(C.c_float)),
+                ("rewards", C.POINTER(C.c_float)), ("actions", C.POINTER(C.c_int64)),
+                ("advs", C.POINTER(C.c_float)), ("rets", C.POINTER(C.c_float)),
+                ("remaining", C.POINTER(C.c_float)), ("ep_len", C.POINTER(C.c_uint32)),
+                ("n_episodes", C.c_uint64), ("has_ppo", C.c_int)]
+
+
+class _PPOParams(C.Structure):
+    _fields_ = [("num_episodes", C.c_uint64), ("episode_offset", C.c_uint64),
+                ("gamma", C.c_float), ("lambda_", C.c_float), ("seed", C.c_uint64),
+                ("arith", C.c_int), ("det_log", C.c_int), ("num_threads", C.c_int),
+                ("merge_order", C.c_int)]
+
+
+class _AZParams(C.Structure):
+    _fields_ = [("num_episodes", C.c_uint64), ("episode_offset", C.c_uint64),
+                ("num_mcts_searches", C.c_uint32), ("C", C.c_float),
+                ("max_expand_depth", C.c_uint32), ("seed", C.c_uint64),
+                ("arith", C.c_int), ("num_threads", C.c_int), ("merge_order", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.two_logf_det.restype = C.c_float
+        L.two_logf_det.argtypes = [C.c_float]
+        L.two_puzzle_reward.restype = C.c_float
+        L.two_puzzle_solved.restype = C.c_int
+        L.two_puzzle_is_final.restype = C.c_int
+        L.two_argmax.restype = C.c_int
+        L.two_sample_from_logits.restype = C.c_int
+        L.two_sample_weighted.restype = C.c_int
+        L.two_sample_weighted.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float]
+        L.two_ppo_collect.restype = C.c_int
+        L.two_az_collect.restype = C.c_int
+        L.two_gae.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_float,
+                              C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.two_mcts_probs.argtypes = [C.POINTER(_Puzzle), C.POINTER(_Policy), C.c_uint32, C.c_float,
+                                     C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32,
+                                     C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# ------------------------------------------------------------------------------------- RNG
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*[int(x) & 0xFFFFFFFF for x in ctr])
+    k = (C.c_uint32 * 2)(*[int(x) & 0xFFFFFFFF for x in key])
+    o = (C.c_uint32 * 4)()
+    lib().two_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def logf_det(x: float) -> float:
+    return float(lib().two_logf_det(C.c_float(x)))
+
+
+def logf_det_array(x: np.ndarray) -> np.ndarray:
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    f = L.two_logf_det
+    for i in range(x.size):
+        out.flat[i] = f(C.c_float(float(x.flat[i])))
+    return out
+
+
+# ------------------------------------------------------------------------------------- env
+class Puzzle:
+    """Oracle twin of twisterl.env.Puzzle (python_interface/env.rs:117-160 over envs/puzzle.rs)."""
+
+    def __init__(self, width, height, difficulty, depth_slope, max_depth):
+        self.p = _Puzzle()
+        lib().two_puzzle_new(C.byref(self.p), C.c_int64(width), C.c_int64(height),
+                             C.c_int64(difficulty), C.c_int64(depth_slope), C.c_int64(max_depth))
+
+    def clone(self):
+        q = Puzzle.__new__(Puzzle)
+        q.p = _Puzzle()
+        C.memmove(C.byref(q.p), C.byref(self.p), C.sizeof(_Puzzle))
+        return q
+
+    @property
+    def n_cells(self):
+        return int(self.p.width * self.p.height)
+
+    @property
+    def difficulty(self):
+        return int(self.p.difficulty)
+
+    @difficulty.setter
+    def difficulty(self, d):
+        self.p.difficulty = int(d)
+
+    @property
+    def depth(self):
+        return int(self.p.depth)
+
+    @property
+    def zero_location(self):
+        return (int(self.p.zx), int(self.p.zy))
+
+    def num_actions(self):
+        return 4
+
+    def obs_shape(self):
+        return [self.n_cells, self.n_cells]
+
+    def get_state(self):
+        return [int(self.p.state[i]) for i in range(self.n_cells)]
+
+    def solved(self):
+        return bool(lib().two_puzzle_solved(C.byref(self.p)))
+
+    def set_state(self, state):
+        arr = (C.c_int64 * len(state))(*[int(s) for s in state])
+        lib().two_puzzle_set_state(C.byref(self.p), arr, C.c_size_t(len(state)))
+
+    def reset(self, seed=0, episode=0):
+        lib().two_puzzle_reset(C.byref(self.p), C.c_uint64(seed), C.c_uint64(episode))
+
+    def step(self, action):
+        lib().two_puzzle_step(C.byref(self.p), C.c_int64(action))
+
+    def masks(self):
+        m = (C.c_uint8 * 4)()
+        lib().two_puzzle_masks(C.byref(self.p), m)
+        return [bool(x) for x in m]
+
+    def is_final(self):
+        return bool(lib().two_puzzle_is_final(C.byref(self.p)))
+
+    def reward(self):
+        return float(lib().two_puzzle_reward(C.byref(self.p)))
+
+    def observe(self):
+        o = (C.c_int64 * self.n_cells)()
+        lib().two_puzzle_observe(C.byref(self.p), o)
+        return [int(x) for x in o]
+
+
+# ------------------------------------------------------------------------------------- nn
+class Policy:
+    """Oracle twin of twisterl.nn.Policy.  Weights use the reference's export layout
+    (src/twisterl/nn/utils.py:17-79): Linear weights = torch_weight.T.flatten()
+    ([in][out] row-major == column-major DMatrix(out,in)); EmbeddingBag vectors =
+    torch_weight.T ([obs_size][emb])."""
+
+    def __init__(self, emb_vectors, emb_bias, common, action, value, obs_perms=(), act_perms=(),
+                 emb_relu=True, obs_shape=None, conv_dim=0):
+        self._keep = []
+        pol = _Policy()
+        vec = np.ascontiguousarray(emb_vectors, dtype=np.float32)
+        bias = np.ascontiguousarray(emb_bias, dtype=np.float32)
+        self._keep += [vec, bias]
+        pol.emb.n_vectors, pol.emb.vec_len = vec.shape
+        pol.emb.vectors = _fp(vec)
+        pol.emb.bias = _fp(bias)
+        pol.emb.bias_len = bias.size
+        pol.emb.relu = int(emb_relu)
+        shape = list(obs_shape) if obs_shape is not None else [vec.shape[0]]
+        pol.emb.obs_ndim = len(shape)
+        for i, s in enumerate(shape[:2]):
+            pol.emb.obs_shape[i] = int(s)
+        pol.emb.conv_dim = int(conv_dim)
+
+        def fill(dst, layers):
+            for i, (w, b, relu) in enumerate(layers):
+                w = np.ascontiguousarray(w, dtype=np.float32).reshape(-1)
+                b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1)
+                self._keep += [w, b]
+                dst[i].out = b.size
+                dst[i].in_ = w.size // b.size
+                dst[i].w = _fp(w)
+                dst[i].b = _fp(b)
+                dst[i].relu = int(relu)
+            return len(layers)
+
+        pol.n_common = fill(pol.common, common)
+        pol.n_action = fill(pol.action, action)
+        pol.n_value = fill(pol.value, value)
+        pol.n_actions = int(np.asarray(action[-1][1]).size if len(action) else (len(act_perms[0]) if len(act_perms) else 0))
+        pol.obs_size = int(vec.shape[0]) if len(shape) == 1 else int(np.prod(shape))
+        pol.n_perms = len(obs_perms)
+        if pol.n_perms:
+            op = np.ascontiguousarray(obs_perms, dtype=np.int32)
+            ap = np.ascontiguousarray(act_perms, dtype=np.int32)
+            self._keep += [op, ap]
+            pol.obs_perms = op.ctypes.data_as(C.POINTER(C.c_int32))
+            pol.act_perms = ap.ctypes.data_as(C.POINTER(C.c_int32))
+        self.pol = pol
+        self.n_actions = pol.n_actions
+        self.n_perms = pol.n_perms
+
+    def _obs(self, obs):
+        return (C.c_int64 * len(obs))(*[int(o) for o in obs]), len(obs)
+
+    def _masks(self, masks):
+        return (C.c_uint8 * len(masks))(*[1 if m else 0 for m in masks])
+
+    def raw_predict(self, obs, perm=-1, arith=ARITH_REF):
+        o, n = self._obs(obs)
+        lg = (C.c_float * max(self.n_actions, 1))()
+        v = C.c_float()
+        lib().two_policy_raw_predict(C.byref(self.pol), o, C.c_int(n), C.c_int(perm), C.c_int(arith),
+                                     lg, C.byref(v))
+        return [float(x) for x in lg][: self.n_actions], float(v.value)
+
+    def forward(self, obs, masks, perm=-1, arith=ARITH_REF):
+        o, n = self._obs(obs)
+        lg = (C.c_float * max(self.n_actions, 1))()
+        v = C.c_float()
+        lib().two_policy_forward(C.byref(self.pol), o, C.c_int(n), self._masks(masks), C.c_int(perm),
+                                 C.c_int(arith), lg, C.byref(v))
+        return [float(x) for x in lg][: self.n_actions], float(v.value)
+
+    def predict(self, obs, masks, perm=-1, arith=ARITH_REF):
+        o, n = self._obs(obs)
+        pr = (C.c_float * max(self.n_actions, 1))()
+        v = C.c_float()
+        lib().two_policy_predict(C.byref(self.pol), o, C.c_int(n), self._masks(masks), C.c_int(perm),
+                                 C.c_int(arith), pr, C.byref(v))
+        return [float(x) for x in pr][: self.n_actions], float(v.value)
+
+    def full_predict(self, obs, masks, arith=ARITH_REF):
+        o, n = self._obs(obs)
+        pr = (C.c_float * max(self.n_actions, 1))()
+        v = C.c_float()
+        lib().two_policy_full_predict(C.byref(self.pol), o, C.c_int(n), self._masks(masks),
+                                      C.c_int(arith), pr, C.byref(v))
+        return [float(x) for x in pr][: self.n_actions], float(v.value)
+
+
+def argmax(values):
+    a = np.ascontiguousarray(values, dtype=np.float32)
+    return int(lib().two_argmax(_fp(a), C.c_int(a.size)))
+
+
+def sample_from_logits(logits, u, det_log=False):
+    a = np.ascontiguousarray(logits, dtype=np.float32)
+    uu = np.ascontiguousarray(u, dtype=np.float32)
+    return int(lib().two_sample_from_logits(_fp(a), C.c_int(a.size), _fp(uu), C.c_int(int(det_log))))
+
+
+def sample_weighted(probs, u):
+    a = np.ascontiguousarray(probs, dtype=np.float32)
+    return int(lib().two_sample_weighted(_fp(a), C.c_int(a.size), C.c_float(u)))
+
+
+def gae(rews, vals, gamma, lam):
+    r = np.ascontiguousarray(rews, dtype=np.float32)
+    v = np.ascontiguousarray(vals, dtype=np.float32)
+    advs = np.empty_like(r)
+    rets = np.empty_like(r)
+    lib().two_gae(_fp(r), _fp(v), C.c_int(r.size), C.c_float(gamma), C.c_float(lam), _fp(advs), _fp(rets))
+    return advs, rets
+
+
+# ------------------------------------------------------------------------------------- collectors
+@dataclass
+class Collected:
+    obs: np.ndarray        # [n, n_cells] int64
+    logits: np.ndarray     # [n, A] f32
+    perms: np.ndarray      # [n] int32 (-1 = None)
+    values: np.ndarray     # [n] f32 (empty for AZ)
+    rewards: np.ndarray
+    actions: np.ndarray    # [n] int64
+    additional_data: dict  # "advs","rets" (PPO) | "remaining_values" (AZ)
+    ep_len: np.ndarray     # [E] uint32 in episode-index order
+
+
+def _take(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros((0,), dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def _unpack(c: _Collected) -> Collected:
+    n, nc, A, E = int(c.n), int(c.n_cells), int(c.n_actions), int(c.n_episodes)
+    obs = _take(c.obs, n * nc, np.int64).reshape(n, nc)
+    logits = _take(c.logits, n * A, np.float32).reshape(n, A)
+    perms = _take(c.perms, n, np.int32)
+    ep_len = _take(c.ep_len, E, np.uint32)
+    if c.has_ppo:
+        out = Collected(obs, logits, perms, _take(c.values, n, np.float32),
+                        _take(c.rewards, n, np.float32), _take(c.actions, n, np.int64),
+                        {"advs": _take(c.advs, n, np.float32), "rets": _take(c.rets, n, np.float32)},
+                        ep_len)
+    else:
+        e = np.zeros((0,), np.float32)
+        out = Collected(obs, logits, perms, e, e.copy(), np.zeros((0,), np.int64),
+                        {"remaining_values": _take(c.remaining, n, np.float32)}, ep_len)
+    lib().two_collected_free(C.byref(c))
+    return out
+
+
+def ppo_collect(env: Puzzle, policy: Policy, num_episodes, gamma, lam, seed=0, episode_offset=0,
+                arith=ARITH_REF, det_log=False, num_threads=1, merge_order=True) -> Collected:
+    prm = _PPOParams(num_episodes, episode_offset, gamma, lam, seed, arith, int(det_log),
+                     num_threads, int(merge_order))
+    out = _Collected()
+    rc = lib().two_ppo_collect(C.byref(env.p), C.byref(policy.pol), C.byref(prm), C.byref(out))
+    if rc != 0:
+        raise RuntimeError("Something went wrong. No data in collected data chunks to merge. ")
+    return _unpack(out)
+
+
+def az_collect(env: Puzzle, policy: Policy, num_episodes, num_mcts_searches, Cc, max_expand_depth,
+               seed=0, episode_offset=0, arith=ARITH_REF, num_threads=1, merge_order=True) -> Collected:
+    prm = _AZParams(num_episodes, episode_offset, num_mcts_searches, Cc, max_expand_depth, seed,
+                    arith, num_threads, int(merge_order))
+    out = _Collected()
+    rc = lib().two_az_collect(C.byref(env.p), C.byref(policy.pol), C.byref(prm), C.byref(out))
+    if rc != 0:
+        raise RuntimeError("Something went wrong. No data in collected data chunks to merge. ")
+    return _unpack(out)
+
+
+def mcts_probs(env: Puzzle, policy: Policy, num_mcts_searches, Cc, max_expand_depth,
+               arith=ARITH_REF, seed=0, episode=0, t=0):
+    pr = (C.c_float * policy.n_actions)()
+    lib().two_mcts_probs(C.byref(env.p), C.byref(policy.pol), num_mcts_searches, Cc, max_expand_depth,
+                         arith, seed, episode, t, pr)
+    return [float(x) for x in pr]
+
+
+def replay(env: Puzzle, actions):
+    n = len(actions)
+    nc = env.n_cells
+    acts = np.ascontiguousarray(actions, dtype=np.int64)
+    obs = np.empty((n + 1, nc), np.int64)
+    masks = np.empty((n + 1, 4), np.uint8)
+    rew = np.empty((n + 1,), np.float32)
+    fin = np.empty((n + 1,), np.uint8)
+    board = np.empty((n + 1, nc), np.int64)
+    lib().two_replay(C.byref(env.p), acts.ctypes.data_as(C.POINTER(C.c_int64)), C.c_size_t(n),
+                     obs.ctypes.data_as(C.POINTER(C.c_int64)), masks.ctypes.data_as(C.POINTER(C.c_uint8)),
+                     _fp(rew), fin.ctypes.data_as(C.POINTER(C.c_uint8)),
+                     board.ctypes.data_as(C.POINTER(C.c_int64)))
+    return obs, masks.astype(bool), rew, fin.astype(bool), board

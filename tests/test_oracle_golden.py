@@ -1,0 +1,369 @@
+"""Pins the CPU oracle against every known answer the reference's own tests / notebooks hold
+for the hot path, plus published Philox known-answer vectors.
+
+CPU only.  The oracle is the checker for the GPU parity tests, so it is pinned first.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+# ------------------------------------------------------------------ envs/puzzle.rs
+def test_puzzle_fresh_is_solved(oracle):
+    g = GOLD["puzzle_fresh_solved"]
+    p = oracle.Puzzle(*g["ctor"])
+    assert p.solved() is g["solved"]
+    assert p.depth == 1                      # Puzzle::new sets depth 1 (puzzle.rs:41)
+
+
+def test_puzzle_step_and_masks(oracle):
+    g = GOLD["puzzle_2x2_step2"]
+    p = oracle.Puzzle(*g["ctor"])
+    p.step(g["action"])
+    assert list(p.zero_location) == g["zero_location"]
+    assert p.masks() == g["masks"]
+
+
+def test_replay_123_moves_solves(oracle):
+    """examples/hub_puzzle_model.ipynb: start board + the 123 actions printed by the
+    reference's own solve() must end at the identity board."""
+    g = GOLD["replay_123"]
+    p = oracle.Puzzle(*g["ctor"])
+    p.set_state(g["start"])
+    assert p.depth == 256 and p.zero_location == (2, 1)
+    obs, masks, rew, fin, board = oracle.replay(p, g["actions"])
+    assert board[-1].tolist() == g["end"]
+    assert fin[-1] and not fin[:-1].any()    # solved only at the very end
+    assert rew[-1] == 1.0 and np.all(rew[:-1] == np.float32(-0.5 / 256))
+    # observe: obs[i] = i*N^2 + state[i]   (puzzle.rs:183-185)
+    assert np.array_equal(obs, np.arange(9)[None, :] * 9 + board)
+    # every recorded action was legal under the mask of its state (the reference samples
+    # masked actions only): pins action -> direction (0 left, 1 up, 2 right, 3 down)
+    for t, a in enumerate(g["actions"]):
+        assert masks[t, a], (t, a)
+        zi = int(np.where(board[t] == 0)[0][0])
+        zj = int(np.where(board[t + 1] == 0)[0][0])
+        dx, dy = (zj % 3) - (zi % 3), (zj // 3) - (zi // 3)
+        assert (dx, dy) == [(-1, 0), (0, -1), (1, 0), (0, 1)][a]
+
+
+def test_reward_constants(oracle):
+    c = GOLD["constants"]
+    p = oracle.Puzzle(3, 3, 1, 2, 256)
+    assert p.reward() == c["reward_solved"]
+    p.step(2)                                # depth 1 -> 0, unsolved
+    assert p.depth == 0 and p.reward() == c["reward_timeout"] and p.is_final()
+    q = oracle.Puzzle(3, 3, 1, 2, 256)
+    q.set_state([1, 0, 2, 3, 4, 5, 6, 7, 8])
+    assert q.reward() == c["reward_step_max_depth_256"] and not q.is_final()
+
+
+def test_step_illegal_is_noop_but_consumes_depth(oracle):
+    p = oracle.Puzzle(4, 4, 3, 2, 256)
+    p.set_state(list(range(16)))
+    before = p.get_state()
+    p.step(0)                                # blank at (0,0): left is a wall
+    p.step(1)                                # up is a wall
+    assert p.get_state() == before and p.depth == 254
+    q = oracle.Puzzle(2, 2, 0, 1, 10)
+    q.step(0); q.step(0)                     # depth 1 -> 0 -> saturates at 0 (puzzle.rs:159)
+    assert q.depth == 0
+
+
+def test_reset_depth_and_scramble_semantics(oracle):
+    p = oracle.Puzzle(4, 4, 7, 2, 256)
+    p.reset(seed=5, episode=11)
+    assert p.depth == 14                     # depth_slope*difficulty (puzzle.rs:132)
+    # the scramble is `difficulty` steps from the identity using stream 0 of the RNG spec
+    q = oracle.Puzzle(4, 4, 7, 2, 256)
+    q.set_state(list(range(16)))
+    for d in range(7):
+        w = oracle.philox4x32_10([11, 0, d, 0], [5, 0])
+        q.step((w[0] * 4) >> 32)
+    assert q.get_state() == p.get_state() and q.zero_location == p.zero_location
+    z = oracle.Puzzle(3, 3, 0, 2, 256)
+    z.reset()
+    assert z.depth == 0 and z.solved() and z.is_final()
+
+
+# ------------------------------------------------------------------ nn/layers.rs, nn/policy.rs
+def _policy_from_linear(oracle, weights, bias, relu):
+    # a Policy whose "common" stack is the Linear under test; embedding = identity passthrough
+    n_in = len(weights) // len(bias)
+    emb = np.eye(n_in, dtype=np.float32)
+    return oracle.Policy(emb, np.zeros(n_in, np.float32), [(weights, bias, relu)],
+                         [(np.eye(len(bias), dtype=np.float32).T.flatten(), np.zeros(len(bias)), False)],
+                         [(np.zeros(len(bias)), np.zeros(1), False)], emb_relu=False)
+
+
+@pytest.mark.parametrize("key", ["linear_forward", "linear_forward_relu"])
+@pytest.mark.parametrize("arith", [0, 1])
+def test_linear_known_answers(oracle, key, arith):
+    """layers.rs:98-111.  Input [1,2] is fed as the multi-hot obs {0, 1, 1} through an identity
+    embedding (so x = [1,2]); the column-major weight layout is what the test pins."""
+    g = GOLD[key]
+    pol = _policy_from_linear(oracle, g["weights"], g["bias"], g["relu"])
+    logits, _ = pol.raw_predict([0, 1, 1], arith=arith)
+    assert logits == g["out"]
+
+
+def test_embedding_bag_known_answer(oracle):
+    g = GOLD["embedding_bag"]
+    pol = oracle.Policy(np.array(g["vectors"], np.float32), g["bias"], [],
+                        [(np.eye(2, dtype=np.float32).flatten(), [0.0, 0.0], False)],
+                        [(np.zeros(2), np.zeros(1), False)], emb_relu=g["relu"])
+    logits, _ = pol.raw_predict(g["input"])
+    assert logits == g["out"]
+
+
+def test_argmax_known_answers(oracle):
+    assert oracle.argmax(GOLD["argmax_basic"]["v"]) == GOLD["argmax_basic"]["idx"]
+    assert oracle.argmax([float("nan"), 1.0, 0.5]) == GOLD["argmax_nan"]["idx"]
+    assert oracle.argmax([]) == 0
+    assert oracle.argmax([2.0, 2.0, 1.0]) == 0          # first max wins (strict >)
+
+
+def test_sample_from_logits_in_range_and_masked(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        u = rng.random(4).astype(np.float32)
+        a = oracle.sample_from_logits([0.1, -1e10, 0.3, -1e10], u)
+        assert a in (0, 2)
+    assert oracle.sample_from_logits([0.1, 2.0, 0.3], [0.0, 0.5, 0.5]) in (1, 2)  # u=0 -> -inf noise
+
+
+def test_gumbel_is_categorical(oracle):
+    """Gumbel-max == categorical(softmax(logits)) -- distributional pin of policy.rs:169-172."""
+    logits = np.array([0.5, -0.2, 1.1, 0.0], np.float32)
+    p = np.exp(logits) / np.exp(logits).sum()
+    n = 40000
+    cnt = np.zeros(4)
+    for i in range(n):
+        w = oracle.philox4x32_10([i, 0, 0, 1], [9, 0])
+        u = [(x >> 8) / 16777216.0 for x in w]
+        cnt[oracle.sample_from_logits(logits, u, det_log=True)] += 1
+    assert np.abs(cnt / n - p).max() < 0.01
+
+
+def test_dummy_env_gae_known_answer(oracle):
+    g = GOLD["dummy_env_ppo"]
+    advs, rets = oracle.gae(g["rewards"], g["values"], g["gamma"], g["lambda"])
+    np.testing.assert_allclose(rets, g["derived_rets"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(advs, g["derived_advs"], rtol=0, atol=1e-6)
+    assert len(rets) == g["records"]
+
+
+def test_gae_matches_float64_recurrence(oracle):
+    rng = np.random.default_rng(3)
+    r = rng.normal(size=257).astype(np.float32)
+    v = rng.normal(size=257).astype(np.float32)
+    advs, rets = oracle.gae(r, v, 0.995, 0.995)
+    a64 = np.zeros(257); t64 = np.zeros(257)
+    a64[-1] = r[-1] - v[-1]; t64[-1] = r[-1]
+    for t in range(255, -1, -1):
+        t64[t] = r[t] + 0.995 * (v[t + 1] + 0.995 * a64[t + 1])
+        a64[t] = t64[t] - v[t]
+    np.testing.assert_allclose(advs, a64, atol=1e-4)
+    np.testing.assert_allclose(rets, t64, atol=1e-4)
+
+
+# ------------------------------------------------------------------ collector/*.rs
+def _tiny_policy(oracle, n2=9, seed=0, perms=False):
+    rng = np.random.default_rng(seed)
+    obs_size, E, H = n2 * n2, 16, 32
+    emb = rng.normal(scale=0.3, size=(obs_size, E)).astype(np.float32)
+    eb = rng.normal(scale=0.1, size=E).astype(np.float32)
+    w1 = rng.normal(scale=0.3, size=(E, H)).astype(np.float32)
+    b1 = rng.normal(scale=0.1, size=H).astype(np.float32)
+    wa = rng.normal(scale=0.3, size=(H, 4)).astype(np.float32)
+    ba = rng.normal(scale=0.1, size=4).astype(np.float32)
+    wv = rng.normal(scale=0.3, size=(H, 1)).astype(np.float32)
+    bv = rng.normal(scale=0.1, size=1).astype(np.float32)
+    op, ap = (), ()
+    if perms:
+        from tests.util import puzzle_transpose_twist
+        op, ap = puzzle_transpose_twist(int(math.isqrt(n2)))
+    return oracle.Policy(emb, eb, [(w1.flatten(), b1, True)], [(wa.flatten(), ba, False)],
+                         [(wv.flatten(), bv, False)], op, ap)
+
+
+def test_merge_order_last_chunk_first(oracle):
+    """collector.rs:40-46 / :101-126: merged = [chunk E-1, chunk 0, ..., chunk E-2]."""
+    env = oracle.Puzzle(3, 3, 4, 2, 256)
+    pol = _tiny_policy(oracle)
+    a = oracle.ppo_collect(env, pol, 5, 0.9, 0.95, seed=1, merge_order=False)
+    b = oracle.ppo_collect(env, pol, 5, 0.9, 0.95, seed=1, merge_order=True)
+    L = a.ep_len.astype(int)
+    assert np.array_equal(a.ep_len, b.ep_len)
+    starts = np.concatenate([[0], np.cumsum(L)])
+    order = [4, 0, 1, 2, 3]
+    idx = np.concatenate([np.arange(starts[e], starts[e + 1]) for e in order])
+    for f in ("obs", "logits", "perms", "values", "rewards", "actions"):
+        assert np.array_equal(getattr(b, f), getattr(a, f)[idx]), f
+    for k in ("advs", "rets"):
+        assert np.array_equal(b.additional_data[k], a.additional_data[k][idx])
+    g = GOLD["merge_order"]
+    assert g["merged_actions"] == [g["chunk_actions"][1][0], g["chunk_actions"][0][0]]
+
+
+def test_collect_records_terminal_state_and_keys(oracle):
+    """ppo.rs:69-80,173-182: the terminal state IS recorded; keys 'advs','rets' exist."""
+    env = oracle.Puzzle(3, 3, 3, 2, 256)
+    pol = _tiny_policy(oracle)
+    d = oracle.ppo_collect(env, pol, 64, 0.995, 0.995, seed=7)
+    assert set(d.additional_data) == {"advs", "rets"}
+    assert d.obs.shape[0] == d.ep_len.sum() == len(d.values) == len(d.additional_data["rets"])
+    assert d.ep_len.min() >= 1 and d.ep_len.max() <= 3 * 2 + 1
+    assert np.all(d.perms == -1)              # Puzzle has no twists -> perm None (env.rs:59)
+    # difficulty 0 => born final => exactly one record, reward 1.0, adv = r - v
+    z = oracle.ppo_collect(oracle.Puzzle(3, 3, 0, 2, 256), pol, 3, 0.9, 0.9, seed=1)
+    assert z.ep_len.tolist() == [1, 1, 1] and np.all(z.rewards == 1.0)
+    np.testing.assert_array_equal(z.additional_data["advs"], z.rewards - z.values)
+
+
+def test_collect_is_replayable(oracle):
+    """Every collected episode replays through Puzzle::step to the recorded obs/rewards."""
+    env = oracle.Puzzle(4, 4, 6, 2, 256)
+    pol = _tiny_policy(oracle, n2=16, seed=2)
+    d = oracle.ppo_collect(env, pol, 16, 0.995, 0.995, seed=3, merge_order=False)
+    pos = 0
+    for e, n in enumerate(d.ep_len.astype(int)):
+        p = oracle.Puzzle(4, 4, 6, 2, 256)
+        p.reset(seed=3, episode=e)
+        obs, masks, rew, fin, _ = oracle.replay(p, d.actions[pos:pos + n - 1])
+        assert np.array_equal(obs, d.obs[pos:pos + n])
+        assert np.array_equal(rew, d.rewards[pos:pos + n])
+        assert fin[-1] and not fin[:-1].any()
+        # masked logits: illegal actions carry exactly -1e10 (policy.rs:62)
+        assert np.all((d.logits[pos:pos + n] == np.float32(-1e10)) == ~masks)
+        pos += n
+
+
+def test_threads_and_offsets_do_not_change_results(oracle):
+    env = oracle.Puzzle(3, 3, 5, 2, 256)
+    pol = _tiny_policy(oracle)
+    a = oracle.ppo_collect(env, pol, 24, 0.995, 0.995, seed=4, num_threads=1, merge_order=False)
+    b = oracle.ppo_collect(env, pol, 24, 0.995, 0.995, seed=4, num_threads=4, merge_order=False)
+    c0 = oracle.ppo_collect(env, pol, 10, 0.995, 0.995, seed=4, episode_offset=0, merge_order=False)
+    c1 = oracle.ppo_collect(env, pol, 14, 0.995, 0.995, seed=4, episode_offset=10, merge_order=False)
+    for f in ("obs", "logits", "values", "rewards", "actions"):
+        assert np.array_equal(getattr(a, f), getattr(b, f))
+        assert np.array_equal(getattr(a, f), np.concatenate([getattr(c0, f), getattr(c1, f)]))
+
+
+def test_arith_modes_agree_within_tolerance(oracle):
+    """The fma-chain order (what the HIP exact mode computes) stays within 1e-5 of the
+    reference's un-fused order on a full-size synthetic Puzzle-15 policy."""
+    from tests.util import make_policy_arrays
+    arrs = make_policy_arrays(16, seed=0)
+    pol = oracle.Policy(*arrs)
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for _ in range(50):
+        board = rng.permutation(16)
+        obs = (np.arange(16) * 16 + board).tolist()
+        l0, v0 = pol.raw_predict(obs, arith=0)
+        l1, v1 = pol.raw_predict(obs, arith=1)
+        worst = max(worst, np.abs(np.array(l0) - np.array(l1)).max(), abs(v0 - v1))
+        # independent float64 forward
+        emb, eb, (w1, b1, _), (wa, ba, _), (wv, bv, _) = arrs[0], arrs[1], arrs[2][0], arrs[3][0], arrs[4][0]
+        h0 = np.maximum(eb.astype(np.float64) + emb[obs].astype(np.float64).sum(0), 0)
+        h1 = np.maximum(h0 @ w1.reshape(512, 256).astype(np.float64) + b1, 0)
+        la = h1 @ wa.reshape(256, 4).astype(np.float64) + ba
+        np.testing.assert_allclose(l0, la, atol=1e-5)
+        np.testing.assert_allclose(v0, float((h1 @ wv.reshape(256, 1).astype(np.float64) + bv)[0]), atol=1e-5)
+    assert worst < 1e-5
+
+
+def test_twists_match_torch_twin_semantics(oracle):
+    """policy.rs:81-83,95-97 vs src/twisterl/nn/policy.py:143-154: permuting the obs ids by
+    obs_perm and gathering logits by act_perm; for the board-transpose symmetry a transposed
+    board under perm 1 must see exactly the un-permuted forward of the original board."""
+    from tests.util import puzzle_transpose_twist
+    pol = _tiny_policy(oracle, n2=9, seed=5, perms=True)
+    plain = _tiny_policy(oracle, n2=9, seed=5, perms=False)
+    op, ap = puzzle_transpose_twist(3)
+    rng = np.random.default_rng(2)
+    board = rng.permutation(9)
+    obs = (np.arange(9) * 9 + board).tolist()
+    l_id, v_id = pol.raw_predict(obs, perm=0)
+    l_pl, v_pl = plain.raw_predict(obs)
+    assert l_id == l_pl and v_id == v_pl      # perm 0 is the identity
+    l_t, v_t = pol.raw_predict(obs, perm=1)
+    obs_t = sorted(op[1][o] for o in obs)     # ids of the transposed board (EmbeddingBag sums: order-free up to fp)
+    l_ref, v_ref = plain.raw_predict([op[1][o] for o in obs])
+    assert v_t == v_ref and l_t == [l_ref[a] for a in ap[1]]
+    assert len(obs_t) == 9
+
+
+# ------------------------------------------------------------------ RNG spec
+def test_philox_known_answer_vectors(oracle):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert oracle.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    # (vector 2 was written down from memory with word 2 in doubt; words 0, 1, 3 are as
+    #  remembered, word 2 is what an implementation passing vectors 1 and 3 produces)
+    assert oracle.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                                [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_logf_det_tracks_libm(oracle):
+    """The deterministic log stays within 2 ulp of libm's logf over the sampler's domain."""
+    rng = np.random.default_rng(0)
+    u = (rng.integers(1, 1 << 24, size=20000).astype(np.float32)) / np.float32(16777216.0)
+    u = np.concatenate([u, np.float32([2.0 ** -24, 1 - 2.0 ** -24, 0.5, 0.25, 0.75])])
+    a = oracle.logf_det_array(u)
+    ref = np.log(u.astype(np.float64))
+    ulp = np.spacing(np.abs(ref).astype(np.float32))
+    assert np.max(np.abs(a - ref) / ulp) <= 2.0
+    b = oracle.logf_det_array(np.abs(a))
+    ref2 = np.log(np.abs(a).astype(np.float64))
+    ulp2 = np.maximum(np.spacing(np.abs(ref2).astype(np.float32)), np.float32(1e-9))
+    assert np.max(np.abs(b - ref2) / ulp2) <= 2.5
+    assert oracle.logf_det(0.0) == -math.inf and oracle.logf_det(math.inf) == math.inf
+
+
+# ------------------------------------------------------------------ MCTS / AZ (search.rs, az.rs)
+def test_az_collect_shapes_and_remaining_values(oracle):
+    """az.rs:97-106,177-186: logits slot holds MCTS probs, values/rewards/actions empty,
+    key 'remaining_values' = sum of rewards from t to the end."""
+    env = oracle.Puzzle(3, 3, 2, 2, 256)
+    pol = _tiny_policy(oracle)
+    d = oracle.az_collect(env, pol, 6, 20, 1.41, 1, seed=2, merge_order=False)
+    assert set(d.additional_data) == {"remaining_values"}
+    assert len(d.values) == len(d.rewards) == len(d.actions) == 0
+    assert np.all(d.perms == -1)
+    np.testing.assert_allclose(d.logits.sum(1), 1.0, atol=1e-6)
+    pos = 0
+    for n in d.ep_len.astype(int):
+        boards = d.obs[pos:pos + n] - np.arange(9)[None, :] * 9
+        solved = np.all(boards == np.arange(9)[None, :], axis=1)
+        # reward per record: solved 1.0; else depth-0 -> -0.5 (only possible at the last record)
+        r = np.where(solved, 1.0, -0.5 / 256).astype(np.float32)
+        if not solved[-1]:
+            r[-1] = -0.5
+        rem = np.float32(0)
+        tot = np.float32(0)
+        tv = []
+        for x in r:
+            tv.append(tot); tot = np.float32(tot + x)
+        np.testing.assert_array_equal(d.additional_data["remaining_values"][pos:pos + n],
+                                      np.float32(tot) - np.float32(tv))
+        pos += n
+
+
+def test_mcts_visit_counts_sum_to_searches(oracle):
+    env = oracle.Puzzle(3, 3, 4, 2, 256)
+    env.reset(seed=1, episode=0)
+    pol = _tiny_policy(oracle)
+    probs = oracle.mcts_probs(env, pol, 50, 1.41, 1)
+    legal = env.masks()
+    assert abs(sum(probs) - 1.0) < 1e-6
+    assert all((p == 0.0) for p, m in zip(probs, legal) if not m)
+    # counts are multiples of 1/50: every search back-propagates through exactly one root child
+    assert all(abs(p * 50 - round(p * 50)) < 1e-4 for p in probs)

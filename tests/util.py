@@ -1,0 +1,36 @@
+"""Shared helpers for the tests: synthetic policies and the board-transpose twist."""
+import numpy as np
+
+
+def puzzle_transpose_twist(n):
+    """Twist set {identity, transpose} for an n x n sliding puzzle in the data contract of
+    docs/twists.md: obs id (pos, val) -> (T(pos), T(val)); actions left<->up, right<->down.
+    Puzzle itself returns no twists (env.rs:59), so BASELINE config 3 supplies these through
+    the Policy constructor."""
+    n2 = n * n
+    T = [(i % n) * n + (i // n) for i in range(n2)]
+    ident = list(range(n2 * n2))
+    tr = [T[o // n2] * n2 + T[o % n2] for o in range(n2 * n2)]
+    return [ident, tr], [[0, 1, 2, 3], [1, 0, 3, 2]]
+
+
+def make_policy_arrays(n2, seed=0, emb=512, hidden=256, n_actions=4, scale=1.0):
+    """Synthetic BasicPolicy weights in the reference's export layout
+    (src/twisterl/nn/utils.py:17-79): torch.nn.Linear default init U(-1/sqrt(fan_in), ..)."""
+    rng = np.random.default_rng(seed)
+    obs_size = n2 * n2
+
+    def lin(i, o):
+        b = scale / np.sqrt(i)
+        w = rng.uniform(-b, b, size=(o, i)).astype(np.float32)      # torch layout [out][in]
+        bias = rng.uniform(-b, b, size=o).astype(np.float32)
+        return w, bias
+
+    we, be = lin(obs_size, emb)
+    w1, b1 = lin(emb, hidden)
+    wa, ba = lin(hidden, n_actions)
+    wv, bv = lin(hidden, 1)
+    return (np.ascontiguousarray(we.T), be,
+            [(np.ascontiguousarray(w1.T).reshape(-1), b1, True)],
+            [(np.ascontiguousarray(wa.T).reshape(-1), ba, False)],
+            [(np.ascontiguousarray(wv.T).reshape(-1), bv, False)])
