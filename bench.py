@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the Puzzle-15 PPO rollout on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one full `PPOCollector.collect()` over the workload: reset+scramble, the fused
+step/observe/reward/mask + policy forward + Gumbel sampling rollout, the GAE pass, compaction into
+the reference merge order, and (N > 1) the RCCL gather of the finished trajectories to rank 0.
+1 env-step = 1 trajectory record.  Weak scaling: every GPU gets --envs episodes.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     dominant kernel (rollout) against the f32 MFMA peak, measured with HIP events
+                  around the kernel on its own stream (tw_collect_stats.ms_rollout)
+  "cpu_baseline": the CPU oracle (reference algorithm restated in C, rayon pool -> pthreads)
+                  timed on this box's host cores over a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+FLOP_PER_RECORD = {16: 272_896, 9: 269_312}
+BYTES_PER_RECORD = {16: 58, 9: 51}
+PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0}     # MI355X_MICROARCH.md: f32 MFMA (=vector) / dense f16 MFMA
+
+
+def synthetic_weights(n2: int, seed: int = 0):
+    """torch default-init weights of BasicPolicy(obs n2*n2 -> 512 -> 256 -> 4|1) under
+    torch.manual_seed(seed), exported in the reference layout (src/twisterl/nn/utils.py:17-79)."""
+    import torch
+    torch.manual_seed(seed)
+    emb = torch.nn.Linear(n2 * n2, 512)
+    common = torch.nn.Linear(512, 256)
+    action = torch.nn.Linear(256, 4)
+    value = torch.nn.Linear(256, 1)
+    f = lambda t: np.ascontiguousarray(t.detach().numpy(), dtype=np.float32)
+    return (f(emb.weight.T), f(emb.bias),
+            [(f(common.weight.T).reshape(-1), f(common.bias), True)],
+            [(f(action.weight.T).reshape(-1), f(action.bias), False)],
+            [(f(value.weight.T).reshape(-1), f(value.bias), False)])
+
+
+def transpose_twist(n: int):
+    n2 = n * n
+    T = [(i % n) * n + (i // n) for i in range(n2)]
+    return ([list(range(n2 * n2)), [T[o // n2] * n2 + T[o % n2] for o in range(n2 * n2)]],
+            [[0, 1, 2, 3], [1, 0, 3, 2]])
+
+
+def build_policy(arrs, obs_perms, act_perms):
+    from twisterl_amd import twisterl
+    emb, eb, common, action, value = arrs
+    seq = lambda ls: twisterl.nn.Sequential([twisterl.nn.Linear(w, b, r) for (w, b, r) in ls])
+    return twisterl.nn.Policy(twisterl.nn.EmbeddingBag(emb, eb, True, [emb.shape[0]], 0), seq(common), seq(action),
+                              seq(value), obs_perms, act_perms)
+
+
+def cpu_baseline(arrs, obs_perms, act_perms, side, difficulty, target_seconds):
+    """Times the CPU oracle (kind 'port': the reference binary cannot be built here) on all host
+    cores over a bounded sample of the same workload."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    pol = O.Policy(*arrs, obs_perms, act_perms)
+    env = O.Puzzle(side, side, difficulty, 2, 256)
+    run = lambda E, seed: O.ppo_collect(env, pol, E, 0.995, 0.995, seed=seed, arith=O.ARITH_REF, det_log=False,
+                                        num_threads=cores, merge_order=True)
+    pilot_E = 4 * cores
+    t0 = time.perf_counter(); d = run(pilot_E, 1); dt = time.perf_counter() - t0
+    rate = len(d.values) / dt
+    E = int(max(pilot_E, min(1 << 16, rate * target_seconds / max(1.0, len(d.values) / pilot_E))))
+    t0 = time.perf_counter(); d = run(E, 2); dt = time.perf_counter() - t0
+    return {"value": len(d.values) / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{E} episodes ({len(d.values)} records) of the same Puzzle workload, reference-order f32 "
+                      f"arithmetic, {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=262_144, help="episodes per GPU per step")
+    ap.add_argument("--puzzle", type=int, default=15, choices=[8, 15])
+    ap.add_argument("--difficulty", type=int, default=128)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--no-twists", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import twisterl_amd
+    from twisterl_amd import _lib, twisterl
+    if twisterl_amd.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP collector has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    _lib.check(_lib.lib().tw_set_device(local_rank))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        from twisterl_amd.dist import collect_sharded
+
+    side = 4 if args.puzzle == 15 else 3
+    n2 = side * side
+    arrs = synthetic_weights(n2, seed=0)
+    obs_perms, act_perms = ([], []) if args.no_twists else transpose_twist(side)
+    policy = build_policy(arrs, obs_perms, act_perms)
+    env = twisterl.env.Puzzle(side, side, args.difficulty, 2, 256)
+    E_total = args.envs * world
+    coll = twisterl.collector.PPOCollector(**{"num_episodes": E_total, "gamma": 0.995, "lambda": 0.995, "num_cores": 32},
+                                           precision=args.precision)
+
+    def step(i):
+        seed = 1000 + i
+        if world > 1:
+            merged, data = collect_sharded(coll, env, policy, seed=seed, dst=0)
+            n = len(data)
+            del merged
+            return n, data.stats
+        data = coll.collect(env, policy, seed=seed)
+        return len(data), data.stats
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    records, ms_rollout = 0, []
+    for i in range(args.steps):
+        n, st = step(args.warmup + i)
+        records += n
+        ms_rollout.append(st["ms_rollout"])
+    fence()
+    dt = time.perf_counter() - t0
+
+    rec_t = torch.tensor([float(records)], device="cuda")
+    dt_t = torch.tensor([dt], device="cuda")
+    if dist is not None:
+        dist.all_reduce(rec_t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    total_records, wall = float(rec_t.item()), float(dt_t.item())
+
+    if rank == 0:
+        kern_s = float(np.mean(ms_rollout)) * 1e-3
+        rec_per_launch = records / args.steps
+        achieved = rec_per_launch * FLOP_PER_RECORD[n2] / kern_s / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        out = {
+            "metric": "env-steps/s (whole node) Puzzle-15 PPO rollout" if args.puzzle == 15 else "env-steps/s Puzzle-8 PPO rollout",
+            "value": total_records / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Puzzle-{args.puzzle} PPO rollout + GAE + merge: {args.envs} envs/GPU, difficulty {args.difficulty} "
+                            f"(<= {2 * args.difficulty + 1} records/episode), twists "
+                            f"{'none' if args.no_twists else '{identity, transpose}'}, BasicPolicy {n2 * n2}->512->256->4|1, "
+                            f"gamma=lambda=0.995, torch-default-init weights seed 0",
+                "envs_per_gpu": args.envs, "records_per_step": rec_per_launch * world, "parallelism": f"episodes sharded x{world}",
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": "tw::rollout_f32_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
+                "kernel_ms": kern_s * 1e3, "flop_per_record": FLOP_PER_RECORD[n2],
+                "hbm_bytes_per_record": BYTES_PER_RECORD[n2],
+                "hbm_frac": rec_per_launch * BYTES_PER_RECORD[n2] / kern_s / 8e12,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,225 @@
+/*
+ * twisterl_hip.h -- C ABI of the MI355X-native twisteRL episode collector.
+ *
+ * This is the drop-in boundary for ONE hot path of AI4quantum/twisteRL: the vectorised
+ * episode collection (Puzzle step/observe/reward/masks loop + policy forward + Gumbel
+ * sampling + GAE + merge), i.e. what `Collector::collect(&Box<dyn Env>, &Policy)`
+ * (rust/src/collector/collector.rs:92-95) does for `PPOCollector` / `AZCollector`.
+ * Plain pointers and sizes only; no torch / pybind types.  All compute entry points run
+ * hand-written HIP kernels on the current gfx950 device and FAIL (status != TW_OK, message in
+ * tw_last_error()) when no GPU is available -- there is no CPU fallback in this library.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   tw_puzzle_*            PyBaseEnv / Puzzle pymethods   rust/src/python_interface/env.rs:44-160
+ *                          over Env for Puzzle            rust/src/envs/puzzle.rs:81-187
+ *   tw_policy_create       Policy::new + Linear/EmbeddingBag/Sequential ctors
+ *                                                         rust/src/python_interface/policy.rs:28-31,
+ *                                                         layers.rs:29-32,45-48, modules.rs:28-32
+ *   tw_policy_evaluate     Policy.predict/forward/full_predict
+ *                                                         rust/src/python_interface/policy.rs:33-45
+ *   tw_ppo_collect         PyBaseCollector.collect -> PPOCollector::collect
+ *                                                         rust/src/python_interface/collector.rs:147-151,
+ *                                                         rust/src/collector/ppo.rs:108-126
+ *   tw_az_collect          ... -> AZCollector::collect    rust/src/collector/az.rs:112-130
+ *   tw_collected_*         PyCollectedData getters        rust/src/python_interface/collector.rs:55-136
+ *   tw_last_error          anyhow::Error -> PyRuntimeError rust/src/python_interface/error_mapping.rs:20-33
+ */
+#ifndef TWISTERL_HIP_H
+#define TWISTERL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TW_ABI_VERSION 1
+
+/* status codes */
+enum {
+    TW_OK              = 0,
+    TW_ERR_INVALID     = 1,  /* bad argument                                               */
+    TW_ERR_UNSUPPORTED = 2,  /* env / policy shape outside what the HIP path implements    */
+    TW_ERR_NO_DEVICE   = 3,  /* no usable gfx950 device                                    */
+    TW_ERR_HIP         = 4,  /* a HIP runtime call failed (message has the HIP error)      */
+    TW_ERR_EMPTY       = 5   /* zero episodes: "No data in collected data chunks to merge" */
+};
+
+/* arithmetic of the policy forward inside the collectors */
+enum {
+    TW_PREC_F32_EXACT = 0,  /* f32 MFMA, k-ordered fma chain: bit-equal to the oracle      */
+    TW_PREC_F16       = 1   /* fp16-input MFMA, f32 accumulate (throughput mode)           */
+};
+
+int         tw_abi_version(void);
+const char *tw_last_error(void);              /* thread-local, valid until the next call    */
+int         tw_device_count(void);
+int         tw_set_device(int device);
+int         tw_set_stream(void *hip_stream);  /* launch on this hipStream_t (NULL = default)*/
+
+typedef struct {
+    char     name[128];
+    char     arch[64];
+    int32_t  compute_units;
+    int32_t  wavefront_size;
+    uint64_t total_mem_bytes;
+    uint64_t lds_bytes_per_block;
+} tw_device_info;
+int tw_get_device_info(tw_device_info *out);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Env: host object with the PyBaseEnv / Puzzle surface.  Collectors only read its          */
+/* descriptor (the reference clones + resets the env per episode, ppo.rs:59-60).            */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t width, height, difficulty, depth_slope, max_depth;
+} tw_puzzle_desc;
+
+typedef struct tw_puzzle tw_puzzle;
+
+tw_puzzle *tw_puzzle_create(uint32_t width, uint32_t height, uint32_t difficulty,
+                            uint32_t depth_slope, uint32_t max_depth);
+tw_puzzle *tw_puzzle_clone(const tw_puzzle *p);
+void       tw_puzzle_destroy(tw_puzzle *p);
+int        tw_puzzle_get_desc(const tw_puzzle *p, tw_puzzle_desc *out);
+uint32_t   tw_puzzle_num_actions(const tw_puzzle *p);
+int        tw_puzzle_obs_shape(const tw_puzzle *p, uint32_t out[2]);
+int        tw_puzzle_set_difficulty(tw_puzzle *p, uint32_t difficulty);
+uint32_t   tw_puzzle_get_difficulty(const tw_puzzle *p);
+int        tw_puzzle_set_state(tw_puzzle *p, const int64_t *state, size_t n);
+int        tw_puzzle_reset(tw_puzzle *p, uint64_t seed, uint64_t episode);
+int        tw_puzzle_step(tw_puzzle *p, uint32_t action);
+int        tw_puzzle_masks(const tw_puzzle *p, uint8_t out[4]);
+int        tw_puzzle_is_final(const tw_puzzle *p);
+float      tw_puzzle_reward(const tw_puzzle *p);
+int        tw_puzzle_observe(const tw_puzzle *p, int64_t *out /* width*height */);
+int        tw_puzzle_solved(const tw_puzzle *p);
+int        tw_puzzle_get_state(const tw_puzzle *p, int64_t *out /* width*height */);
+int        tw_puzzle_set_position(tw_puzzle *p, uint32_t x, uint32_t y, int64_t val);
+int64_t    tw_puzzle_get_position(const tw_puzzle *p, uint32_t x, uint32_t y);
+uint32_t   tw_puzzle_depth(const tw_puzzle *p);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Policy: weights in the reference's export layout (src/twisterl/nn/utils.py:17-79)        */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t     in_features, out_features;
+    const float *weights;   /* [in][out] row-major == torch_weight.T.flatten() (layers.rs:26)  */
+    const float *bias;      /* [out]                                                           */
+    uint32_t     apply_relu;
+} tw_linear_desc;
+
+typedef struct {
+    /* EmbeddingBag, 1-D mode (layers.rs:56-62): out = bias + sum_k vectors[obs[k]], ReLU      */
+    uint32_t     obs_size, emb_size;
+    const float *emb_vectors;   /* [obs_size][emb_size] == torch_weight.T                      */
+    const float *emb_bias;      /* [emb_size]                                                  */
+    uint32_t     emb_apply_relu;
+    uint32_t n_common; const tw_linear_desc *common;
+    uint32_t n_action; const tw_linear_desc *action;
+    uint32_t n_value;  const tw_linear_desc *value;
+    /* twists (policy.rs:25-26): obs_perms[n_perms][obs_size], act_perms[n_perms][n_actions]   */
+    uint32_t       n_perms, n_actions;
+    const int32_t *obs_perms;
+    const int32_t *act_perms;
+} tw_policy_desc;
+
+typedef struct tw_policy tw_policy;
+
+/* Copies the weights to the device (host pointers in `desc` need not outlive the call).
+ * Supported shape: 1-D EmbeddingBag -> ONE common Linear -> ONE action Linear (n_actions
+ * outputs) and ONE value Linear (1 output); emb_size % 32 == 0, hidden % 32 == 0 (<= 256),
+ * obs_size <= 256.  Anything else: NULL + TW_ERR_UNSUPPORTED. */
+tw_policy *tw_policy_create(const tw_policy_desc *desc);
+void       tw_policy_destroy(tw_policy *p);
+uint32_t   tw_policy_num_actions(const tw_policy *p);
+uint32_t   tw_policy_num_perms(const tw_policy *p);
+
+enum {
+    TW_EVAL_FORWARD      = 0, /* masked logits, -1e10 fill       (policy.rs:56-65)             */
+    TW_EVAL_PREDICT      = 1, /* masked softmax, eps 1e-6        (policy.rs:39-49)             */
+    TW_EVAL_FULL_PREDICT = 2  /* average over all twists, softmax (policy.rs:102-126)          */
+};
+/* Batched Policy.{forward,predict,full_predict} on the device.  Host pointers.
+ * obs [n][n_obs] ids, masks [n][n_actions] (0/1), perms [n] (-1 = None; NULL = all None;
+ * ignored by FULL_PREDICT).  out_actions [n][n_actions], out_values [n]. */
+int tw_policy_evaluate(const tw_policy *p, int mode, uint32_t precision,
+                       const int32_t *obs, uint32_t n, uint32_t n_obs,
+                       const uint8_t *masks, const int32_t *perms,
+                       float *out_actions, float *out_values);
+
+/* ---------------------------------------------------------------------------------------- */
+/* Collectors                                                                               */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t num_episodes;    /* episodes collected by THIS call (this rank's shard)           */
+    uint64_t episode_offset;  /* global index of the first one: RNG is keyed by global index,  */
+                              /* so results do not depend on how episodes are sharded          */
+    float    gamma, lambda;   /* PPOCollector::new (ppo.rs:30-37)                              */
+    uint64_t seed;            /* build extension: the reference RNG is unseedable              */
+    uint32_t precision;       /* TW_PREC_*                                                     */
+    uint32_t merge_order;     /* 1: reference order [E-1, 0, .., E-2] (collector.rs:40-46)     */
+                              /* 0: episode-index order (shards, before the cross-GPU gather)  */
+} tw_ppo_params;
+
+typedef struct {
+    uint64_t num_episodes, episode_offset;
+    uint32_t num_mcts_searches;   /* AZCollector::new (az.rs:32-46)                            */
+    float    C;
+    uint32_t max_expand_depth;
+    uint64_t seed;
+    uint32_t precision;
+    uint32_t merge_order;
+} tw_az_params;
+
+typedef struct tw_collected tw_collected;
+
+int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy,
+                   const tw_ppo_params *params, tw_collected **out);
+int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
+                  const tw_az_params *params, tw_collected **out);
+
+/* Fields of the result (device-resident, compact, in the order params.merge_order asked for) */
+enum {
+    TW_F_OBS       = 0,  /* uint8  [n][n_cells]    obs ids (< 256)                             */
+    TW_F_LOGITS    = 1,  /* float  [n][n_actions]  PPO: masked logits; AZ: MCTS probs          */
+    TW_F_PERMS     = 2,  /* int8   [n]             -1 = None                                   */
+    TW_F_VALUES    = 3,  /* float  [n]             (PPO only)                                  */
+    TW_F_REWARDS   = 4,  /* float  [n]             (PPO only)                                  */
+    TW_F_ACTIONS   = 5,  /* uint8  [n]             (PPO only)                                  */
+    TW_F_ADVS      = 6,  /* float  [n]             additional_data["advs"]  (PPO)              */
+    TW_F_RETS      = 7,  /* float  [n]             additional_data["rets"]  (PPO)              */
+    TW_F_REMAINING = 8,  /* float  [n]             additional_data["remaining_values"] (AZ)    */
+    TW_F_EP_LEN    = 9,  /* uint32 [num_episodes]  records per episode, episode-index order    */
+    TW_F_EP_START  = 10, /* uint64 [num_episodes]  first record of each episode in the output  */
+    TW_F_COUNT     = 11
+};
+
+uint64_t tw_collected_num_records(const tw_collected *c);
+uint64_t tw_collected_num_episodes(const tw_collected *c);
+uint32_t tw_collected_num_cells(const tw_collected *c);
+uint32_t tw_collected_num_actions(const tw_collected *c);
+int      tw_collected_is_ppo(const tw_collected *c);
+/* device pointer + byte size of a field (NULL/0 when the collector does not produce it) */
+void    *tw_collected_device_ptr(const tw_collected *c, int field, size_t *bytes);
+int      tw_collected_copy_to_host(const tw_collected *c, int field, void *dst, size_t bytes);
+
+typedef struct {
+    float    ms_rollout;    /* fused step+observe+reward+forward+sample kernel (HIP events)     */
+    float    ms_scan;       /* episode-length scan kernels                                      */
+    float    ms_finalize;   /* GAE + compaction kernel                                          */
+    float    ms_total;      /* first launch -> last kernel done                                 */
+    uint64_t records;
+    uint64_t episodes;
+    uint64_t padded_bytes;  /* workspace used by the padded trajectory buffers                  */
+    uint32_t rollout_blocks, rollout_threads;
+    uint64_t forward_evals; /* policy forwards executed (AZ: leaf evaluations x twists)         */
+} tw_collect_stats;
+int  tw_collected_stats(const tw_collected *c, tw_collect_stats *out);
+void tw_collected_free(tw_collected *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWISTERL_HIP_H */

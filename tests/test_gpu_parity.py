@@ -1,0 +1,229 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Every test calls the product through
+its public surface (twisterl_amd -> C ABI -> HIP kernels) and checks it against the CPU oracle.
+
+Bars (BASELINE.json north_star): state transitions / masks / obs / rewards / actions BIT-EXACT;
+in the f32 "exact" mode logits, values, advantages and returns are bit-exact too (the oracle's
+TWO_ARITH_CHAIN order is what the f32 MFMA computes); against the reference's un-fused order the
+tolerance is 1e-5.
+"""
+import numpy as np
+import pytest
+
+from tests.util import amd_policy, f32_bits, make_policy_arrays, oracle_policy, puzzle_transpose_twist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tw():
+    import twisterl_amd
+    assert twisterl_amd.device_count() >= 1, "no GPU visible: the -m gpu tests need the MI355X box"
+    return twisterl_amd.twisterl
+
+
+def _assert_same_collect(g, o, n_cells):
+    """g: twisterl_amd CollectedData (device), o: oracle Collected.  Bitwise equality."""
+    a = g.to_numpy()
+    assert a["obs"].shape == (o.obs.shape[0], n_cells)
+    assert np.array_equal(a["ep_len"], o.ep_len)
+    assert np.array_equal(a["obs"].astype(np.int64), o.obs)
+    assert np.array_equal(a["actions"].astype(np.int64), o.actions)
+    assert np.array_equal(a["perms"].astype(np.int32), o.perms)
+    assert np.array_equal(f32_bits(a["rewards"]), f32_bits(o.rewards))
+    assert np.array_equal(f32_bits(a["logits"]), f32_bits(o.logits))
+    assert np.array_equal(f32_bits(a["values"]), f32_bits(o.values))
+    assert np.array_equal(f32_bits(a["advs"]), f32_bits(o.additional_data["advs"]))
+    assert np.array_equal(f32_bits(a["rets"]), f32_bits(o.additional_data["rets"]))
+
+
+def _pair(oracle, n2, seed, emb, hidden, twists=False, scale=1.0):
+    arrs = make_policy_arrays(n2, seed=seed, emb=emb, hidden=hidden, scale=scale)
+    op, ap = puzzle_transpose_twist(int(round(n2 ** 0.5))) if twists else ((), ())
+    return amd_policy(arrs, op, ap), oracle_policy(oracle, arrs, op, ap)
+
+
+# ------------------------------------------------------------------------------ policy forward
+@pytest.mark.parametrize("n2,emb,hidden", [(9, 64, 32), (16, 512, 256)])
+def test_policy_evaluate_matches_oracle(tw, oracle, n2, emb, hidden):
+    gp, op = _pair(oracle, n2, 3, emb, hidden, twists=True)
+    rng = np.random.default_rng(0)
+    n = 64
+    boards = np.stack([rng.permutation(n2) for _ in range(n)])
+    obs = np.arange(n2)[None, :] * n2 + boards
+    masks = rng.integers(0, 2, size=(n, 4)).astype(np.uint8)
+    masks[:, 0] = 1
+    perms = rng.integers(-1, 2, size=n).astype(np.int32)
+    from twisterl_amd import _lib
+    la, va = gp.evaluate_batch(_lib.TW_EVAL_FORWARD, obs, masks, perms)
+    pa, pv = gp.evaluate_batch(_lib.TW_EVAL_PREDICT, obs, masks, perms)
+    fa, fv = gp.evaluate_batch(_lib.TW_EVAL_FULL_PREDICT, obs, masks)
+    for i in range(n):
+        lo, vo = op.forward(obs[i].tolist(), masks[i].tolist(), perm=int(perms[i]), arith=oracle.ARITH_CHAIN)
+        assert np.array_equal(f32_bits(la[i]), f32_bits(lo)) and f32_bits(va[i]) == f32_bits(vo)   # bit-exact
+        lr, vr = op.forward(obs[i].tolist(), masks[i].tolist(), perm=int(perms[i]), arith=oracle.ARITH_REF)
+        np.testing.assert_allclose(la[i], lr, atol=1e-5, rtol=1e-5)                                  # vs reference order
+        assert abs(va[i] - vr) <= 1e-5
+        po, _ = op.predict(obs[i].tolist(), masks[i].tolist(), perm=int(perms[i]), arith=oracle.ARITH_CHAIN)
+        np.testing.assert_allclose(pa[i], po, atol=1e-6, rtol=1e-5)      # device expf vs libm expf
+        fo, fvo = op.full_predict(obs[i].tolist(), masks[i].tolist(), arith=oracle.ARITH_CHAIN)
+        np.testing.assert_allclose(fa[i], fo, atol=1e-6, rtol=1e-5)
+        assert abs(fv[i] - fvo) <= 1e-6
+    # single-observation PyO3-style methods
+    probs, val = gp.predict(obs[0].tolist(), [bool(m) for m in masks[0]], perm=0)
+    assert len(probs) == 4 and abs(sum(probs) - 1.0) < 1e-4 and isinstance(val, float)
+
+
+# ------------------------------------------------------------------------------ PPO collect
+@pytest.mark.parametrize("w,h,diff,emb,hidden,E,twists", [
+    (3, 3, 5, 32, 32, 300, False),      # Puzzle-8, tiny net, ragged workgroup tail
+    (3, 3, 12, 64, 64, 129, True),      # twists, hidden 64
+    (2, 2, 3, 32, 32, 64, False),       # the reference unit test's 2x2 board
+    (3, 2, 4, 32, 128, 70, False),      # non-square board (6 cells -> padded to the 9-cell kernel)
+    (4, 4, 6, 512, 256, 256, True),     # Puzzle-15 at the benchmark's network size, with twists
+])
+def test_ppo_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, twists):
+    n2 = w * h
+    if twists and w != h:
+        pytest.skip("transpose twist needs a square board")
+    gp, op = _pair(oracle, n2, 1, emb, hidden, twists=twists)
+    genv = tw.env.Puzzle(w, h, diff, 2, 256)
+    oenv = oracle.Puzzle(w, h, diff, 2, 256)
+    for merge_order in (True, False):
+        coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32},
+                                         seed=11, merge_order=merge_order)
+        g = coll.collect(genv, gp, seed=11)
+        o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=11, arith=oracle.ARITH_CHAIN, det_log=True,
+                               merge_order=merge_order)
+        _assert_same_collect(g, o, n2)
+
+
+def test_ppo_collect_within_1e5_of_reference_order(tw, oracle):
+    """north_star tolerance: returns/advantages within 1e-5 of the reference arithmetic.  The
+    reference order (un-fused, libm log) is replayed on the GPU's own trajectory: same boards and
+    actions -> its logits/values at every record, then its GAE."""
+    gp, op = _pair(oracle, 16, 2, 512, 256)
+    genv = tw.env.Puzzle(4, 4, 5, 2, 256)
+    g = tw.collector.PPOCollector(128, 0.995, 0.995, 1, seed=5, merge_order=False).collect(genv, gp, seed=5).to_numpy()
+    pos = 0
+    for n in g["ep_len"].astype(int):
+        obs = g["obs"][pos:pos + n].astype(np.int64)
+        vals = np.empty(n, np.float32)
+        for t in range(n):
+            board = obs[t] - np.arange(16) * 16
+            zi = int(np.where(board == 0)[0][0])
+            masks = [zi % 4 > 0, zi // 4 > 0, zi % 4 < 3, zi // 4 < 3]
+            lr, vr = op.forward(obs[t].tolist(), masks, arith=oracle.ARITH_REF)
+            np.testing.assert_allclose(g["logits"][pos + t], lr, atol=1e-5, rtol=1e-5)
+            vals[t] = vr
+        np.testing.assert_allclose(g["values"][pos:pos + n], vals, atol=1e-5)
+        advs, rets = oracle.gae(g["rewards"][pos:pos + n], vals, 0.995, 0.995)
+        np.testing.assert_allclose(g["advs"][pos:pos + n], advs, atol=1e-5)
+        np.testing.assert_allclose(g["rets"][pos:pos + n], rets, atol=1e-5)
+        pos += n
+
+
+def test_sharding_invariance_and_offsets(tw, oracle):
+    gp, _ = _pair(oracle, 9, 4, 64, 32)
+    env = tw.env.Puzzle(3, 3, 6, 2, 256)
+    full = tw.collector.PPOCollector(500, 0.99, 0.95, 1, merge_order=False).collect(env, gp, seed=9).to_numpy()
+    a = tw.collector.PPOCollector(200, 0.99, 0.95, 1, merge_order=False, episode_offset=0).collect(env, gp, seed=9).to_numpy()
+    b = tw.collector.PPOCollector(300, 0.99, 0.95, 1, merge_order=False, episode_offset=200).collect(env, gp, seed=9).to_numpy()
+    for k in ("obs", "logits", "perms", "values", "rewards", "actions", "advs", "rets", "ep_len"):
+        assert np.array_equal(full[k], np.concatenate([a[k], b[k]])), k
+
+
+def test_edge_cases(tw, oracle):
+    gp, op = _pair(oracle, 9, 6, 32, 32)
+    # difficulty 0: every episode is born solved -> exactly one record, reward 1, adv = r - v
+    d = tw.collector.PPOCollector(130, 0.9, 0.9, 1).collect(tw.env.Puzzle(3, 3, 0, 2, 256), gp, seed=1).to_numpy()
+    assert d["ep_len"].tolist() == [1] * 130 and np.all(d["rewards"] == 1.0)
+    assert np.array_equal(f32_bits(d["advs"]), f32_bits(d["rewards"] - d["values"]))
+    # a single episode
+    g = tw.collector.PPOCollector(1, 0.9, 0.9, 1).collect(tw.env.Puzzle(3, 3, 7, 2, 256), gp, seed=2)
+    o = oracle.ppo_collect(oracle.Puzzle(3, 3, 7, 2, 256), op, 1, 0.9, 0.9, seed=2, arith=oracle.ARITH_CHAIN, det_log=True)
+    _assert_same_collect(g, o, 9)
+    # maximum depth of the benchmark config: difficulty 128 -> 257-record episodes
+    g = tw.collector.PPOCollector(40, 0.995, 0.995, 1).collect(tw.env.Puzzle(3, 3, 128, 2, 256), gp, seed=3)
+    o = oracle.ppo_collect(oracle.Puzzle(3, 3, 128, 2, 256), op, 40, 0.995, 0.995, seed=3, arith=oracle.ARITH_CHAIN, det_log=True)
+    _assert_same_collect(g, o, 9)
+    assert g.to_numpy()["ep_len"].max() == 257
+    # the curriculum mutates env.difficulty between collects (algorithm.py:168): read it every call
+    env = tw.env.Puzzle(3, 3, 1, 2, 256)
+    c = tw.collector.PPOCollector(64, 0.9, 0.9, 1)
+    assert c.collect(env, gp, seed=4).to_numpy()["ep_len"].max() <= 3
+    env.difficulty = 10
+    assert c.collect(env, gp, seed=4).to_numpy()["ep_len"].max() > 3
+
+
+def test_reference_style_attribute_access(tw, oracle):
+    """The duck-typed consumer of the reference trainer (src/twisterl/rl/ppo.py:27-36)."""
+    gp, _ = _pair(oracle, 9, 7, 32, 32)
+    data = tw.collector.PPOCollector(**{"num_cores": 32, "num_episodes": 16, "lambda": 0.995, "gamma": 0.995}).collect(
+        tw.env.Puzzle(3, 3, 4, 2, 256), gp)
+    obs, logits, acts = data.obs, data.logits, data.actions
+    rets, advs = data.additional_data["rets"], data.additional_data["advs"]
+    perms = getattr(data, "perms", [-1] * len(data.obs))
+    n = len(obs)
+    assert n == len(logits) == len(acts) == len(rets) == len(advs) == len(perms) == len(data.values) == len(data.rewards)
+    assert all(len(o) == 9 and all(isinstance(x, int) for x in o) for o in obs)
+    assert all(len(l) == 4 for l in logits) and set(perms) == {-1}
+    np_obs = np.zeros((n, 81))
+    for i, o in enumerate(obs):
+        np_obs[i, o] = 1.0
+    assert np.all(np_obs.sum(1) == 9)
+    other = tw.collector.CollectedData([[0]], [[0.1]], [0.2], [0.3], [1])
+    data.merge(other)
+    assert len(data.obs) == n + 1 and data.actions[-1] == 1 and data.perms[-1] == -1
+
+
+def test_errors(tw, oracle):
+    gp, _ = _pair(oracle, 9, 8, 32, 32)
+    with pytest.raises(RuntimeError, match="No data in collected data chunks to merge"):
+        tw.collector.PPOCollector(0, 0.9, 0.9, 1).collect(tw.env.Puzzle(3, 3, 1, 2, 256), gp)
+    with pytest.raises(TypeError, match="__extract_env__"):
+        tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(object(), gp)
+    with pytest.raises(RuntimeError, match="width\\*height <= 16"):
+        tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)
+    with pytest.raises(ValueError):
+        tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(4, 4, 1, 2, 256), gp)   # obs_size mismatch
+    arrs = make_policy_arrays(9, emb=48, hidden=32)
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        amd_policy(arrs)._handle()
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_puzzle8_65k(tw, oracle):
+    """BASELINE config 2 size (65,536 envs): determinism, replay parity on a sample, GAE parity on
+    a sample, record-count identities."""
+    gp, op = _pair(oracle, 9, 0, 512, 256)
+    env = tw.env.Puzzle(3, 3, 32, 2, 256)
+    coll = tw.collector.PPOCollector(65536, 0.995, 0.995, 32, merge_order=False)
+    a = coll.collect(env, gp, seed=21).to_numpy()
+    b = coll.collect(env, gp, seed=21).to_numpy()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k                       # same seed twice -> identical buffers
+    L = a["ep_len"].astype(np.int64)
+    assert L.sum() == a["obs"].shape[0] and L.min() >= 1 and L.max() <= 65
+    starts = np.concatenate([[0], np.cumsum(L)])
+    assert np.array_equal(a["ep_start"].astype(np.int64), starts[:-1])
+    rng = np.random.default_rng(0)
+    for e in rng.choice(65536, size=48, replace=False):
+        s, n = int(starts[e]), int(L[e])
+        p = oracle.Puzzle(3, 3, 32, 2, 256)
+        p.reset(seed=21, episode=int(e))
+        obs, masks, rew, fin, _ = oracle.replay(p, a["actions"][s:s + n - 1].astype(np.int64))
+        assert np.array_equal(obs, a["obs"][s:s + n].astype(np.int64))
+        assert np.array_equal(f32_bits(rew), f32_bits(a["rewards"][s:s + n]))
+        assert fin[-1] and not fin[:-1].any()
+        assert np.all((a["logits"][s:s + n] == np.float32(-1e10)) == ~masks)
+        advs, rets = oracle.gae(a["rewards"][s:s + n], a["values"][s:s + n], 0.995, 0.995)
+        assert np.array_equal(f32_bits(advs), f32_bits(a["advs"][s:s + n]))
+        assert np.array_equal(f32_bits(rets), f32_bits(a["rets"][s:s + n]))
+        for t in (0, n - 1):
+            lo, vo = op.forward(obs[t].tolist(), masks[t].tolist(), arith=oracle.ARITH_CHAIN)
+            assert np.array_equal(f32_bits(lo), f32_bits(a["logits"][s + t])) and f32_bits(vo) == f32_bits(a["values"][s + t])
+    # merge order = rotation of the index order by one episode (collector.rs:40-46)
+    m = tw.collector.PPOCollector(65536, 0.995, 0.995, 32, merge_order=True).collect(env, gp, seed=21).to_numpy()
+    tail = int(L[-1])
+    for k in ("obs", "logits", "values", "actions", "advs", "rets"):
+        assert np.array_equal(m[k][:tail], a[k][-tail:]) and np.array_equal(m[k][tail:], a[k][:-tail]), k

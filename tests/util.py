@@ -34,3 +34,22 @@ def make_policy_arrays(n2, seed=0, emb=512, hidden=256, n_actions=4, scale=1.0):
             [(np.ascontiguousarray(w1.T).reshape(-1), b1, True)],
             [(np.ascontiguousarray(wa.T).reshape(-1), ba, False)],
             [(np.ascontiguousarray(wv.T).reshape(-1), bv, False)])
+
+
+def amd_policy(arrs, obs_perms=(), act_perms=()):
+    """twisterl_amd.nn.Policy from make_policy_arrays() output, built through the same
+    constructor calls BasicPolicy.to_rust() makes (src/twisterl/nn/policy.py:191-199)."""
+    from twisterl_amd import twisterl
+    emb, eb, common, action, value = arrs
+    seq = lambda ls: twisterl.nn.Sequential([twisterl.nn.Linear(w.tolist(), b.tolist(), r) for (w, b, r) in ls])
+    return twisterl.nn.Policy(twisterl.nn.EmbeddingBag(emb.tolist(), eb.tolist(), True, [emb.shape[0]], 0),
+                              seq(common), seq(action), seq(value), [list(p) for p in obs_perms],
+                              [list(p) for p in act_perms])
+
+
+def oracle_policy(oracle, arrs, obs_perms=(), act_perms=()):
+    return oracle.Policy(*arrs, obs_perms, act_perms)
+
+
+def f32_bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)

@@ -1,0 +1,72 @@
+"""Builds the HIP collector library for gfx950 with hipcc (in-tree, no JIT cache).
+
+    python -m twisterl_amd.build            # incremental
+    python -m twisterl_amd.build --force
+
+Output: twisterl_amd/lib/libtwisterl_hip.so (git-ignored; it travels to the GPU box with the tree).
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtwisterl_hip.so")
+SOURCES = ["tw_api.hip", "tw_rollout.hip", "tw_finalize.hip", "tw_eval.hip", "tw_mcts.hip"]
+HEADERS = [os.path.join(CSRC, "tw_common.hpp"), os.path.join(ROOT, "include", "twisterl_hip.h")]
+
+# -ffp-contract=off: the numeric spec allows only the explicit fma() calls
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    procs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS):
+            cmd = [hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for name, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {name}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    if force or procs or _stale(LIB_PATH, objs):
+        cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH, *objs]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

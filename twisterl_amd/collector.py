@@ -1,0 +1,325 @@
+"""`twisterl.collector` surface: CollectedData, PPOCollector, AZCollector.
+
+Mirrors reference rust/src/python_interface/collector.rs:24-187.  `collect(env, policy)` runs
+the whole episode collection on the GPU (tw_ppo_collect / tw_az_collect); the result stays
+device-resident and is only turned into Python lists when a reference-style attribute
+(`.obs`, `.logits`, ...) is read.  `.device_arrays()` / `.to_torch()` expose the same buffers
+zero-copy for trainers that can take tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .env import get_env_desc
+from .nn import Policy
+
+_FIELD_DTYPES = {
+    _lib.TW_F_OBS: np.uint8, _lib.TW_F_LOGITS: np.float32, _lib.TW_F_PERMS: np.int8,
+    _lib.TW_F_VALUES: np.float32, _lib.TW_F_REWARDS: np.float32, _lib.TW_F_ACTIONS: np.uint8,
+    _lib.TW_F_ADVS: np.float32, _lib.TW_F_RETS: np.float32, _lib.TW_F_REMAINING: np.float32,
+    _lib.TW_F_EP_LEN: np.uint32, _lib.TW_F_EP_START: np.uint64,
+}
+_FIELD_NAMES = {
+    "obs": _lib.TW_F_OBS, "logits": _lib.TW_F_LOGITS, "perms": _lib.TW_F_PERMS, "values": _lib.TW_F_VALUES,
+    "rewards": _lib.TW_F_REWARDS, "actions": _lib.TW_F_ACTIONS, "advs": _lib.TW_F_ADVS, "rets": _lib.TW_F_RETS,
+    "remaining_values": _lib.TW_F_REMAINING, "ep_len": _lib.TW_F_EP_LEN, "ep_start": _lib.TW_F_EP_START,
+}
+
+
+class _DeviceResult:
+    """Owner of a tw_collected handle."""
+
+    def __init__(self, handle):
+        self.h = handle
+        L = _lib.lib()
+        self.n = int(L.tw_collected_num_records(handle))
+        self.n_episodes = int(L.tw_collected_num_episodes(handle))
+        self.n_cells = int(L.tw_collected_num_cells(handle))
+        self.n_actions = int(L.tw_collected_num_actions(handle))
+        self.is_ppo = bool(L.tw_collected_is_ppo(handle))
+        st = _lib.CollectStats()
+        _lib.check(L.tw_collected_stats(handle, C.byref(st)))
+        self.stats = {k: getattr(st, k) for k, _ in st._fields_}
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                _lib.lib().tw_collected_free(h)
+            except Exception:
+                pass
+
+    def shape(self, field):
+        if field == _lib.TW_F_OBS:
+            return (self.n, self.n_cells)
+        if field == _lib.TW_F_LOGITS:
+            return (self.n, self.n_actions)
+        if field in (_lib.TW_F_EP_LEN, _lib.TW_F_EP_START):
+            return (self.n_episodes,)
+        return (self.n,)
+
+    def ptr(self, field):
+        nbytes = C.c_size_t()
+        p = _lib.lib().tw_collected_device_ptr(self.h, field, C.byref(nbytes))
+        return (int(p) if p else 0), int(nbytes.value)
+
+    def host(self, field) -> np.ndarray:
+        p, nbytes = self.ptr(field)
+        dt = np.dtype(_FIELD_DTYPES[field])
+        if nbytes == 0:
+            return np.zeros((0,), dt)
+        out = np.empty(self.shape(field), dt)
+        assert out.nbytes == nbytes, (field, out.nbytes, nbytes)
+        _lib.check(_lib.lib().tw_collected_copy_to_host(self.h, field, out.ctypes.data_as(C.c_void_p), nbytes))
+        return out
+
+
+class DeviceArray:
+    """Zero-copy view of one result field: implements __cuda_array_interface__ (which PyTorch-ROCm
+    accepts: torch.as_tensor(view, device='cuda'))."""
+
+    def __init__(self, owner: _DeviceResult, field: int):
+        self._owner = owner
+        ptr, nbytes = owner.ptr(field)
+        self.shape = owner.shape(field)
+        self.dtype = np.dtype(_FIELD_DTYPES[field])
+        self.nbytes = nbytes
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": self.dtype.str, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+class CollectedData:
+    """CollectedData(obs, logits, values, rewards, actions, perms=None) with get/set attributes
+    obs, logits, perms, values, rewards, actions, additional_data and the methods merge,
+    get_additional_data_item, set_additional_data_item (python_interface/collector.rs:24-137)."""
+
+    def __init__(self, obs, logits, values, rewards, actions, perms=None):
+        self._dev = None
+        self._obs = [list(map(int, o)) for o in obs]
+        self._logits = [list(map(float, l)) for l in logits]
+        self._values = [float(v) for v in values]
+        self._rewards = [float(v) for v in rewards]
+        self._actions = [int(a) for a in actions]
+        # perms.unwrap_or_else(|| vec![None; obs.len()])  (collector.rs:42)
+        self._perms = [-1] * len(self._obs) if perms is None else [(-1 if p is None or p < 0 else int(p)) for p in perms]
+        self._additional = {}
+
+    # ---- construction from a device result ----------------------------------------------------
+    @classmethod
+    def _from_device(cls, dev: _DeviceResult) -> "CollectedData":
+        self = cls.__new__(cls)
+        self._dev = dev
+        self._obs = self._logits = self._values = self._rewards = self._actions = self._perms = None
+        self._additional = None
+        return self
+
+    def _materialize(self):
+        """device buffers -> the reference's list-of-lists representation (each PyO3 getter clones
+        into fresh Python lists, collector.rs:55-131)."""
+        if self._dev is None or self._obs is not None:
+            return
+        d = self._dev
+        self._obs = d.host(_lib.TW_F_OBS).astype(np.int64).tolist()
+        self._logits = d.host(_lib.TW_F_LOGITS).tolist()
+        self._perms = d.host(_lib.TW_F_PERMS).astype(np.int64).tolist()
+        if d.is_ppo:
+            self._values = d.host(_lib.TW_F_VALUES).tolist()
+            self._rewards = d.host(_lib.TW_F_REWARDS).tolist()
+            self._actions = d.host(_lib.TW_F_ACTIONS).astype(np.int64).tolist()
+            self._additional = {"advs": d.host(_lib.TW_F_ADVS).tolist(), "rets": d.host(_lib.TW_F_RETS).tolist()}
+        else:   # AZ: values / rewards / actions stay empty (collector/az.rs:97-104)
+            self._values, self._rewards, self._actions = [], [], []
+            self._additional = {"remaining_values": d.host(_lib.TW_F_REMAINING).tolist()}
+
+    def _detach(self):
+        self._materialize()
+        self._dev = None
+
+    # ---- reference attributes ------------------------------------------------------------------
+    def _get(self, name):
+        self._materialize()
+        return getattr(self, name)
+
+    obs = property(lambda s: [list(o) for o in s._get("_obs")], lambda s, v: s._set("_obs", [list(map(int, o)) for o in v]))
+    logits = property(lambda s: [list(l) for l in s._get("_logits")], lambda s, v: s._set("_logits", [list(map(float, l)) for l in v]))
+    perms = property(lambda s: list(s._get("_perms")), lambda s, v: s._set("_perms", [(-1 if p < 0 else int(p)) for p in v]))
+    values = property(lambda s: list(s._get("_values")), lambda s, v: s._set("_values", [float(x) for x in v]))
+    rewards = property(lambda s: list(s._get("_rewards")), lambda s, v: s._set("_rewards", [float(x) for x in v]))
+    actions = property(lambda s: list(s._get("_actions")), lambda s, v: s._set("_actions", [int(x) for x in v]))
+    additional_data = property(lambda s: {k: list(v) for k, v in s._get("_additional").items()},
+                               lambda s, v: s._set("_additional", {str(k): [float(x) for x in vv] for k, vv in v.items()}))
+
+    def _set(self, name, value):
+        self._detach()
+        setattr(self, name, value)
+
+    def merge(self, other: "CollectedData") -> None:
+        """Append `other` (collector/collector.rs:70-88)."""
+        self._detach()
+        other._materialize()
+        self._obs.extend([list(o) for o in other._obs])
+        self._logits.extend([list(l) for l in other._logits])
+        self._perms.extend(other._perms)
+        self._values.extend(other._values)
+        self._rewards.extend(other._rewards)
+        self._actions.extend(other._actions)
+        for k, v in other._additional.items():
+            self._additional.setdefault(k, [])
+            self._additional[k].extend(v)
+
+    def get_additional_data_item(self, key: str):
+        self._materialize()
+        v = self._additional.get(key)
+        return None if v is None else list(v)
+
+    def set_additional_data_item(self, key: str, value) -> None:
+        self._detach()
+        self._additional[str(key)] = [float(x) for x in value]
+
+    # ---- build extensions: zero-copy access -----------------------------------------------------
+    def __len__(self):
+        return self._dev.n if (self._dev is not None and self._obs is None) else len(self._get("_obs"))
+
+    @property
+    def on_device(self) -> bool:
+        return self._dev is not None
+
+    @property
+    def stats(self) -> dict:
+        """Per-kernel HIP-event timings and counts of the collect() call that produced this."""
+        return dict(self._dev.stats) if self._dev is not None else {}
+
+    def device_arrays(self) -> dict:
+        """name -> DeviceArray (zero-copy, __cuda_array_interface__) for every field present."""
+        if self._dev is None:
+            raise RuntimeError("this CollectedData no longer aliases device buffers (it was modified or built on the host)")
+        out = {}
+        for name, f in _FIELD_NAMES.items():
+            if self._dev.ptr(f)[1] > 0:
+                out[name] = DeviceArray(self._dev, f)
+        return out
+
+    def to_numpy(self) -> dict:
+        if self._dev is None:
+            raise RuntimeError("this CollectedData no longer aliases device buffers")
+        return {name: self._dev.host(f) for name, f in _FIELD_NAMES.items() if self._dev.ptr(f)[1] > 0}
+
+    def to_torch(self) -> dict:
+        """name -> torch tensor on the current GPU aliasing the result buffers (no copy)."""
+        import torch
+        out = {}
+        for name, arr in self.device_arrays().items():
+            t = torch.as_tensor(arr, device="cuda")
+            t._tw_owner = arr   # keep the owner alive as long as the tensor
+            out[name] = t
+        return out
+
+
+class PyBaseCollector:
+    """collect(py_env, policy) -> CollectedData (python_interface/collector.rs:139-152)."""
+
+    def collect(self, py_env, policy: Policy) -> CollectedData:
+        raise NotImplementedError
+
+    @staticmethod
+    def _check(py_env, policy):
+        desc = get_env_desc(py_env)
+        if not isinstance(policy, Policy):
+            raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
+        return desc
+
+
+def _u(name, v):
+    if int(v) < 0:
+        raise OverflowError(f"{name}: can't convert negative int to unsigned")
+    return int(v)
+
+
+class PPOCollector(PyBaseCollector):
+    """PPOCollector(num_episodes, gamma, lambda, num_cores) (collector.rs:154-170).
+
+    `lambda` is a Python keyword, so -- exactly as with the reference -- it is reachable through
+    `PPOCollector(**config["collecting"])` (src/twisterl/rl/ppo.py:23).  `num_cores` is accepted
+    for compatibility; the episodes run as GPU lanes, not rayon tasks.  Build extensions (all
+    keyword-only, defaulted): seed, precision ("fp32" exact | "fp16"), episode_offset /
+    merge_order for sharded collection (twisterl_amd.dist).
+    """
+
+    def __init__(self, *args, **kwargs):
+        names = ["num_episodes", "gamma", "lambda", "num_cores"]
+        vals = dict(zip(names, args))
+        if len(args) > 4:
+            raise TypeError("PPOCollector() takes 4 positional arguments")
+        for k in list(kwargs):
+            if k in names:
+                if k in vals:
+                    raise TypeError(f"PPOCollector() got multiple values for argument '{k}'")
+                vals[k] = kwargs.pop(k)
+        missing = [n for n in names if n not in vals]
+        if missing:
+            raise TypeError(f"PPOCollector() missing required argument: '{missing[0]}'")
+        self.num_episodes = _u("num_episodes", vals["num_episodes"])
+        self.gamma = float(vals["gamma"])
+        self.lambda_ = float(vals["lambda"])
+        self.num_cores = _u("num_cores", vals["num_cores"])
+        self.seed = kwargs.pop("seed", None)
+        self.precision = kwargs.pop("precision", "fp32")
+        self.episode_offset = int(kwargs.pop("episode_offset", 0))
+        self.merge_order = bool(kwargs.pop("merge_order", True))
+        if kwargs:
+            raise TypeError(f"PPOCollector() got an unexpected keyword argument '{next(iter(kwargs))}'")
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        self._calls = 0
+
+    def _next_seed(self) -> int:
+        # The reference draws fresh OS entropy per call (rand::thread_rng()).  With seed=None we do
+        # the same; with a fixed seed every call advances a counter so successive learn_steps see
+        # different episodes while the whole run stays reproducible.
+        if self.seed is None:
+            import os
+            return int.from_bytes(os.urandom(8), "little")
+        s = (int(self.seed) + 0x9E3779B97F4A7C15 * self._calls) & (2**64 - 1)
+        self._calls += 1
+        return s
+
+    def collect(self, py_env, policy: Policy, *, seed=None) -> CollectedData:
+        desc = self._check(py_env, policy)
+        prm = _lib.PPOParams(self.num_episodes, self.episode_offset, self.gamma, self.lambda_,
+                             (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed(),
+                             _lib.PRECISIONS[self.precision], int(self.merge_order))
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tw_ppo_collect(C.byref(desc), policy._handle(), C.byref(prm), C.byref(out)))
+        return CollectedData._from_device(_DeviceResult(out.value))
+
+
+class AZCollector(PyBaseCollector):
+    """AZCollector(num_episodes, num_mcts_searches, C, max_expand_depth, num_cores) (collector.rs:172-187)."""
+
+    def __init__(self, num_episodes, num_mcts_searches, C, max_expand_depth, num_cores, *, seed=None,
+                 precision="fp32", episode_offset=0, merge_order=True):
+        self.num_episodes = _u("num_episodes", num_episodes)
+        self.num_mcts_searches = _u("num_mcts_searches", num_mcts_searches)
+        self.C = float(C)
+        self.max_expand_depth = _u("max_expand_depth", max_expand_depth)
+        self.num_cores = _u("num_cores", num_cores)
+        self.seed, self.precision = seed, precision
+        self.episode_offset, self.merge_order = int(episode_offset), bool(merge_order)
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        self._calls = 0
+
+    _next_seed = PPOCollector._next_seed
+
+    def collect(self, py_env, policy: Policy, *, seed=None) -> CollectedData:
+        desc = self._check(py_env, policy)
+        prm = _lib.AZParams(self.num_episodes, self.episode_offset, self.num_mcts_searches, self.C,
+                            self.max_expand_depth,
+                            (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed(),
+                            _lib.PRECISIONS[self.precision], int(self.merge_order))
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tw_az_collect(C.byref(desc), policy._handle(), C.byref(prm), C.byref(out)))
+        return CollectedData._from_device(_DeviceResult(out.value))

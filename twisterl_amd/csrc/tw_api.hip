@@ -1,0 +1,577 @@
+// tw_api.hip -- C ABI (include/twisterl_hip.h): host-side logic of the collector library.
+//
+// Host mirror of the reference's compiled (Rust) layer for the hot path:
+//   * tw_puzzle_*      Env for Puzzle         rust/src/envs/puzzle.rs:20-185 (single-env API
+//                                             behind PyBaseEnv, python_interface/env.rs:44-160)
+//   * tw_policy_*      Policy/Linear/EmbeddingBag/Sequential ctors, nn/policy.rs:29-32
+//   * tw_ppo_collect   PPOCollector::collect  rust/src/collector/ppo.rs:108-126 + merge
+//                                             (collector/collector.rs:40-46)
+// All arithmetic of the hot path runs in the HIP kernels; nothing here computes a trajectory.
+#include "tw_common.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace tw {
+
+// ---------------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static thread_local hipStream_t g_stream = nullptr;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? TW_ERR_NO_DEVICE : TW_ERR_HIP;
+}
+
+hipStream_t current_stream() { return g_stream; }
+
+static int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (hipGetDeviceCount: %s); this library has no CPU fallback",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return TW_ERR_NO_DEVICE;
+    }
+    return TW_OK;
+}
+
+// ---------------------------------------------------------------------------------- workspace
+// Padded trajectory buffers are large (E * t_pad * 42 B) and have the same size every
+// iteration of the trainer, so they are cached per device instead of hipMalloc'ed per call.
+struct Workspace {
+    void *ptr = nullptr; size_t cap = 0; int device = -1;
+};
+static std::mutex g_ws_mutex;
+static Workspace g_ws;
+
+static int ws_reserve(size_t bytes, void **out)
+{
+    int dev = 0; TW_HIP(hipGetDevice(&dev));
+    if (g_ws.ptr && (g_ws.device != dev || g_ws.cap < bytes)) {
+        TW_HIP(hipFree(g_ws.ptr)); g_ws.ptr = nullptr; g_ws.cap = 0;
+    }
+    if (!g_ws.ptr) {
+        TW_HIP(hipMalloc(&g_ws.ptr, bytes));
+        g_ws.cap = bytes; g_ws.device = dev;
+    }
+    *out = g_ws.ptr;
+    return TW_OK;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace tw
+
+using namespace tw;
+
+// ====================================================================================== misc
+extern "C" int tw_abi_version(void) { return TW_ABI_VERSION; }
+extern "C" const char *tw_last_error(void) { return g_err.c_str(); }
+
+extern "C" int tw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int tw_set_device(int device)
+{
+    int rc = require_device(); if (rc) return rc;
+    TW_HIP(hipSetDevice(device));
+    return TW_OK;
+}
+
+extern "C" int tw_set_stream(void *hip_stream) { g_stream = reinterpret_cast<hipStream_t>(hip_stream); return TW_OK; }
+
+extern "C" int tw_get_device_info(tw_device_info *out)
+{
+    if (!out) { set_error("tw_get_device_info: null output"); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+    int dev = 0; TW_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p; TW_HIP(hipGetDeviceProperties(&p, dev));
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", p.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", p.gcnArchName);
+    out->compute_units = p.multiProcessorCount;
+    out->wavefront_size = p.warpSize;
+    out->total_mem_bytes = p.totalGlobalMem;
+    out->lds_bytes_per_block = p.sharedMemPerBlock;
+    return TW_OK;
+}
+
+// ====================================================================================== Puzzle (host object)
+struct tw_puzzle {
+    std::vector<int64_t> state;            // puzzle.rs:21
+    int64_t zx = 0, zy = 0, depth = 1;      // puzzle.rs:22-23, depth 1 from Puzzle::new (:41)
+    int64_t width = 0, height = 0, difficulty = 0, depth_slope = 0, max_depth = 0;
+};
+
+extern "C" tw_puzzle *tw_puzzle_create(uint32_t width, uint32_t height, uint32_t difficulty, uint32_t depth_slope,
+                                       uint32_t max_depth)
+{
+    if (width == 0 || height == 0) { set_error("Puzzle: width and height must be positive"); return nullptr; }
+    tw_puzzle *p = new tw_puzzle();
+    p->width = width; p->height = height; p->difficulty = difficulty; p->depth_slope = depth_slope; p->max_depth = max_depth;
+    p->state.resize((size_t)width * height);
+    for (size_t i = 0; i < p->state.size(); ++i) p->state[i] = (int64_t)i;
+    return p;
+}
+extern "C" tw_puzzle *tw_puzzle_clone(const tw_puzzle *p) { return p ? new tw_puzzle(*p) : nullptr; }
+extern "C" void tw_puzzle_destroy(tw_puzzle *p) { delete p; }
+
+extern "C" int tw_puzzle_get_desc(const tw_puzzle *p, tw_puzzle_desc *out)
+{
+    if (!p || !out) { set_error("tw_puzzle_get_desc: null argument"); return TW_ERR_INVALID; }
+    out->width = (uint32_t)p->width; out->height = (uint32_t)p->height; out->difficulty = (uint32_t)p->difficulty;
+    out->depth_slope = (uint32_t)p->depth_slope; out->max_depth = (uint32_t)p->max_depth;
+    return TW_OK;
+}
+extern "C" uint32_t tw_puzzle_num_actions(const tw_puzzle *) { return 4; }                      // puzzle.rs:90-92
+extern "C" int tw_puzzle_obs_shape(const tw_puzzle *p, uint32_t out[2])                          // puzzle.rs:94-97
+{
+    out[0] = out[1] = (uint32_t)p->state.size(); return TW_OK;
+}
+extern "C" int tw_puzzle_set_difficulty(tw_puzzle *p, uint32_t d) { p->difficulty = d; return TW_OK; }   // :99-101
+extern "C" uint32_t tw_puzzle_get_difficulty(const tw_puzzle *p) { return (uint32_t)p->difficulty; }      // :103-105
+extern "C" uint32_t tw_puzzle_depth(const tw_puzzle *p) { return (uint32_t)p->depth; }
+
+extern "C" int tw_puzzle_set_state(tw_puzzle *p, const int64_t *state, size_t n)                 // puzzle.rs:107-117
+{
+    if (!p || !state) { set_error("set_state: null argument"); return TW_ERR_INVALID; }
+    p->state.assign(state, state + n);
+    p->depth = p->max_depth;
+    for (size_t i = 0; i < n; ++i)
+        if (state[i] == 0) { p->zx = (int64_t)i % p->width; p->zy = (int64_t)i / p->width; break; }
+    return TW_OK;
+}
+
+extern "C" int tw_puzzle_step(tw_puzzle *p, uint32_t action)                                     // puzzle.rs:135-160
+{
+    const int64_t zx = p->zx, zy = p->zy, w = p->width;
+    int64_t nx = zx, ny = zy; bool ok = false;
+    if (action == 0 && zx > 0) { nx = zx - 1; ok = true; }
+    else if (action == 1 && zy > 0) { ny = zy - 1; ok = true; }
+    else if (action == 2 && zx < p->width - 1) { nx = zx + 1; ok = true; }
+    else if (action == 3 && zy < p->height - 1) { ny = zy + 1; ok = true; }
+    if (ok) {
+        const size_t zi = (size_t)(zy * w + zx), ti = (size_t)(ny * w + nx);
+        if (zi >= p->state.size() || ti >= p->state.size()) { set_error("step: blank outside the board"); return TW_ERR_INVALID; }
+        p->state[zi] = p->state[ti]; p->state[ti] = 0; p->zx = nx; p->zy = ny;
+    }
+    p->depth = p->depth > 0 ? p->depth - 1 : 0;
+    return TW_OK;
+}
+
+extern "C" int tw_puzzle_reset(tw_puzzle *p, uint64_t seed, uint64_t episode)                    // puzzle.rs:119-133
+{
+    for (size_t i = 0; i < p->state.size(); ++i) p->state[i] = (int64_t)i;
+    p->zx = 0; p->zy = 0;
+    for (int64_t d = 0; d < p->difficulty; ++d) {
+        const u32x4 w = rng_draw(seed, episode, (uint32_t)d, STREAM_SCRAMBLE);
+        tw_puzzle_step(p, u32_below(w.x, 4u));
+    }
+    p->depth = p->depth_slope * p->difficulty;
+    return TW_OK;
+}
+
+extern "C" int tw_puzzle_masks(const tw_puzzle *p, uint8_t out[4])                               // puzzle.rs:162-165
+{
+    out[0] = p->zx > 0; out[1] = p->zy > 0; out[2] = p->zx < p->width - 1; out[3] = p->zy < p->height - 1;
+    return TW_OK;
+}
+extern "C" int tw_puzzle_solved(const tw_puzzle *p)                                              // puzzle.rs:44-50
+{
+    for (size_t i = 0; i < p->state.size(); ++i) if (p->state[i] != (int64_t)i) return 0;
+    return 1;
+}
+extern "C" int tw_puzzle_is_final(const tw_puzzle *p) { return p->depth == 0 || tw_puzzle_solved(p); }   // :167-169
+extern "C" float tw_puzzle_reward(const tw_puzzle *p)                                            // puzzle.rs:171-177
+{
+    if (tw_puzzle_solved(p)) return 1.0f;
+    return p->depth == 0 ? -0.5f : -0.5f / (float)p->max_depth;
+}
+extern "C" int tw_puzzle_observe(const tw_puzzle *p, int64_t *out)                               // puzzle.rs:183-185
+{
+    const int64_t n = (int64_t)p->state.size();
+    for (int64_t i = 0; i < n; ++i) out[i] = i * n + p->state[(size_t)i];
+    return TW_OK;
+}
+extern "C" int tw_puzzle_get_state(const tw_puzzle *p, int64_t *out)
+{
+    memcpy(out, p->state.data(), p->state.size() * sizeof(int64_t)); return TW_OK;
+}
+extern "C" int tw_puzzle_set_position(tw_puzzle *p, uint32_t x, uint32_t y, int64_t val)         // puzzle.rs:71-73
+{
+    const size_t i = (size_t)y * p->width + x;
+    if (i >= p->state.size()) { set_error("set_position: index out of bounds"); return TW_ERR_INVALID; }
+    p->state[i] = val; return TW_OK;
+}
+extern "C" int64_t tw_puzzle_get_position(const tw_puzzle *p, uint32_t x, uint32_t y)            // puzzle.rs:75-77
+{
+    const size_t i = (size_t)y * p->width + x;
+    return i < p->state.size() ? p->state[i] : -1;
+}
+
+// ====================================================================================== Policy
+struct tw_policy {
+    PolicyDev dev{};
+    void *arena = nullptr;
+    int device = -1;
+};
+
+namespace {
+int hid_row(int r, int i) { return 32 * r + 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }   // == tw::hid() in tw_rollout.hip
+}
+
+extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
+{
+    if (!d || !d->emb_vectors || !d->emb_bias) { set_error("tw_policy_create: null descriptor"); return nullptr; }
+    if (require_device()) return nullptr;
+    // ---- shape validation: the HIP path implements the BasicPolicy of the Puzzle configs
+    //      (examples/ppo_puzzle{8,15}_v1.json: embedding -> one common layer -> two linear heads)
+    if (d->n_common != 1 || d->n_action != 1 || d->n_value != 1 || !d->common || !d->action || !d->value) {
+        set_error("policy: HIP path supports exactly one common, one action and one value Linear (got %u/%u/%u)",
+                  d->n_common, d->n_action, d->n_value);
+        return nullptr;
+    }
+    const tw_linear_desc &c = d->common[0], &a = d->action[0], &v = d->value[0];
+    const uint32_t E = d->emb_size, H = c.out_features, A = a.out_features;
+    if (c.in_features != E || a.in_features != H || v.in_features != H || v.out_features != 1 || A != d->n_actions ||
+        A == 0 || A > 31 || E == 0 || E % 32 != 0 || H % 32 != 0 || H == 0 || H > 256 || d->obs_size == 0 ||
+        d->obs_size > 256 || a.apply_relu || v.apply_relu) {
+        set_error("policy: unsupported shape (obs_size=%u emb=%u hidden=%u actions=%u; need emb%%32==0, hidden%%32==0 "
+                  "and <=256, obs_size<=256, linear heads)", d->obs_size, E, H, A);
+        return nullptr;
+    }
+    if (d->n_perms > 0 && (!d->obs_perms || !d->act_perms)) { set_error("policy: n_perms > 0 but perms are null"); return nullptr; }
+    if (d->n_perms > 127) { set_error("policy: at most 127 twists"); return nullptr; }
+    for (uint32_t p = 0; p < d->n_perms; ++p) {
+        for (uint32_t i = 0; i < d->obs_size; ++i)
+            if (d->obs_perms[(size_t)p * d->obs_size + i] < 0 || (uint32_t)d->obs_perms[(size_t)p * d->obs_size + i] >= d->obs_size) {
+                set_error("policy: obs_perms[%u][%u] out of range", p, i); return nullptr;
+            }
+        for (uint32_t i = 0; i < A; ++i)
+            if (d->act_perms[(size_t)p * A + i] < 0 || (uint32_t)d->act_perms[(size_t)p * A + i] >= A) {
+                set_error("policy: act_perms[%u][%u] out of range", p, i); return nullptr;
+            }
+    }
+
+    const uint32_t NT = H / 32, OS = d->obs_size;
+    // ---- host image ------------------------------------------------------------------------
+    struct Seg { size_t off, bytes; };
+    size_t cur = 0;
+    auto seg = [&](size_t bytes) { Seg s{cur, bytes}; cur = align_up(cur + bytes, 256); return s; };
+    const Seg s_emb = seg((size_t)(OS + 2) * E * 4), s_w1p = seg((size_t)E * H * 4), s_b1 = seg((size_t)H * 4),
+              s_wh8 = seg((size_t)H * 8 * 4), s_bh8 = seg(8 * 4), s_w1 = seg((size_t)E * H * 4), s_wa = seg((size_t)H * A * 4),
+              s_ba = seg((size_t)A * 4), s_wv = seg((size_t)H * 4), s_bv = seg(4),
+              s_op = seg((size_t)(d->n_perms ? d->n_perms : 1) * OS), s_ap = seg((size_t)(d->n_perms ? d->n_perms : 1) * A);
+    std::vector<uint8_t> img(cur, 0);
+    float *emb = reinterpret_cast<float *>(img.data() + s_emb.off);
+    memcpy(emb, d->emb_vectors, (size_t)OS * E * 4);
+    memcpy(emb + (size_t)OS * E, d->emb_bias, (size_t)E * 4);                 // bias row; row OS+1 stays zero
+    float *w1p = reinterpret_cast<float *>(img.data() + s_w1p.off);
+    for (uint32_t k = 0; k < E; ++k)
+        for (uint32_t i = 0; i < 32; ++i)
+            for (uint32_t r = 0; r < NT; ++r)
+                w1p[((size_t)k * 32 + i) * NT + r] = c.weights[(size_t)k * H + hid_row((int)r, (int)i)];
+    memcpy(img.data() + s_b1.off, c.bias, (size_t)H * 4);
+    float *wh8 = reinterpret_cast<float *>(img.data() + s_wh8.off);
+    float *bh8 = reinterpret_cast<float *>(img.data() + s_bh8.off);
+    if (A <= 4) {
+        for (uint32_t n = 0; n < H; ++n) {
+            for (uint32_t i = 0; i < A; ++i) wh8[(size_t)n * 8 + i] = a.weights[(size_t)n * A + i];
+            wh8[(size_t)n * 8 + 4] = v.weights[n];
+        }
+        for (uint32_t i = 0; i < A; ++i) bh8[i] = a.bias[i];
+        bh8[4] = v.bias[0];
+    }
+    memcpy(img.data() + s_w1.off, c.weights, (size_t)E * H * 4);
+    memcpy(img.data() + s_wa.off, a.weights, (size_t)H * A * 4);
+    memcpy(img.data() + s_ba.off, a.bias, (size_t)A * 4);
+    memcpy(img.data() + s_wv.off, v.weights, (size_t)H * 4);
+    memcpy(img.data() + s_bv.off, v.bias, 4);
+    for (uint32_t p = 0; p < d->n_perms; ++p) {
+        for (uint32_t i = 0; i < OS; ++i) img[s_op.off + (size_t)p * OS + i] = (uint8_t)d->obs_perms[(size_t)p * OS + i];
+        for (uint32_t i = 0; i < A; ++i) img[s_ap.off + (size_t)p * A + i] = (uint8_t)d->act_perms[(size_t)p * A + i];
+    }
+
+    tw_policy *pol = new tw_policy();
+    hipError_t e = hipGetDevice(&pol->device);
+    if (e == hipSuccess) e = hipMalloc(&pol->arena, img.size());
+    if (e == hipSuccess) e = hipMemcpy(pol->arena, img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hip_fail(e, "policy upload", __FILE__, __LINE__);
+        if (pol->arena) (void)hipFree(pol->arena);
+        delete pol; return nullptr;
+    }
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(pol->arena);
+    PolicyDev &pd = pol->dev;
+    pd.obs_size = (int)OS; pd.emb = (int)E; pd.hidden = (int)H; pd.n_actions = (int)A; pd.n_perms = (int)d->n_perms;
+    pd.emb_relu = d->emb_apply_relu ? 1 : 0; pd.common_relu = c.apply_relu ? 1 : 0;
+    pd.emb_rows = reinterpret_cast<const float *>(base + s_emb.off);
+    pd.w1p = reinterpret_cast<const float *>(base + s_w1p.off);
+    pd.b1 = reinterpret_cast<const float *>(base + s_b1.off);
+    pd.wh8 = reinterpret_cast<const float *>(base + s_wh8.off);
+    pd.bh8 = reinterpret_cast<const float *>(base + s_bh8.off);
+    pd.w1 = reinterpret_cast<const float *>(base + s_w1.off);
+    pd.wa = reinterpret_cast<const float *>(base + s_wa.off);
+    pd.ba = reinterpret_cast<const float *>(base + s_ba.off);
+    pd.wv = reinterpret_cast<const float *>(base + s_wv.off);
+    pd.bv = reinterpret_cast<const float *>(base + s_bv.off);
+    pd.obs_perms = base + s_op.off;
+    pd.act_perms = base + s_ap.off;
+    return pol;
+}
+
+extern "C" void tw_policy_destroy(tw_policy *p)
+{
+    if (!p) return;
+    if (p->arena) (void)hipFree(p->arena);
+    delete p;
+}
+extern "C" uint32_t tw_policy_num_actions(const tw_policy *p) { return p ? (uint32_t)p->dev.n_actions : 0; }
+extern "C" uint32_t tw_policy_num_perms(const tw_policy *p) { return p ? (uint32_t)p->dev.n_perms : 0; }
+
+extern "C" int tw_policy_evaluate(const tw_policy *p, int mode, uint32_t precision, const int32_t *obs, uint32_t n,
+                                  uint32_t n_obs, const uint8_t *masks, const int32_t *perms, float *out_actions,
+                                  float *out_values)
+{
+    if (!p || !obs || !masks || !out_actions || !out_values) { set_error("tw_policy_evaluate: null argument"); return TW_ERR_INVALID; }
+    if (mode < TW_EVAL_FORWARD || mode > TW_EVAL_FULL_PREDICT) { set_error("tw_policy_evaluate: bad mode %d", mode); return TW_ERR_INVALID; }
+    if (precision != TW_PREC_F32_EXACT) { set_error("tw_policy_evaluate: only TW_PREC_F32_EXACT is implemented"); return TW_ERR_UNSUPPORTED; }
+    if (n == 0) return TW_OK;
+    if (n_obs == 0 || n_obs > 64) { set_error("tw_policy_evaluate: n_obs %u out of range", n_obs); return TW_ERR_INVALID; }
+    const int A = p->dev.n_actions;
+    for (size_t i = 0; i < (size_t)n * n_obs; ++i)
+        if (obs[i] < 0 || obs[i] >= p->dev.obs_size) { set_error("index out of bounds: obs id %d, obs_size %d", obs[i], p->dev.obs_size); return TW_ERR_INVALID; }
+    if (perms)
+        for (uint32_t i = 0; i < n; ++i)
+            if (perms[i] >= p->dev.n_perms) { set_error("perm index %d out of range (%d twists)", perms[i], p->dev.n_perms); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+    hipStream_t s = current_stream();
+    const size_t b_obs = (size_t)n * n_obs * 4, b_m = (size_t)n * A, b_p = (size_t)n * 4, b_oa = (size_t)n * A * 4, b_ov = (size_t)n * 4;
+    const size_t o_obs = 0, o_m = align_up(o_obs + b_obs, 256), o_p = align_up(o_m + b_m, 256),
+                 o_oa = align_up(o_p + b_p, 256), o_ov = align_up(o_oa + b_oa, 256), tot = align_up(o_ov + b_ov, 256);
+    uint8_t *buf = nullptr;
+    TW_HIP(hipMalloc((void **)&buf, tot));
+    auto cleanup = [&]() { (void)hipFree(buf); };
+#define TW_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
+    TW_HIP_C(hipMemcpyAsync(buf + o_obs, obs, b_obs, hipMemcpyHostToDevice, s));
+    TW_HIP_C(hipMemcpyAsync(buf + o_m, masks, b_m, hipMemcpyHostToDevice, s));
+    if (perms) TW_HIP_C(hipMemcpyAsync(buf + o_p, perms, b_p, hipMemcpyHostToDevice, s));
+    rc = launch_policy_eval(p->dev, mode, reinterpret_cast<const int32_t *>(buf + o_obs), n, n_obs, buf + o_m,
+                            perms ? reinterpret_cast<const int32_t *>(buf + o_p) : nullptr,
+                            reinterpret_cast<float *>(buf + o_oa), reinterpret_cast<float *>(buf + o_ov), s);
+    if (rc) { cleanup(); return rc; }
+    TW_HIP_C(hipMemcpyAsync(out_actions, buf + o_oa, b_oa, hipMemcpyDeviceToHost, s));
+    TW_HIP_C(hipMemcpyAsync(out_values, buf + o_ov, b_ov, hipMemcpyDeviceToHost, s));
+    TW_HIP_C(hipStreamSynchronize(s));
+#undef TW_HIP_C
+    cleanup();
+    return TW_OK;
+}
+
+// ====================================================================================== Collected
+struct tw_collected {
+    void *arena = nullptr;                  // one allocation holding every compact field
+    void *field_ptr[TW_F_COUNT] = {};
+    size_t field_bytes[TW_F_COUNT] = {};
+    uint64_t n_records = 0, n_episodes = 0;
+    uint32_t n_cells = 0, n_actions = 0;
+    int is_ppo = 0;
+    tw_collect_stats stats{};
+};
+
+extern "C" uint64_t tw_collected_num_records(const tw_collected *c) { return c ? c->n_records : 0; }
+extern "C" uint64_t tw_collected_num_episodes(const tw_collected *c) { return c ? c->n_episodes : 0; }
+extern "C" uint32_t tw_collected_num_cells(const tw_collected *c) { return c ? c->n_cells : 0; }
+extern "C" uint32_t tw_collected_num_actions(const tw_collected *c) { return c ? c->n_actions : 0; }
+extern "C" int tw_collected_is_ppo(const tw_collected *c) { return c ? c->is_ppo : 0; }
+
+extern "C" void *tw_collected_device_ptr(const tw_collected *c, int field, size_t *bytes)
+{
+    if (!c || field < 0 || field >= TW_F_COUNT) { if (bytes) *bytes = 0; return nullptr; }
+    if (bytes) *bytes = c->field_bytes[field];
+    return c->field_ptr[field];
+}
+
+extern "C" int tw_collected_copy_to_host(const tw_collected *c, int field, void *dst, size_t bytes)
+{
+    if (!c || !dst || field < 0 || field >= TW_F_COUNT) { set_error("copy_to_host: bad argument"); return TW_ERR_INVALID; }
+    if (bytes != c->field_bytes[field]) {
+        set_error("copy_to_host: field %d holds %zu bytes, caller asked for %zu", field, c->field_bytes[field], bytes);
+        return TW_ERR_INVALID;
+    }
+    if (bytes == 0) return TW_OK;
+    TW_HIP(hipMemcpy(dst, c->field_ptr[field], bytes, hipMemcpyDeviceToHost));
+    return TW_OK;
+}
+
+extern "C" int tw_collected_stats(const tw_collected *c, tw_collect_stats *out)
+{
+    if (!c || !out) { set_error("tw_collected_stats: null argument"); return TW_ERR_INVALID; }
+    *out = c->stats; return TW_OK;
+}
+
+extern "C" void tw_collected_free(tw_collected *c)
+{
+    if (!c) return;
+    if (c->arena) (void)hipFree(c->arena);
+    delete c;
+}
+
+// ====================================================================================== PPO collect
+namespace {
+
+struct EventSet {
+    hipEvent_t ev[5] = {};
+    int n = 0;
+    ~EventSet() { for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]); }
+    int init() { for (; n < 5; ++n) TW_HIP(hipEventCreate(&ev[n])); return TW_OK; }
+};
+
+int make_env_consts(const tw_puzzle_desc *env, PuzzleConsts *out)
+{
+    const uint64_t nc = (uint64_t)env->width * env->height;
+    if (env->width == 0 || env->height == 0 || nc > 16) {
+        set_error("Puzzle %ux%u: the HIP path packs the board as 16 nibbles (width*height <= 16)", env->width, env->height);
+        return TW_ERR_UNSUPPORTED;
+    }
+    const uint64_t depth0 = (uint64_t)env->depth_slope * env->difficulty;
+    if (depth0 > 1022 || env->max_depth == 0) {
+        set_error("Puzzle: depth_slope*difficulty = %llu exceeds the supported 1022 (or max_depth == 0)", (unsigned long long)depth0);
+        return TW_ERR_UNSUPPORTED;
+    }
+    out->width = (int)env->width; out->height = (int)env->height; out->n_cells = (int)nc;
+    out->difficulty = (int)env->difficulty; out->depth0 = (int)depth0;
+    out->r_step = -0.5f / (float)env->max_depth;           // puzzle.rs:175
+    uint64_t id = 0;
+    for (uint64_t i = 0; i < nc; ++i) id |= i << (4 * i);
+    out->ident = id;
+    return TW_OK;
+}
+
+}  // namespace
+
+extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy, const tw_ppo_params *prm,
+                              tw_collected **out)
+{
+    if (!env || !policy || !prm || !out) { set_error("tw_ppo_collect: null argument"); return TW_ERR_INVALID; }
+    *out = nullptr;
+    if (prm->num_episodes == 0) {
+        set_error("Something went wrong. No data in collected data chunks to merge. ");   // collector.rs:41
+        return TW_ERR_EMPTY;
+    }
+    if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_ppo_collect: precision %u not implemented", prm->precision); return TW_ERR_UNSUPPORTED; }
+    int rc = require_device(); if (rc) return rc;
+
+    RolloutArgs ra{};
+    rc = make_env_consts(env, &ra.env); if (rc) return rc;
+    ra.pol = policy->dev;
+    if (ra.pol.obs_size != ra.env.n_cells * ra.env.n_cells) {
+        set_error("index out of bounds: policy obs_size %d != Puzzle obs ids %d", ra.pol.obs_size, ra.env.n_cells * ra.env.n_cells);
+        return TW_ERR_INVALID;
+    }
+    if (ra.pol.n_actions != 4) { set_error("Puzzle has 4 actions, policy has %d", ra.pol.n_actions); return TW_ERR_INVALID; }
+    const uint64_t E = prm->num_episodes;
+    const int t_pad = ra.env.depth0 + 1;
+    ra.num_episodes = E; ra.episode_offset = prm->episode_offset; ra.seed = prm->seed;
+
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    hipStream_t s = current_stream();
+
+    // ---- workspace carve ---------------------------------------------------------------------
+    const uint64_t R = E * (uint64_t)t_pad;
+    size_t cur = 0;
+    auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    const size_t o_obs = seg(R * 16), o_lg = seg(R * 16), o_val = seg(R * 4), o_rew = seg(R * 4), o_act = seg(R),
+                 o_prm = seg(R), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
+                 o_scan = seg(scan_scratch_bytes(E));
+    void *wsp = nullptr;
+    rc = ws_reserve(cur, &wsp); if (rc) return rc;
+    uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
+    ra.out.obs = ws + o_obs; ra.out.logits = reinterpret_cast<float *>(ws + o_lg);
+    ra.out.values = reinterpret_cast<float *>(ws + o_val); ra.out.rewards = reinterpret_cast<float *>(ws + o_rew);
+    ra.out.actions = ws + o_act; ra.out.perms = reinterpret_cast<int8_t *>(ws + o_prm);
+    ra.out.ep_len = reinterpret_cast<uint32_t *>(ws + o_len); ra.out.t_pad = t_pad;
+    uint64_t *ep_start_ws = reinterpret_cast<uint64_t *>(ws + o_start);
+    uint64_t *total_d = reinterpret_cast<uint64_t *>(ws + o_total);
+
+    EventSet ev; rc = ev.init(); if (rc) return rc;
+    tw_collect_stats st{};
+    TW_HIP(hipEventRecord(ev.ev[0], s));
+    rc = launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads); if (rc) return rc;
+    TW_HIP(hipEventRecord(ev.ev[1], s));
+    rc = launch_scan(ra.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
+    if (rc) return rc;
+    TW_HIP(hipEventRecord(ev.ev[2], s));
+    uint64_t total = 0;
+    TW_HIP(hipMemcpyAsync(&total, total_d, 8, hipMemcpyDeviceToHost, s));
+    TW_HIP(hipStreamSynchronize(s));
+    if (total == 0 || total > R) { set_error("collect: inconsistent record count %llu (max %llu)", (unsigned long long)total, (unsigned long long)R); return TW_ERR_HIP; }
+
+    // ---- compact result ----------------------------------------------------------------------
+    tw_collected *c = new tw_collected();
+    c->n_records = total; c->n_episodes = E; c->n_cells = (uint32_t)ra.env.n_cells; c->n_actions = 4; c->is_ppo = 1;
+    size_t ccur = 0;
+    auto cseg = [&](int f, size_t bytes) { c->field_bytes[f] = bytes; size_t o = ccur; ccur = align_up(ccur + bytes, 256); return o; };
+    const size_t c_obs = cseg(TW_F_OBS, total * c->n_cells), c_lg = cseg(TW_F_LOGITS, total * 16), c_prm = cseg(TW_F_PERMS, total),
+                 c_val = cseg(TW_F_VALUES, total * 4), c_rew = cseg(TW_F_REWARDS, total * 4), c_act = cseg(TW_F_ACTIONS, total),
+                 c_adv = cseg(TW_F_ADVS, total * 4), c_ret = cseg(TW_F_RETS, total * 4), c_len = cseg(TW_F_EP_LEN, E * 4),
+                 c_start = cseg(TW_F_EP_START, E * 8);
+    hipError_t he = hipMalloc(&c->arena, ccur);
+    if (he != hipSuccess) { delete c; return hip_fail(he, "hipMalloc(compact result)", __FILE__, __LINE__); }
+    uint8_t *ca = reinterpret_cast<uint8_t *>(c->arena);
+    const size_t offs[TW_F_COUNT] = {c_obs, c_lg, c_prm, c_val, c_rew, c_act, c_adv, c_ret, 0, c_len, c_start};
+    for (int f = 0; f < TW_F_COUNT; ++f) c->field_ptr[f] = c->field_bytes[f] ? ca + offs[f] : nullptr;
+    CompactTraj ct{};
+    ct.obs = ca + c_obs; ct.logits = reinterpret_cast<float *>(ca + c_lg); ct.perms = reinterpret_cast<int8_t *>(ca + c_prm);
+    ct.values = reinterpret_cast<float *>(ca + c_val); ct.rewards = reinterpret_cast<float *>(ca + c_rew);
+    ct.actions = ca + c_act; ct.advs = reinterpret_cast<float *>(ca + c_adv); ct.rets = reinterpret_cast<float *>(ca + c_ret);
+
+#define TW_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { tw_collected_free(c); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
+    TW_HIP_C(hipEventRecord(ev.ev[3], s));
+    rc = launch_finalize_ppo(ra.out, ep_start_ws, E, ra.env.n_cells, prm->gamma, prm->lambda, ct, s);
+    if (rc) { tw_collected_free(c); return rc; }
+    TW_HIP_C(hipMemcpyAsync(ca + c_len, ra.out.ep_len, E * 4, hipMemcpyDeviceToDevice, s));
+    TW_HIP_C(hipMemcpyAsync(ca + c_start, ep_start_ws, E * 8, hipMemcpyDeviceToDevice, s));
+    TW_HIP_C(hipEventRecord(ev.ev[4], s));
+    TW_HIP_C(hipStreamSynchronize(s));
+    float ms = 0;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[0], ev.ev[1])); st.ms_rollout = ms;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[1], ev.ev[2])); st.ms_scan = ms;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[3], ev.ev[4])); st.ms_finalize = ms;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[0], ev.ev[4])); st.ms_total = ms;
+#undef TW_HIP_C
+    st.records = total; st.episodes = E; st.padded_bytes = cur; st.forward_evals = total;
+    c->stats = st;
+    *out = c;
+    return TW_OK;
+}
+
+extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy, const tw_az_params *prm, tw_collected **out)
+{
+    (void)env; (void)policy; (void)prm;
+    if (out) *out = nullptr;
+    set_error("tw_az_collect: the MCTS self-play kernel is not built yet (SURVEY.md §8a rows 19-22)");
+    return TW_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,243 @@
+// tw_common.hpp -- shared declarations of the HIP collector library (gfx950 only).
+//
+// Numeric spec shared by every kernel (and restated independently by the CPU oracle):
+//  * RNG: Philox4x32-10, counter = (episode_lo, episode_hi, index, stream), key = seed.
+//    Replaces rand::thread_rng() (reference puzzle.rs:124, policy.rs:72,170), which cannot
+//    be seeded.
+//  * "exact" forward: every Linear is a k-ordered fused-multiply-add chain from 0 with the
+//    bias added last -- exactly what v_mfma_f32_32x32x2_f32 accumulates.
+//  * tw_logf: fixed operation sequence (explicit fma), bit-reproducible on CPU and GPU.
+// The library is compiled with -ffp-contract=off: the only FMAs are the explicit ones.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "twisterl_hip.h"
+
+namespace tw {
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int  hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define TW_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t _e = (call);                                                   \
+        if (_e != hipSuccess) return ::tw::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+hipStream_t current_stream();
+
+// ---- RNG streams (see DESIGN.md "RNG spec") -------------------------------------------------
+enum : uint32_t {
+    STREAM_SCRAMBLE = 0,  // Puzzle::reset scramble actions      (puzzle.rs:124-131)
+    STREAM_GUMBEL   = 1,  // sample_from_logits uniforms         (policy.rs:169-172)
+    STREAM_PERM     = 2,  // Policy::get_perm_id                 (policy.rs:67-77)
+    STREAM_AZ_ACT   = 3,  // AZCollector root action sample      (az.rs:72)
+    STREAM_MCTS     = 4   // MCTSTree::next_sample               (search.rs:94-100)
+};
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0;
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += W0; k1 += W1;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+__host__ __device__ inline u32x4 rng_draw(uint64_t seed, uint64_t episode, uint32_t index, uint32_t stream)
+{
+    return philox4x32_10((uint32_t)episode, (uint32_t)(episode >> 32), index, stream,
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// integer in [0,n): high half of word*n
+__host__ __device__ inline uint32_t u32_below(uint32_t word, uint32_t n)
+{
+    return (uint32_t)(((uint64_t)word * (uint64_t)n) >> 32);
+}
+
+// f32 in [0,1) with 24 random bits (granularity of rand's gen::<f32>(), policy.rs:171)
+__host__ __device__ inline float u32_to_unit(uint32_t word)
+{
+    return (float)(word >> 8) * (1.0f / 16777216.0f);
+}
+
+// Deterministic natural log: explicit op order, same on host and device.
+// Domain: positive normal floats, +0 -> -inf, +inf -> +inf.
+__host__ __device__ inline float tw_logf(float x)
+{
+    if (x == 0.0f) return -__builtin_inff();
+    if (x > 3.4028234e38f) return __builtin_inff();
+    uint32_t ix = __builtin_bit_cast(uint32_t, x);
+    int e = (int)(ix >> 23) - 127;
+    float m = __builtin_bit_cast(float, (ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, f, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, f,  1.1676998740e-1f);
+    p = __builtin_fmaf(p, f, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, f,  1.4249322787e-1f);
+    p = __builtin_fmaf(p, f, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, f,  2.0000714765e-1f);
+    p = __builtin_fmaf(p, f, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, f,  3.3333331174e-1f);
+    float y = (p * f) * z;
+    const float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+// Gumbel-max over 4 masked logits with injected uniforms (policy.rs:130-151,169-172):
+// argmax_i( l_i - ln(|ln(u_i)|) ), strict '>' => first max wins, NaN never wins.
+__host__ __device__ inline int gumbel_argmax4(const float l[4], const u32x4 w)
+{
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    float g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = tw_logf(u32_to_unit(ww[i]));
+        const float b = __builtin_fabsf(a);
+        g[i] = l[i] - tw_logf(b);
+    }
+    int best = 0; float bv = g[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (g[i] > bv) { bv = g[i]; best = i; }
+    return best;
+}
+
+// ---- Puzzle state packed for the device: one nibble per cell (n_cells <= 16, tiles < 16) ----
+struct PuzzleConsts {
+    int32_t  width, height, n_cells;
+    int32_t  difficulty;
+    int32_t  depth0;      // depth_slope * difficulty (puzzle.rs:132)
+    float    r_step;      // -0.5 / max_depth (puzzle.rs:175), computed once on the host in f32
+    uint64_t ident;       // identity board: nibble i == i
+};
+
+struct PuzzleLane {
+    uint64_t board;   // nibble i = tile at cell i
+    int32_t  zx, zy;  // blank location (puzzle.rs:22)
+    int32_t  depth;
+};
+
+__host__ __device__ inline uint32_t nib(uint64_t b, int i) { return (uint32_t)(b >> (4 * i)) & 15u; }
+
+// Env::step (puzzle.rs:135-160): 0 left, 1 up, 2 right, 3 down; illegal = no-op; depth
+// saturating_sub(1) always.
+__host__ __device__ inline void puzzle_step(PuzzleLane &s, const PuzzleConsts &c, int action)
+{
+    int nx = s.zx, ny = s.zy; bool ok = false;
+    if (action == 0)      { ok = s.zx > 0;            nx = s.zx - 1; }
+    else if (action == 1) { ok = s.zy > 0;            ny = s.zy - 1; }
+    else if (action == 2) { ok = s.zx < c.width - 1;  nx = s.zx + 1; }
+    else if (action == 3) { ok = s.zy < c.height - 1; ny = s.zy + 1; }
+    if (ok) {
+        const int zi = s.zy * c.width + s.zx, ti = ny * c.width + nx;
+        const uint64_t tile = (s.board >> (4 * ti)) & 15ull;
+        s.board = (s.board & ~(15ull << (4 * ti))) | (tile << (4 * zi));   // cell zi held 0
+        s.zx = nx; s.zy = ny;
+    }
+    s.depth = s.depth > 0 ? s.depth - 1 : 0;
+}
+
+// Env::reset (puzzle.rs:119-133)
+__host__ __device__ inline void puzzle_reset(PuzzleLane &s, const PuzzleConsts &c, uint64_t seed, uint64_t episode)
+{
+    s.board = c.ident; s.zx = 0; s.zy = 0; s.depth = 0;
+    for (int d = 0; d < c.difficulty; ++d) {
+        const u32x4 w = rng_draw(seed, episode, (uint32_t)d, STREAM_SCRAMBLE);
+        puzzle_step(s, c, (int)u32_below(w.x, 4u));
+    }
+    s.depth = c.depth0;
+}
+
+__host__ __device__ inline bool  puzzle_solved(const PuzzleLane &s, const PuzzleConsts &c) { return s.board == c.ident; }
+__host__ __device__ inline bool  puzzle_final(const PuzzleLane &s, const PuzzleConsts &c) { return s.depth == 0 || s.board == c.ident; }
+__host__ __device__ inline float puzzle_reward(const PuzzleLane &s, const PuzzleConsts &c)
+{
+    return s.board == c.ident ? 1.0f : (s.depth == 0 ? -0.5f : c.r_step);   // puzzle.rs:171-177
+}
+// Env::masks (puzzle.rs:162-165) as bit i = action i allowed
+__host__ __device__ inline uint32_t puzzle_maskbits(const PuzzleLane &s, const PuzzleConsts &c)
+{
+    return (s.zx > 0 ? 1u : 0u) | (s.zy > 0 ? 2u : 0u) | (s.zx < c.width - 1 ? 4u : 0u) | (s.zy < c.height - 1 ? 8u : 0u);
+}
+
+// ---- device-side policy image (built once by tw_policy_create) ------------------------------
+struct PolicyDev {
+    int32_t obs_size, emb, hidden, n_actions, n_perms;
+    int32_t emb_relu, common_relu;
+    // f32 image ("exact" mode)
+    const float *emb_rows;   // [(obs_size+2)][emb]: rows 0..obs_size-1 vectors, row obs_size = bias, row obs_size+1 = 0
+    const float *w1p;        // [emb][32][NT]: w1p[(k*32+i)*NT + r] = W1[k][hid(r,i)]  (MFMA-row order, see tw_rollout.hip)
+    const float *b1;         // [hidden] natural order
+    const float *wh8;        // [hidden][8]: cols 0..3 action weights, col 4 value weight, rest 0
+    const float *bh8;        // [8]: action bias 0..3, value bias 4
+    // natural-layout copies for the generic evaluate kernel
+    const float *w1;         // [emb][hidden]
+    const float *wa;         // [hidden][n_actions]
+    const float *ba;         // [n_actions]
+    const float *wv;         // [hidden]
+    const float *bv;         // [1]
+    const uint8_t *obs_perms; // [n_perms][obs_size] (ids < 256)
+    const uint8_t *act_perms; // [n_perms][n_actions]
+};
+
+// padded (episode-major) trajectory workspace written by the rollout kernel
+struct PaddedTraj {
+    uint8_t *obs;      // [E][t_pad][16]  obs ids, zero padded to 16
+    float   *logits;   // [E][t_pad][4]
+    float   *values;   // [E][t_pad]
+    float   *rewards;  // [E][t_pad]
+    uint8_t *actions;  // [E][t_pad]
+    int8_t  *perms;    // [E][t_pad]
+    uint32_t *ep_len;  // [E]
+    int32_t  t_pad;
+};
+
+// compact output
+struct CompactTraj {
+    uint8_t *obs;      // [n][n_cells]
+    float   *logits;   // [n][4]
+    int8_t  *perms;
+    float   *values, *rewards;
+    uint8_t *actions;
+    float   *advs, *rets;
+};
+
+struct RolloutArgs {
+    PuzzleConsts env;
+    PolicyDev    pol;
+    PaddedTraj   out;
+    uint64_t     num_episodes, episode_offset, seed;
+};
+
+// kernel launchers (each returns a TW_* status)
+int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, uint64_t *ep_start,
+                uint64_t *total /*device*/, void *scratch, size_t scratch_bytes, hipStream_t s);
+size_t scan_scratch_bytes(uint64_t n_episodes);
+int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,
+                        float gamma, float lambda, const CompactTraj &out, hipStream_t s);
+int launch_policy_eval(const PolicyDev &pol, int mode, const int32_t *obs_d, uint32_t n, uint32_t n_obs,
+                       const uint8_t *masks_d, const int32_t *perms_d, float *out_actions_d, float *out_values_d,
+                       hipStream_t s);
+
+}  // namespace tw

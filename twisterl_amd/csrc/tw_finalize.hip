@@ -1,0 +1,205 @@
+// tw_finalize.hip -- episode-length scan, GAE and compaction kernels (gfx950).
+//
+//  * scan: exclusive prefix sum of the per-episode record counts in OUTPUT order.  With
+//    merge_order=1 the output order is the reference's merge() order: the LAST episode first,
+//    then episodes 0..E-2 (rust/src/collector/collector.rs:40-46).
+//  * finalize_ppo: one wave per episode.  Reads the episode's padded rewards/values, runs the
+//    GAE recurrence exactly as written in rust/src/collector/ppo.rs:82-92 (sequential in t,
+//    no contraction: the library is built with -ffp-contract=off), and copies every field of
+//    the episode into its compact slot with coalesced loads/stores.  HBM-bound byte moving;
+//    algorithmic traffic = N^2+34 B written + N^2+26 B read per record.
+#include "tw_common.hpp"
+
+namespace tw {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS   = 4;                       // episodes per thread
+constexpr int SCAN_TILE    = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline uint64_t episode_at(uint64_t pos, uint64_t E, int merge_order)
+{
+    if (!merge_order) return pos;
+    return pos == 0 ? E - 1 : pos - 1;
+}
+
+__device__ inline uint64_t block_reduce_sum(uint64_t v, uint64_t *smem)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    uint64_t tot = 0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) tot += smem[w];
+    __syncthreads();
+    return tot;
+}
+
+// phase 1: per-tile sums
+__global__ void __launch_bounds__(SCAN_THREADS) scan_tile_sums(const uint32_t *ep_len, uint64_t E, int merge_order,
+                                                               uint64_t *tile_sums)
+{
+    __shared__ uint64_t smem[SCAN_THREADS / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const uint64_t pos = base + i;
+        if (pos < E) v += ep_len[episode_at(pos, E, merge_order)];
+    }
+    const uint64_t tot = block_reduce_sum(v, smem);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// phase 2: exclusive scan of the tile sums by ONE workgroup (n_tiles <= a few thousand)
+__global__ void __launch_bounds__(SCAN_THREADS) scan_tile_offsets(uint64_t *tile_sums, uint64_t n_tiles, uint64_t *total)
+{
+    __shared__ uint64_t smem[SCAN_THREADS];
+    __shared__ uint64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n_tiles; base += SCAN_THREADS) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n_tiles ? tile_sums[i] : 0;
+        smem[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < SCAN_THREADS; o <<= 1) {          // Hillis-Steele inclusive scan
+            const uint64_t add = threadIdx.x >= (unsigned)o ? smem[threadIdx.x - o] : 0;
+            __syncthreads();
+            smem[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint64_t carry = carry_s;
+        if (i < n_tiles) tile_sums[i] = carry + smem[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_THREADS - 1) carry_s = carry + smem[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+// phase 3: per-episode start offsets
+__global__ void __launch_bounds__(SCAN_THREADS) scan_write(const uint32_t *ep_len, uint64_t E, int merge_order,
+                                                           const uint64_t *tile_offsets, uint64_t *ep_start)
+{
+    __shared__ uint64_t smem[SCAN_THREADS];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t l[SCAN_ITEMS]; uint64_t ep[SCAN_ITEMS]; uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const uint64_t pos = base + i;
+        ep[i] = pos < E ? episode_at(pos, E, merge_order) : 0;
+        l[i]  = pos < E ? ep_len[ep[i]] : 0u;
+        v += l[i];
+    }
+    smem[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < SCAN_THREADS; o <<= 1) {
+        const uint64_t add = threadIdx.x >= (unsigned)o ? smem[threadIdx.x - o] : 0;
+        __syncthreads();
+        smem[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint64_t run = tile_offsets[blockIdx.x] + smem[threadIdx.x] - v;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < E) ep_start[ep[i]] = run;
+        run += l[i];
+    }
+}
+
+size_t scan_scratch_bytes(uint64_t n_episodes)
+{
+    const uint64_t n_tiles = (n_episodes + SCAN_TILE - 1) / SCAN_TILE;
+    return (size_t)(n_tiles + 1) * sizeof(uint64_t);
+}
+
+int launch_scan(const uint32_t *ep_len, uint64_t E, int merge_order, uint64_t *ep_start, uint64_t *total,
+                void *scratch, size_t scratch_bytes, hipStream_t s)
+{
+    const uint64_t n_tiles = (E + SCAN_TILE - 1) / SCAN_TILE;
+    if (E == 0 || n_tiles > 0x7fffffffull || scratch_bytes < scan_scratch_bytes(E)) {
+        set_error("scan: bad episode count or scratch size");
+        return TW_ERR_INVALID;
+    }
+    uint64_t *tiles = reinterpret_cast<uint64_t *>(scratch);
+    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s, ep_len, E, merge_order, tiles);
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, s, tiles, n_tiles, total);
+    hipLaunchKernelGGL(scan_write, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s, ep_len, E, merge_order, tiles, ep_start);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
+// ---- GAE + compaction ---------------------------------------------------------------------
+constexpr int FIN_WAVES = 4;   // episodes per workgroup (one per wave)
+
+__global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const PaddedTraj in, const uint64_t *ep_start,
+                                                                      uint64_t E, int n_cells, float gamma, float lambda,
+                                                                      const CompactTraj out)
+{
+    extern __shared__ __attribute__((aligned(16))) float fin_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_pad = in.t_pad;
+    float *sr = fin_lds + (size_t)wave * 4 * t_pad;   // rewards | values | advs | rets
+    float *sv = sr + t_pad, *sa = sv + t_pad, *st = sa + t_pad;
+
+    for (uint64_t e = (uint64_t)blockIdx.x * FIN_WAVES + wave; e < E; e += (uint64_t)gridDim.x * FIN_WAVES) {
+        const int      n     = (int)in.ep_len[e];
+        const uint64_t src   = e * (uint64_t)t_pad;
+        const uint64_t dst   = ep_start[e];
+        for (int t = lane; t < n; t += 64) { sr[t] = in.rewards[src + t]; sv[t] = in.values[src + t]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // GAE (ppo.rs:82-92): every lane walks the same chain (LDS broadcast reads); lane 0 stores
+        {
+            float adv = sr[n - 1] - sv[n - 1];
+            float ret = sr[n - 1];
+            if (lane == 0) { sa[n - 1] = adv; st[n - 1] = ret; }
+            for (int t = n - 2; t >= 0; --t) {
+                float inner = lambda * adv;
+                inner = sv[t + 1] + inner;
+                inner = gamma * inner;
+                ret = sr[t] + inner;
+                adv = ret - sv[t];
+                if (lane == 0) { sa[t] = adv; st[t] = ret; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < n; t += 64) {
+            out.values[dst + t]  = sv[t];
+            out.rewards[dst + t] = sr[t];
+            out.advs[dst + t]    = sa[t];
+            out.rets[dst + t]    = st[t];
+            out.actions[dst + t] = in.actions[src + t];
+            out.perms[dst + t]   = in.perms[src + t];
+            reinterpret_cast<float4 *>(out.logits)[dst + t] = reinterpret_cast<const float4 *>(in.logits)[src + t];
+        }
+        if (n_cells == 16) {
+            for (int t = lane; t < n; t += 64)
+                reinterpret_cast<uint4 *>(out.obs)[dst + t] = reinterpret_cast<const uint4 *>(in.obs)[src + t];
+        } else {
+            const int nb = n * n_cells;
+            for (int i = lane; i < nb; i += 64) {
+                const int t = i / n_cells, c = i - t * n_cells;
+                out.obs[dst * n_cells + i] = in.obs[(src + t) * 16 + c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t E, int n_cells, float gamma,
+                        float lambda, const CompactTraj &out, hipStream_t s)
+{
+    if (E == 0) return TW_OK;
+    const size_t lds_bytes = (size_t)FIN_WAVES * 4 * in.t_pad * sizeof(float);
+    if (lds_bytes > 64 * 1024) { set_error("finalize: t_pad %d too large for the LDS tile", in.t_pad); return TW_ERR_UNSUPPORTED; }
+    uint64_t blocks = (E + FIN_WAVES - 1) / FIN_WAVES;
+    if (blocks > 256ull * 16) blocks = 256ull * 16;   // grid-stride the rest
+    hipLaunchKernelGGL(finalize_ppo_kernel, dim3((unsigned)blocks), dim3(FIN_WAVES * 64), lds_bytes, s, in, ep_start, E,
+                       n_cells, gamma, lambda, out);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
+}  // namespace tw

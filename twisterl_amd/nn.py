@@ -1,0 +1,179 @@
+"""`twisterl.nn` surface: Linear, EmbeddingBag, Sequential, Policy.
+
+Mirrors reference rust/src/python_interface/{layers.rs:19-49, modules.rs:19-33, policy.rs:20-46}.
+The constructors take exactly what `BasicPolicy.to_rust()` passes (src/twisterl/nn/policy.py:
+191-199, src/twisterl/nn/utils.py:17-79), so the reference's Python policy exports unchanged.
+Weights are held on the host until first use, then uploaded once to the GPU
+(tw_policy_create); all arithmetic runs in HIP kernels -- without a GPU every compute method
+raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+class Linear:
+    """Linear(weights_vector, bias_vector, apply_relu) (layers.rs:26-33 / nn/layers.rs:24-29):
+    weights_vector = torch_weight.T.flatten(), i.e. [in][out] row-major."""
+
+    def __init__(self, weights_vector, bias_vector, apply_relu):
+        self.bias = np.ascontiguousarray(bias_vector, dtype=np.float32).reshape(-1)
+        self.weights = np.ascontiguousarray(weights_vector, dtype=np.float32).reshape(-1)
+        if self.bias.size == 0 or self.weights.size % self.bias.size != 0:
+            raise ValueError("Linear: len(weights_vector) must be a multiple of len(bias_vector)")
+        self.out_features = int(self.bias.size)
+        self.in_features = int(self.weights.size // self.bias.size)
+        self.apply_relu = bool(apply_relu)
+
+
+class EmbeddingBag:
+    """EmbeddingBag(vec_vectors, bias_vector, apply_relu, obs_shape, conv_dim) (layers.rs:42-48)."""
+
+    def __init__(self, vec_vectors, bias_vector, apply_relu, obs_shape, conv_dim):
+        self.vectors = np.ascontiguousarray(vec_vectors, dtype=np.float32)
+        if self.vectors.ndim != 2:
+            raise ValueError("EmbeddingBag: vec_vectors must be a list of equal-length vectors")
+        self.bias = np.ascontiguousarray(bias_vector, dtype=np.float32).reshape(-1)
+        self.apply_relu = bool(apply_relu)
+        self.obs_shape = [int(s) for s in obs_shape]
+        self.conv_dim = int(conv_dim)
+
+
+class Sequential:
+    """Sequential(layers: list[Linear]) (modules.rs:26-32)."""
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        for l in self.layers:
+            if not isinstance(l, Linear):
+                raise TypeError("Sequential: layers must be twisterl_amd.nn.Linear")
+
+
+def _linear_descs(seq: Sequential, keep: list):
+    arr = (_lib.LinearDesc * max(1, len(seq.layers)))()
+    for i, l in enumerate(seq.layers):
+        arr[i].in_features = l.in_features
+        arr[i].out_features = l.out_features
+        arr[i].weights = l.weights.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].bias = l.bias.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].apply_relu = int(l.apply_relu)
+        keep += [l.weights, l.bias]
+    keep.append(arr)
+    return arr
+
+
+class Policy:
+    """Policy(embeddings, common, action_net, value_net, obs_perms, act_perms) (policy.rs:26-31)."""
+
+    def __init__(self, embeddings: EmbeddingBag, common: Sequential, action_net: Sequential,
+                 value_net: Sequential, obs_perms, act_perms):
+        if not isinstance(embeddings, EmbeddingBag):
+            raise TypeError("embeddings must be twisterl_amd.nn.EmbeddingBag")
+        for s in (common, action_net, value_net):
+            if not isinstance(s, Sequential):
+                raise TypeError("common/action_net/value_net must be twisterl_amd.nn.Sequential")
+        self.embeddings, self.common, self.action_net, self.value_net = embeddings, common, action_net, value_net
+        self.obs_perms = [[int(v) for v in p] for p in obs_perms]
+        self.act_perms = [[int(v) for v in p] for p in act_perms]
+        if len(self.obs_perms) != len(self.act_perms):
+            raise ValueError("obs_perms and act_perms must have the same length.")
+        self._h = None
+        self._n_actions = action_net.layers[-1].out_features if action_net.layers else 0
+        self._rng = np.random.default_rng(int.from_bytes(os.urandom(8), "little"))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().tw_policy_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def num_actions(self) -> int:
+        return self._n_actions
+
+    @property
+    def num_perms(self) -> int:
+        return len(self.obs_perms)
+
+    def _handle(self):
+        """Upload on first use (tw_policy_create); raises RuntimeError without a GPU or for
+        architectures the HIP path does not implement."""
+        if self._h is None:
+            e = self.embeddings
+            if len(e.obs_shape) != 1:
+                raise RuntimeError("policy: the HIP path implements the 1-D EmbeddingBag mode of BasicPolicy "
+                                   "(conv1d mode of Conv1dPolicy is not built)")
+            keep = []
+            d = _lib.PolicyDesc()
+            d.obs_size, d.emb_size = e.vectors.shape
+            if e.bias.size != e.vectors.shape[1]:
+                raise ValueError("EmbeddingBag: bias length must equal the embedding size in 1-D mode")
+            d.emb_vectors = e.vectors.ctypes.data_as(C.POINTER(C.c_float))
+            d.emb_bias = e.bias.ctypes.data_as(C.POINTER(C.c_float))
+            d.emb_apply_relu = int(e.apply_relu)
+            d.n_common, d.common = len(self.common.layers), _linear_descs(self.common, keep)
+            d.n_action, d.action = len(self.action_net.layers), _linear_descs(self.action_net, keep)
+            d.n_value, d.value = len(self.value_net.layers), _linear_descs(self.value_net, keep)
+            d.n_perms, d.n_actions = len(self.obs_perms), self._n_actions
+            if self.obs_perms:
+                op = np.ascontiguousarray(self.obs_perms, dtype=np.int32)
+                ap = np.ascontiguousarray(self.act_perms, dtype=np.int32)
+                if op.shape != (len(self.obs_perms), d.obs_size) or ap.shape != (len(self.obs_perms), d.n_actions):
+                    raise ValueError("obs_perms must be [n_perms][obs_size] and act_perms [n_perms][n_actions]")
+                keep += [op, ap]
+                d.obs_perms = op.ctypes.data_as(C.POINTER(C.c_int32))
+                d.act_perms = ap.ctypes.data_as(C.POINTER(C.c_int32))
+            h = _lib.lib().tw_policy_create(C.byref(d))
+            if not h:
+                raise RuntimeError(_lib.last_error())
+            self._h = h
+        return self._h
+
+    # ---- batched evaluation (tw_policy_evaluate) ----------------------------------------------
+    def evaluate_batch(self, mode: int, obs, masks, perms=None):
+        obs = np.ascontiguousarray(obs, dtype=np.int32)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        if obs.ndim != 2 or masks.ndim != 2 or obs.shape[0] != masks.shape[0]:
+            raise ValueError("obs must be [n][n_obs] and masks [n][n_actions]")
+        n, n_obs = obs.shape
+        if masks.shape[1] != self._n_actions:
+            raise ValueError("masks must have n_actions columns")
+        out_a = np.empty((n, self._n_actions), np.float32)
+        out_v = np.empty((n,), np.float32)
+        pp = None
+        if perms is not None:
+            perms = np.ascontiguousarray(perms, dtype=np.int32)
+            pp = perms.ctypes.data_as(C.POINTER(C.c_int32))
+        _lib.check(_lib.lib().tw_policy_evaluate(
+            self._handle(), mode, _lib.TW_PREC_F32_EXACT, obs.ctypes.data_as(C.POINTER(C.c_int32)), n, n_obs,
+            masks.ctypes.data_as(C.POINTER(C.c_uint8)), pp, out_a.ctypes.data_as(C.POINTER(C.c_float)),
+            out_v.ctypes.data_as(C.POINTER(C.c_float))))
+        return out_a, out_v
+
+    def _single(self, mode, obs, masks, perm):
+        perms = None
+        if mode != _lib.TW_EVAL_FULL_PREDICT and self.obs_perms:
+            if perm is None:   # get_perm_id: uniform over the twists (policy.rs:67-77)
+                perm = int(self._rng.integers(len(self.obs_perms)))
+            perms = [perm]
+        a, v = self.evaluate_batch(mode, [list(obs)], [[1 if m else 0 for m in masks]], perms)
+        return [float(x) for x in a[0]], float(v[0])
+
+    def predict(self, obs, masks, perm=None):
+        """(masked softmax probs, value) (policy.rs:33-35 -> nn/policy.rs:34-49)"""
+        return self._single(_lib.TW_EVAL_PREDICT, obs, masks, perm)
+
+    def forward(self, obs, masks, perm=None):
+        """(masked logits, value) (policy.rs:38-40 -> nn/policy.rs:51-65)"""
+        return self._single(_lib.TW_EVAL_FORWARD, obs, masks, perm)
+
+    def full_predict(self, obs, masks):
+        """average over all twists (policy.rs:42-44 -> nn/policy.rs:102-126)"""
+        return self._single(_lib.TW_EVAL_FULL_PREDICT, obs, masks, None)
