@@ -64,11 +64,13 @@ def build_policy(arrs, obs_perms, act_perms):
                               seq(value), obs_perms, act_perms)
 
 
-def cpu_baseline(arrs, obs_perms, act_perms, side, difficulty, target_seconds):
+def cpu_baseline(arrs, obs_perms, act_perms, side, difficulty, target_seconds, threads=16):
     """Times the CPU oracle (kind 'port': the reference binary cannot be built here) on all host
     cores over a bounded sample of the same workload."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core share of the host; never oversubscribe it
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, threads))
     pol = O.Policy(*arrs, obs_perms, act_perms)
     env = O.Puzzle(side, side, difficulty, 2, 256)
     run = lambda E, seed: O.ppo_collect(env, pol, E, 0.995, 0.995, seed=seed, arith=O.ARITH_REF, det_log=False,
@@ -94,6 +96,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
     ap.add_argument("--no-twists", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -196,7 +199,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

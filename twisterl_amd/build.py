@@ -22,7 +22,7 @@ SOURCES = ["tw_api.hip", "tw_rollout.hip", "tw_finalize.hip", "tw_eval.hip", "tw
 HEADERS = [os.path.join(CSRC, "tw_common.hpp"), os.path.join(ROOT, "include", "twisterl_hip.h")]
 
 # -ffp-contract=off: the numeric spec allows only the explicit fma() calls
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -280,7 +280,8 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     struct Seg { size_t off, bytes; };
     size_t cur = 0;
     auto seg = [&](size_t bytes) { Seg s{cur, bytes}; cur = align_up(cur + bytes, 256); return s; };
-    const Seg s_emb = seg((size_t)(OS + 2) * E * 4), s_w1p = seg((size_t)E * H * 4), s_b1 = seg((size_t)H * 4),
+    const uint32_t NQ = (NT + 3) / 4;     // float4 groups of row-tiles per (k, i)
+    const Seg s_emb = seg((size_t)(OS + 2) * E * 4), s_w1p = seg((size_t)E * NQ * 128 * 4), s_b1 = seg((size_t)H * 4),
               s_wh8 = seg((size_t)H * 8 * 4), s_bh8 = seg(8 * 4), s_w1 = seg((size_t)E * H * 4), s_wa = seg((size_t)H * A * 4),
               s_ba = seg((size_t)A * 4), s_wv = seg((size_t)H * 4), s_bv = seg(4),
               s_op = seg((size_t)(d->n_perms ? d->n_perms : 1) * OS), s_ap = seg((size_t)(d->n_perms ? d->n_perms : 1) * A);
@@ -289,10 +290,15 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     memcpy(emb, d->emb_vectors, (size_t)OS * E * 4);
     memcpy(emb + (size_t)OS * E, d->emb_bias, (size_t)E * 4);                 // bias row; row OS+1 stays zero
     float *w1p = reinterpret_cast<float *>(img.data() + s_w1p.off);
+    // MFMA A-operand image [k][q][i][4]: lane i of k-step k reads row-tiles 4q..4q+3 as one float4
     for (uint32_t k = 0; k < E; ++k)
-        for (uint32_t i = 0; i < 32; ++i)
-            for (uint32_t r = 0; r < NT; ++r)
-                w1p[((size_t)k * 32 + i) * NT + r] = c.weights[(size_t)k * H + hid_row((int)r, (int)i)];
+        for (uint32_t q = 0; q < NQ; ++q)
+            for (uint32_t i = 0; i < 32; ++i)
+                for (uint32_t cc = 0; cc < 4; ++cc) {
+                    const uint32_t r = 4 * q + cc;
+                    w1p[(((size_t)k * NQ + q) * 32 + i) * 4 + cc] =
+                        r < NT ? c.weights[(size_t)k * H + hid_row((int)r, (int)i)] : 0.0f;
+                }
     memcpy(img.data() + s_b1.off, c.bias, (size_t)H * 4);
     float *wh8 = reinterpret_cast<float *>(img.data() + s_wh8.off);
     float *bh8 = reinterpret_cast<float *>(img.data() + s_bh8.off);

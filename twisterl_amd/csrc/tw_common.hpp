@@ -186,7 +186,7 @@ struct PolicyDev {
     int32_t emb_relu, common_relu;
     // f32 image ("exact" mode)
     const float *emb_rows;   // [(obs_size+2)][emb]: rows 0..obs_size-1 vectors, row obs_size = bias, row obs_size+1 = 0
-    const float *w1p;        // [emb][32][NT]: w1p[(k*32+i)*NT + r] = W1[k][hid(r,i)]  (MFMA-row order, see tw_rollout.hip)
+    const float *w1p;        // [emb][NQ][32][4]: W1[k][hid(4q+c, i)] (MFMA A-operand image, see tw_rollout.hip)
     const float *b1;         // [hidden] natural order
     const float *wh8;        // [hidden][8]: cols 0..3 action weights, col 4 value weight, rest 0
     const float *bh8;        // [8]: action bias 0..3, value bias 4

@@ -6,19 +6,23 @@
 // -1e10 mask), sample_from_logits (policy.rs:169-172) and Env::step (puzzle.rs:135-160).
 //
 // Mapping to CDNA4
-//   * one workgroup = 4 waves = 128 episodes, resident for the WHOLE episode (no inter-workgroup
-//     communication: episodes are independent, ppo.rs:59); board state lives in registers as
-//     16 packed nibbles, both lanes (j, j+32) of an MFMA column hold the same episode.
+//   * one workgroup = 8 waves (2 per SIMD) = 256 episodes, resident for the WHOLE episode: no
+//     inter-workgroup communication (episodes are independent, ppo.rs:59).  Board state lives in
+//     registers as 16 packed nibbles; both lanes (j, j+32) of an MFMA column hold the same episode.
 //   * the network is evaluated TRANSPOSED: h1^T[hidden x 32 episodes] = W1^T . h0^T on
-//     v_mfma_f32_32x32x2_f32, episode = MFMA column = lane&31.  The B operand of k-step s is
-//     ONE f32 per lane: h0[episode][2s + (lane>>5)] -- which the lane computes itself as the
-//     EmbeddingBag gather-sum (bias + sum over cells of table[id][k], in cell order) from a
-//     K-chunk of the table staged in LDS (row stride 33 floats: bank = (id + k) % 32, distinct
-//     tiles of one cell hit distinct banks, equal tiles broadcast).
+//     v_mfma_f32_32x32x2_f32, episode = MFMA column = lane&31.  The B operand of k-step s is ONE
+//     f32 per lane: h0[episode][2s + (lane>>5)], which the lane computes itself as the EmbeddingBag
+//     gather-sum (bias + sum over cells of table[id][k], in cell order) from a 32-column chunk of
+//     the table held in LDS (row stride 33 floats: bank = (id + k) % 32, so distinct tiles of one
+//     cell hit distinct banks and equal tiles broadcast).
 //   * an f32 MFMA chain IS a k-ordered fmaf chain, so the result is bit-equal to the oracle's
-//     TWO_ARITH_CHAIN forward; rows of W1 are fed in an order (hid()) that makes the
-//     accumulator registers come out in natural hidden order for the head product, which
-//     consumes the accumulators directly as its B operand (no LDS round trip, no shuffles).
+//     TWO_ARITH_CHAIN forward; rows of W1 are fed in an order (hid()) that makes the accumulator
+//     registers come out in natural hidden order for the head product, which consumes the
+//     accumulators directly as its B operand (no LDS round trip, no shuffles).
+//   * both weight streams are double-buffered in LDS, one barrier per 32-column chunk: the W1
+//     chunk arrives by LDS-DMA (global_load_lds_dwordx4, its image is lane-linear), the padded
+//     table chunk through registers (loads issued before the chunk's MFMAs, ds_write after).
+//     The streams run ahead across timesteps (chunk 0 of step t+1 is fetched during chunk 15 of t).
 //   * heads: [4 logits + value] x hidden on the same MFMA shape (rows 5..31 are zero).
 #include "tw_common.hpp"
 
@@ -27,46 +31,106 @@ namespace tw {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KC   = 32;       // embedding columns staged per LDS chunk
-constexpr int LSTR = KC + 1;   // padded LDS row stride in floats
-constexpr int EPW  = 32;       // episodes per wave (MFMA columns)
-constexpr int EPB  = 128;      // episodes per workgroup
+constexpr int KC      = 32;        // embedding columns per LDS chunk
+constexpr int LSTR    = KC + 1;    // padded LDS row stride of the table chunk (floats)
+constexpr int THREADS = 512;
+constexpr int EPW     = 32;        // episodes per wave (MFMA columns)
+constexpr int EPB     = 256;       // episodes per workgroup
 
 // MFMA row i of row-tile r carries hidden unit hid(r,i) = 32r + 2g + h with
 // g = (i&3) + 4*(i>>3), h = (i>>2)&1: the C/D layout (row = (g&3) + 8*(g>>2) + 4h for
 // accumulator register g on lane half h) then holds hidden unit 32r + 2g + h in register g.
-__host__ __device__ inline int hid(int r, int i) { return 32 * r + 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
+// (tw_api.hip builds the W1 image [k][q][i][4] = W1[k][hid(4q+c, i)] with the same formula.)
+
+template <int NT> struct Tiles { static constexpr int NQ = (NT + 3) / 4; };
+
+// LDS carve (floats): W[2][KC*NQ*128] | T[2][n_rows*LSTR] | b1[NT*32] | wh8[NT*32*8]
+template <int NT>
+__host__ __device__ inline size_t rollout_lds_floats(int obs_size)
+{
+    return (size_t)2 * KC * Tiles<NT>::NQ * 128 + (size_t)2 * (obs_size + 2) * LSTR + (size_t)NT * 32 * 9;
+}
 
 template <int NT, int NC>
-__global__ void __launch_bounds__(256, 2) rollout_f32_kernel(const RolloutArgs a)
+__global__ void __launch_bounds__(THREADS, 2) rollout_f32_kernel(const RolloutArgs a)
 {
+    constexpr int NQ      = Tiles<NT>::NQ;
+    constexpr int WCHUNK  = KC * NQ * 128;                       // floats per W1 chunk
+    constexpr int WPIECES = WCHUNK / 256;                        // 1-KiB LDS-DMA pieces per chunk
+    constexpr int TITER   = (NC * NC * (KC / 4) + THREADS - 1) / THREADS;   // float4 loads per thread per table chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid  = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const PuzzleConsts env = a.env;
     const PolicyDev    pol = a.pol;
     const int n_rows   = pol.obs_size + 2;
     const int bias_row = pol.obs_size, zero_row = pol.obs_size + 1;
+    const int n_chunks = pol.emb / KC;
 
-    // LDS carve: [n_rows][LSTR] table chunk | b1[hidden] | wh8[hidden][8]
-    float *lds_b1 = lds + n_rows * LSTR;
+    float *lds_w  = lds;                                  // [2][WCHUNK]
+    float *lds_t  = lds + 2 * WCHUNK;                     // [2][n_rows*LSTR]
+    float *lds_b1 = lds_t + 2 * n_rows * LSTR;
     float *lds_wh = lds_b1 + NT * 32;
-    for (int i = tid; i < NT * 32; i += 256) lds_b1[i] = pol.b1[i];
-    for (int i = tid; i < NT * 32 * 8; i += 256) lds_wh[i] = pol.wh8[i];
+    const int tbuf = n_rows * LSTR;
 
-    // weight streams go through buffer descriptors: wave-uniform base + one per-lane VGPR offset
-    // + scalar offset, so no per-load 64-bit address registers are kept live across the loops
+    for (int i = tid; i < NT * 32; i += THREADS) lds_b1[i] = pol.b1[i];
+    for (int i = tid; i < NT * 32 * 8; i += THREADS) lds_wh[i] = pol.wh8[i];
+    if (tid < 2 * LSTR) lds_t[(tid / LSTR) * tbuf + zero_row * LSTR + (tid % LSTR)] = 0.0f;   // zero rows, never restaged
+
     const __amdgpu_buffer_rsrc_t rs_emb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(pol.emb_rows), 0, n_rows * pol.emb * (int)sizeof(float), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(pol.w1p), 0, pol.emb * 32 * NT * (int)sizeof(float), 0x00020000);
-    const int w1_voff = (h * 32 + j) * NT * (int)sizeof(float);
 
+    // ---- weight-stream helpers ----------------------------------------------------------------
+    f32x4 tst[TITER];   // table chunk in flight (registers)
+    f32x4 tsb;          // bias-row piece (threads 0..7)
+    auto stream_issue = [&](int chunk, int buf) {
+        // W1 chunk: contiguous 4*WCHUNK bytes -> lane-linear LDS image by LDS-DMA
+#pragma unroll
+        for (int p = 0; p < (WPIECES + 7) / 8; ++p) {
+            const int piece = wave + 8 * p;
+            if (piece < WPIECES) {
+                const float *src = pol.w1p + (size_t)chunk * WCHUNK + piece * 256 + lane * 4;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(lds_w + buf * WCHUNK + piece * 256),
+                                                 16, 0, 0);
+            }
+        }
+        // table chunk: rows 0..obs_size-1 (+ bias row by threads 0..7) to registers
+#pragma unroll
+        for (int it = 0; it < TITER; ++it) {
+            const int idx = tid + it * THREADS, row = idx >> 3, q = idx & 7;
+            if (row < pol.obs_size)
+                tst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_emb, (row * pol.emb + q * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
+        }
+        if (tid < 8)
+            tsb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_emb, (bias_row * pol.emb + tid * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
+    };
+    auto stream_commit = [&](int buf) {
+        float *tb = lds_t + buf * tbuf;
+#pragma unroll
+        for (int it = 0; it < TITER; ++it) {
+            const int idx = tid + it * THREADS, row = idx >> 3, q = idx & 7;
+            if (row < pol.obs_size) {
+                float *d = tb + row * LSTR + q * 4;
+                d[0] = tst[it][0]; d[1] = tst[it][1]; d[2] = tst[it][2]; d[3] = tst[it][3];
+            }
+        }
+        if (tid < 8) {
+            float *d = tb + bias_row * LSTR + tid * 4;
+            d[0] = tsb[0]; d[1] = tsb[1]; d[2] = tsb[2]; d[3] = tsb[3];
+        }
+    };
+
+    // ---- episode state -------------------------------------------------------------------------
     const uint64_t e_local  = (uint64_t)blockIdx.x * EPB + (uint64_t)(wave * EPW + j);
     const bool     valid    = e_local < a.num_episodes;
     const uint64_t e_global = a.episode_offset + e_local;
+
+    stream_issue(0, 0);                                   // overlaps the scramble below
 
     PuzzleLane st;
     st.board = env.ident; st.zx = 0; st.zy = 0; st.depth = 0;
@@ -76,6 +140,10 @@ __global__ void __launch_bounds__(256, 2) rollout_f32_kernel(const RolloutArgs a
     int      t = 0;
     uint32_t len = 0;
     const uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
+
+    stream_commit(0);
+    int cur = 0;                                          // LDS buffer holding the chunk about to be consumed
+    // (the barrier inside __syncthreads_or publishes buffer 0 and the b1/wh8/zero-row stores)
 
     while (__syncthreads_or(alive ? 1 : 0)) {
         // ---- observe (puzzle.rs:183-185) + twist of the obs ids (policy.rs:67-83) -------------
@@ -102,43 +170,31 @@ __global__ void __launch_bounds__(256, 2) rollout_f32_kernel(const RolloutArgs a
             for (int g = 0; g < 16; ++g) acc[r][g] = 0.0f;
 
         // ---- EmbeddingBag (layers.rs:56-62,82-84) fused into common Linear (layers.rs:31-37) --
-        for (int kc = 0; kc < pol.emb; kc += KC) {
-            __syncthreads();
-            for (int idx = tid; idx < n_rows * (KC / 4); idx += 256) {
-                const int row = idx >> 3, q = idx & 7;
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_emb, (row * pol.emb + q * 4) * (int)sizeof(float), kc * (int)sizeof(float), 0));
-                float *d = lds + row * LSTR + q * 4;
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-            }
-            __syncthreads();
-            const float *bias_p = lds + bias_row * LSTR + h;
+        for (int c = 0; c < n_chunks; ++c) {
+            // run the streams one chunk ahead (wrapping to chunk 0 of the next timestep)
+            stream_issue(c + 1 == n_chunks ? 0 : c + 1, cur ^ 1);
+
+            const float *tb = lds_t + cur * tbuf;
+            const float *wl = lds_w + cur * WCHUNK + (h * NQ * 32 + j) * 4;   // A operand base of this lane
+            const float *bias_p = tb + bias_row * LSTR + h;
 #pragma unroll
             for (int s = 0; s < KC / 2; ++s) {
                 float b = bias_p[2 * s];
 #pragma unroll
-                for (int i = 0; i < NC; ++i) b = b + lds[rowoff[i] + 2 * s];
+                for (int i = 0; i < NC; ++i) b = b + tb[rowoff[i] + 2 * s];
                 if (pol.emb_relu) b = b > 0.0f ? b : 0.0f;
-                const int soff = (kc + 2 * s) * 32 * NT * (int)sizeof(float);   // k = kc + 2s (+h via w1_voff)
-                if constexpr (NT % 4 == 0) {
 #pragma unroll
-                    for (int q = 0; q < NT / 4; ++q) {
-                        const f32x4 aw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            rs_w1, w1_voff + q * 16, soff, 0));
-                        acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[0], b, acc[4 * q + 0], 0, 0, 0);
-                        acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[1], b, acc[4 * q + 1], 0, 0, 0);
-                        acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[2], b, acc[4 * q + 2], 0, 0, 0);
-                        acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[3], b, acc[4 * q + 3], 0, 0, 0);
-                    }
-                } else {
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 aw = *reinterpret_cast<const f32x4 *>(wl + (s * 2 * NQ + q) * 128);
 #pragma unroll
-                    for (int r = 0; r < NT; ++r) {
-                        const float aw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rs_w1, w1_voff + r * 4, soff, 0));
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, b, acc[r], 0, 0, 0);
-                    }
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (4 * q + cc < NT)
+                            acc[4 * q + cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cc], b, acc[4 * q + cc], 0, 0, 0);
                 }
             }
+            stream_commit(cur ^ 1);
+            __syncthreads();     // chunk c fully consumed by every wave; chunk c+1 (DMA + ds_write) landed
+            cur ^= 1;
         }
 
         // ---- bias + ReLU of the common layer, then both heads (policy.rs:86-92) ---------------
@@ -203,6 +259,8 @@ __global__ void __launch_bounds__(256, 2) rollout_f32_kernel(const RolloutArgs a
         }
     }
     if (valid && h == 0) a.out.ep_len[e_local] = len;
+    // drain the stream that ran ahead of the last timestep before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int NT, int NC>
@@ -210,11 +268,18 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
 {
     const uint64_t nb = (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = ((size_t)(a.pol.obs_size + 2) * LSTR + (size_t)NT * 32 * 9) * sizeof(float);
-    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC>), dim3((unsigned)nb), dim3(256), lds_bytes, s, a);
+    const size_t lds_bytes = rollout_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
+    if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
+    static size_t attr_bytes = 0;   // per instantiation: raise the dynamic-LDS limit above the 64 KiB default
+    if (lds_bytes > attr_bytes) {
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
-    if (threads) *threads = 256;
+    if (threads) *threads = THREADS;
     return TW_OK;
 }
 
