@@ -42,6 +42,9 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
+    flags = list(FLAGS)
+    if os.environ.get("TW_ABLATE"):      # timing-only ablation variants of the rollout kernel (profiling aid)
+        flags.append("-DTW_ABLATE")
     objs = []
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     procs = []
@@ -50,7 +53,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
-            cmd = [hipcc(), *FLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+            cmd = [hipcc(), *flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
