@@ -1,0 +1,132 @@
+"""CPU: host-side logic of the product (the Puzzle host object behind the C ABI, the
+CollectedData container, collector constructors) against the reference's known answers and the
+oracle.  Nothing here launches a kernel."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from twisterl_amd import twisterl
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+# ------------------------------------------------------------------ env surface (python_interface/env.rs)
+def test_puzzle_known_answers():
+    g = GOLD["puzzle_2x2_step2"]
+    p = twisterl.env.Puzzle(*g["ctor"])
+    assert p.solved() and p.depth == 1
+    p.step(g["action"])
+    assert p.masks() == g["masks"] and p.get_state() == [1, 0, 2, 3]
+    assert p.num_actions() == 4 and p.obs_shape() == [4, 4] and p.twists() == ([], [])
+    assert isinstance(p.__extract_env__(), int)
+
+
+def test_puzzle_replay_123(oracle):
+    g = GOLD["replay_123"]
+    p = twisterl.env.Puzzle(*g["ctor"])
+    p.set_state(g["start"])
+    assert p.depth == 256
+    for a in g["actions"]:
+        assert not p.is_final() and p.masks()[a] and p.reward() == -0.5 / 256
+        p.step(a)
+    assert p.get_state() == g["end"] and p.solved() and p.is_final() and p.reward() == 1.0
+    assert p.observe() == [i * 9 + i for i in range(9)]
+
+
+@pytest.mark.parametrize("w,h", [(3, 3), (4, 4), (2, 3), (5, 5)])
+def test_puzzle_matches_oracle_on_random_walks(oracle, w, h):
+    rng = np.random.default_rng(w * 10 + h)
+    a = twisterl.env.Puzzle(w, h, 9, 2, 64)
+    b = oracle.Puzzle(w, h, 9, 2, 64)
+    a.reset(seed=3, episode=17)
+    b.reset(seed=3, episode=17)
+    assert a.get_state() == b.get_state() and a.depth == b.depth == 18
+    for _ in range(80):
+        act = int(rng.integers(4))
+        a.step(act); b.step(act)
+        assert a.get_state() == b.get_state() and a.masks() == b.masks() and a.observe() == b.observe()
+        assert a.reward() == b.reward() and a.is_final() == b.is_final() and a.depth == b.depth
+    a.difficulty = 3
+    assert a.difficulty == 3
+    a.set_position(0, 0, 7)
+    assert a.get_position(0, 0) == 7
+    with pytest.raises(OverflowError):
+        twisterl.env.Puzzle(3, 3, -1, 2, 256)
+
+
+# ------------------------------------------------------------------ CollectedData (python_interface/collector.rs:24-137)
+def test_collected_data_ctor_and_defaults():
+    d = twisterl.collector.CollectedData([[0, 5]], [[0.1, 0.2]], [0.5], [1.0], [3])      # (obs, logits, values, rewards, actions)
+    assert d.obs == [[0, 5]] and d.values == [0.5] and d.rewards == [1.0] and d.actions == [3]
+    assert d.perms == [-1] and d.additional_data == {}                                    # perms default: None -> -1
+    d2 = twisterl.collector.CollectedData([[1]], [[0.4]], [0.5], [0.6], [0], perms=[2])
+    assert d2.perms == [2]
+    d2.perms = [-5]
+    assert d2.perms == [-1]
+
+
+def test_collected_data_merge_known_answer():
+    """collector.rs:101-126: merge appends; merging chunk d1 into d2 gives actions [0, 1]."""
+    d1 = twisterl.collector.CollectedData([[0]], [[0.1]], [0.2], [0.3], [1], perms=[0])
+    d2 = twisterl.collector.CollectedData([[1]], [[0.4]], [0.5], [0.6], [0])
+    d2.set_additional_data_item("rets", [1.0])
+    d1.set_additional_data_item("rets", [2.0])
+    d1.set_additional_data_item("advs", [3.0])
+    d2.merge(d1)
+    assert d2.actions == GOLD["merge_order"]["merged_actions"] and d2.obs == [[1], [0]] and d2.perms == [-1, 0]
+    assert d2.additional_data == {"rets": [1.0, 2.0], "advs": [3.0]}
+    assert d2.get_additional_data_item("advs") == [3.0] and d2.get_additional_data_item("nope") is None
+    # getters clone: mutating the returned list must not change the container
+    d2.obs.append([9])
+    assert len(d2.obs) == 2
+    d2.values = [1, 2]
+    assert d2.values == [1.0, 2.0]
+
+
+def test_collector_constructors():
+    cfg = {"num_cores": 32, "num_episodes": 1024, "lambda": 0.995, "gamma": 0.995}      # examples/ppo_puzzle8_v1.json:21-26
+    c = twisterl.collector.PPOCollector(**cfg)
+    assert (c.num_episodes, c.gamma, c.lambda_, c.num_cores) == (1024, 0.995, 0.995, 32)
+    c = twisterl.collector.PPOCollector(8, 0.9, 0.95, 1)
+    assert c.lambda_ == 0.95
+    with pytest.raises(TypeError):
+        twisterl.collector.PPOCollector(8, 0.9, 0.95)
+    with pytest.raises(TypeError):
+        twisterl.collector.PPOCollector(8, 0.9, 0.95, 1, bogus=1)
+    with pytest.raises(OverflowError):
+        twisterl.collector.PPOCollector(-1, 0.9, 0.95, 1)
+    a = twisterl.collector.AZCollector(num_episodes=512, num_mcts_searches=1000, C=1.41, max_expand_depth=1, num_cores=32)
+    assert a.num_mcts_searches == 1000
+    with pytest.raises(TypeError):      # AZ_CONFIG's stray "seed" positional-style misuse is still a TypeError for unknown kwargs
+        twisterl.collector.AZCollector(512, 1000, 1.41, 1, 32, bogus=2)
+
+
+def test_collect_rejects_foreign_envs_and_policies():
+    from tests.util import amd_policy, make_policy_arrays
+    pol = amd_policy(make_policy_arrays(9, emb=32, hidden=32))
+    c = twisterl.collector.PPOCollector(4, 0.9, 0.9, 1)
+    with pytest.raises(TypeError, match="Object must implement __extract_env__ method"):   # env.rs:168-170
+        c.collect(object(), pol)
+
+    class Fake:
+        def __extract_env__(self):
+            return 1234
+    with pytest.raises(TypeError, match="Expected environment of type"):
+        c.collect(Fake(), pol)
+    with pytest.raises(TypeError):
+        c.collect(twisterl.env.Puzzle(3, 3, 1, 2, 256), object())
+
+
+def test_policy_constructor_validation():
+    with pytest.raises(ValueError):
+        twisterl.nn.Linear([1.0, 2.0, 3.0], [0.0, 0.0], False)
+    lin = twisterl.nn.Linear([1.0, 2.0, 3.0, 4.0], [1.0, 1.0], False)      # layers.rs:98-103 layout
+    assert (lin.in_features, lin.out_features) == (2, 2)
+    with pytest.raises(TypeError):
+        twisterl.nn.Sequential([object()])
+    emb = twisterl.nn.EmbeddingBag([[1.0, 2.0], [3.0, 4.0]], [0.0, 0.0], False, [2], 0)
+    with pytest.raises(ValueError):
+        twisterl.nn.Policy(emb, twisterl.nn.Sequential([]), twisterl.nn.Sequential([lin]), twisterl.nn.Sequential([lin]),
+                           [[0, 1]], [])
