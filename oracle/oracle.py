@@ -82,7 +82,8 @@ class _AZParams(C.Structure):
     _fields_ = [("num_episodes", C.c_uint64), ("episode_offset", C.c_uint64),
                 ("num_mcts_searches", C.c_uint32), ("C", C.c_float),
                 ("max_expand_depth", C.c_uint32), ("seed", C.c_uint64),
-                ("arith", C.c_int), ("num_threads", C.c_int), ("merge_order", C.c_int)]
+                ("arith", C.c_int), ("num_threads", C.c_int), ("merge_order", C.c_int),
+                ("det_math", C.c_int)]
 
 
 _lib = None
@@ -95,6 +96,8 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.two_logf_det.restype = C.c_float
         L.two_logf_det.argtypes = [C.c_float]
+        L.two_expf_det.restype = C.c_float
+        L.two_expf_det.argtypes = [C.c_float]
         L.two_puzzle_reward.restype = C.c_float
         L.two_puzzle_solved.restype = C.c_int
         L.two_puzzle_is_final.restype = C.c_int
@@ -128,6 +131,15 @@ def philox4x32_10(ctr, key):
 
 def logf_det(x: float) -> float:
     return float(lib().two_logf_det(C.c_float(x)))
+
+
+def expf_det(x: float) -> float:
+    return float(lib().two_expf_det(C.c_float(x)))
+
+
+def set_det_exp(on: bool) -> None:
+    """masked softmax (predict/full_predict/MCTS priors) uses the deterministic exp when on"""
+    lib().two_set_det_exp(C.c_int(int(on)))
 
 
 def logf_det_array(x: np.ndarray) -> np.ndarray:
@@ -381,9 +393,10 @@ def ppo_collect(env: Puzzle, policy: Policy, num_episodes, gamma, lam, seed=0, e
 
 
 def az_collect(env: Puzzle, policy: Policy, num_episodes, num_mcts_searches, Cc, max_expand_depth,
-               seed=0, episode_offset=0, arith=ARITH_REF, num_threads=1, merge_order=True) -> Collected:
+               seed=0, episode_offset=0, arith=ARITH_REF, num_threads=1, merge_order=True,
+               det_math=False) -> Collected:
     prm = _AZParams(num_episodes, episode_offset, num_mcts_searches, Cc, max_expand_depth, seed,
-                    arith, num_threads, int(merge_order))
+                    arith, num_threads, int(merge_order), int(det_math))
     out = _Collected()
     rc = lib().two_az_collect(C.byref(env.p), C.byref(policy.pol), C.byref(prm), C.byref(out))
     if rc != 0:

@@ -92,6 +92,39 @@ float two_logf_det(float x)
     return r;
 }
 
+/* Deterministic expf (Cephes-style, explicit op order); the HIP kernels implement the same
+ * operation sequence, so MCTS priors are bit-equal on CPU and GPU.  Within 2 ulp of libm. */
+float two_expf_det(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return INFINITY;
+    if (x < -103.972077083991796f) return 0.0f;
+    float fx = fmaf(x, 1.44269504088896341f, 0.5f);
+    float fn = floorf(fx);
+    float r = fmaf(fn, -0.693359375f, x);
+    r = fmaf(fn, 2.12194440e-4f, r);
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, z, r);
+    y = y + 1.0f;
+    int n = (int)fn;
+    int n1 = n / 2, n2 = n - n1;
+    uint32_t b1 = (uint32_t)(n1 + 127) << 23, b2 = (uint32_t)(n2 + 127) << 23;
+    float s1, s2; memcpy(&s1, &b1, 4); memcpy(&s2, &b2, 4);
+    y = y * s1;
+    return y * s2;
+}
+
+/* selects libm expf (reference) or two_expf_det inside masked_softmax; set per call by the
+ * det_math flag of the AZ parameters / two_set_det_exp */
+static _Thread_local int g_det_exp = 0;
+void two_set_det_exp(int on) { g_det_exp = on; }
+
 /* ===================================================================================== */
 /* Puzzle (envs/puzzle.rs)                                                               */
 /* ===================================================================================== */
@@ -313,7 +346,7 @@ static void masked_softmax(const float *logits, const uint8_t *masks, int n, flo
 {
     /* policy.rs:43-47 / 118-124: no max-subtraction, eps 1e-6 */
     float sum = 0.0f;
-    for (int i = 0; i < n; ++i) { probs[i] = masks[i] ? expf(logits[i]) : 0.0f; }
+    for (int i = 0; i < n; ++i) { probs[i] = masks[i] ? (g_det_exp ? two_expf_det(logits[i]) : expf(logits[i])) : 0.0f; }
     for (int i = 0; i < n; ++i) sum = sum + probs[i];
     for (int i = 0; i < n; ++i) probs[i] = probs[i] / (sum + 0.000001f);
 }
@@ -763,6 +796,7 @@ static void az_single_collect(const two_puzzle *env0, const two_policy *pol,
 static void *az_worker(void *arg)
 {
     az_job *job = (az_job *)arg;
+    g_det_exp = job->prm->det_math;
     for (;;) {
         unsigned long long i = atomic_fetch_add(&job->next, 1ULL);
         if (i >= job->prm->num_episodes) break;
@@ -775,6 +809,7 @@ static void *az_worker(void *arg)
 int two_az_collect(const two_puzzle *env, const two_policy *pol, const two_az_params *prm,
                    two_collected *out)
 {
+    const int saved_det = g_det_exp;
     const uint64_t E = prm->num_episodes;
     if (E == 0) return -1;
     episode_buf *eps = (episode_buf *)calloc((size_t)E, sizeof(episode_buf));
@@ -793,6 +828,7 @@ int two_az_collect(const two_puzzle *env, const two_policy *pol, const two_az_pa
                             prm->merge_order, out);
     for (uint64_t e = 0; e < E; ++e) ep_free(&eps[e]);
     free(eps);
+    g_det_exp = saved_det;
     return rc;
 }
 

@@ -35,6 +35,10 @@ enum {
 void two_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* deterministic natural log used by the "exact" sampler (same spec as the HIP kernel) */
 float two_logf_det(float x);
+/* deterministic exp used by the "exact" masked softmax (same spec as the HIP kernels) */
+float two_expf_det(float x);
+/* 1: masked softmax (predict / full_predict / MCTS priors) uses two_expf_det; 0: libm expf */
+void  two_set_det_exp(int on);
 
 /* ---- Puzzle env (envs/puzzle.rs:20-185) -------------------------------------------- */
 #define TWO_MAX_CELLS 64
@@ -158,6 +162,7 @@ typedef struct {
     int      arith;
     int      num_threads;
     int      merge_order;
+    int      det_math;         /* 1: two_expf_det in the softmax (bit-equal to the HIP path)   */
 } two_az_params;
 
 /* AZCollector::collect (az.rs:112-130) over Puzzle */

@@ -64,10 +64,18 @@ def test_policy_evaluate_matches_oracle(tw, oracle, n2, emb, hidden):
         np.testing.assert_allclose(la[i], lr, atol=1e-5, rtol=1e-5)                                  # vs reference order
         assert abs(va[i] - vr) <= 1e-5
         po, _ = op.predict(obs[i].tolist(), masks[i].tolist(), perm=int(perms[i]), arith=oracle.ARITH_CHAIN)
-        np.testing.assert_allclose(pa[i], po, atol=1e-6, rtol=1e-5)      # device expf vs libm expf
+        np.testing.assert_allclose(pa[i], po, atol=1e-6, rtol=1e-5)      # spec exp vs the reference's libm expf
         fo, fvo = op.full_predict(obs[i].tolist(), masks[i].tolist(), arith=oracle.ARITH_CHAIN)
         np.testing.assert_allclose(fa[i], fo, atol=1e-6, rtol=1e-5)
         assert abs(fv[i] - fvo) <= 1e-6
+        oracle.set_det_exp(True)                                          # same exp spec on both sides: bit-exact
+        try:
+            po, pvo = op.predict(obs[i].tolist(), masks[i].tolist(), perm=int(perms[i]), arith=oracle.ARITH_CHAIN)
+            fo, fvo = op.full_predict(obs[i].tolist(), masks[i].tolist(), arith=oracle.ARITH_CHAIN)
+        finally:
+            oracle.set_det_exp(False)
+        assert np.array_equal(f32_bits(pa[i]), f32_bits(po)) and f32_bits(pv[i]) == f32_bits(pvo)
+        assert np.array_equal(f32_bits(fa[i]), f32_bits(fo)) and f32_bits(fv[i]) == f32_bits(fvo)
     # single-observation PyO3-style methods
     probs, val = gp.predict(obs[0].tolist(), [bool(m) for m in masks[0]], perm=0)
     assert len(probs) == 4 and abs(sum(probs) - 1.0) < 1e-4 and isinstance(val, float)
@@ -189,6 +197,50 @@ def test_errors(tw, oracle):
     arrs = make_policy_arrays(9, emb=48, hidden=32)
     with pytest.raises(RuntimeError, match="unsupported shape"):
         amd_policy(arrs)._handle()
+
+
+# ------------------------------------------------------------------------------ AlphaZero / MCTS collect
+def _assert_same_az(g, o, n_cells):
+    a = g.to_numpy()
+    assert set(a) == {"obs", "logits", "perms", "remaining_values", "ep_len", "ep_start"}
+    assert np.array_equal(a["ep_len"], o.ep_len)
+    assert np.array_equal(a["obs"].astype(np.int64), o.obs)
+    assert np.all(a["perms"] == -1)
+    assert np.array_equal(f32_bits(a["logits"]), f32_bits(o.logits))              # MCTS probs, bit-exact
+    assert np.array_equal(f32_bits(a["remaining_values"]), f32_bits(o.additional_data["remaining_values"]))
+
+
+@pytest.mark.parametrize("w,h,diff,emb,hidden,E,S,med,twists", [
+    (3, 3, 3, 32, 32, 70, 24, 1, False),     # Puzzle-8, tiny net
+    (3, 3, 2, 64, 64, 33, 16, 2, True),      # max_expand_depth 2 + full_predict over twists
+    (2, 2, 2, 32, 32, 20, 9, 1, False),      # 2x2 board
+    (3, 3, 4, 32, 32, 16, 0, 1, False),      # zero searches -> uniform probs (search.rs:184-186)
+    (3, 3, 0, 32, 32, 10, 5, 1, False),      # difficulty 0: root is final
+    (4, 4, 3, 512, 256, 48, 12, 1, False),   # Puzzle-15 at the benchmark's network size
+])
+def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
+    n2 = w * h
+    gp, op = _pair(oracle, n2, 2, emb, hidden, twists=twists)
+    genv, oenv = tw.env.Puzzle(w, h, diff, 2, 256), oracle.Puzzle(w, h, diff, 2, 256)
+    for merge_order in (True, False):
+        coll = tw.collector.AZCollector(num_episodes=E, num_mcts_searches=S, C=1.41, max_expand_depth=med, num_cores=32,
+                                        merge_order=merge_order)
+        g = coll.collect(genv, gp, seed=31)
+        o = oracle.az_collect(oenv, op, E, S, 1.41, med, seed=31, arith=oracle.ARITH_CHAIN, merge_order=merge_order,
+                              det_math=True)
+        _assert_same_az(g, o, n2)
+        assert g.stats["forward_evals"] >= len(o.obs)      # at least the root evaluation of every move
+
+
+def test_az_reference_style_consumer(tw, oracle):
+    """AZ.data_to_torch reads obs, logits (= MCTS probs) and additional_data['remaining_values']
+    (src/twisterl/rl/az.py:30-34); values / rewards / actions stay empty (az.rs:97-104)."""
+    gp, _ = _pair(oracle, 9, 3, 32, 32)
+    data = tw.collector.AZCollector(8, 10, 1.41, 1, 32).collect(tw.env.Puzzle(3, 3, 3, 2, 256), gp)
+    obs, probs, vals = data.obs, data.logits, data.additional_data["remaining_values"]
+    assert len(obs) == len(probs) == len(vals) > 0
+    assert data.values == [] and data.rewards == [] and data.actions == [] and set(data.perms) == {-1}
+    assert all(abs(sum(p) - 1.0) < 1e-5 for p in probs)
 
 
 # ------------------------------------------------------------------------------ full-size properties

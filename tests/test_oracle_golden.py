@@ -328,6 +328,27 @@ def test_logf_det_tracks_libm(oracle):
     assert oracle.logf_det(0.0) == -math.inf and oracle.logf_det(math.inf) == math.inf
 
 
+def test_expf_det_tracks_libm(oracle):
+    """The deterministic exp of the masked softmax stays within 1 ulp of libm's expf."""
+    xs = np.concatenate([np.linspace(-87, 88, 4001), np.random.default_rng(1).normal(size=4000) * 4]).astype(np.float32)
+    a = np.array([oracle.expf_det(float(x)) for x in xs], np.float32)
+    ref = np.exp(xs.astype(np.float64))
+    ulp = np.spacing(ref.astype(np.float32))
+    assert np.max(np.abs(a - ref) / ulp) <= 1.0
+    assert oracle.expf_det(0.0) == 1.0 and oracle.expf_det(-200.0) == 0.0 and oracle.expf_det(100.0) == math.inf
+    # det-exp softmax vs libm softmax: same probabilities within 1e-6
+    pol = _tiny_policy(oracle)
+    obs = [i * 9 + i for i in range(9)]
+    p0, _ = pol.predict(obs, [True, False, True, True])
+    oracle.set_det_exp(True)
+    try:
+        p1, _ = pol.predict(obs, [True, False, True, True])
+    finally:
+        oracle.set_det_exp(False)
+    np.testing.assert_allclose(p0, p1, atol=1e-6)
+    assert p1[1] == 0.0
+
+
 # ------------------------------------------------------------------ MCTS / AZ (search.rs, az.rs)
 def test_az_collect_shapes_and_remaining_values(oracle):
     """az.rs:97-106,177-186: logits slot holds MCTS probs, values/rewards/actions empty,

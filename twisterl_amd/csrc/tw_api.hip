@@ -576,8 +576,104 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
 
 extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy, const tw_az_params *prm, tw_collected **out)
 {
-    (void)env; (void)policy; (void)prm;
-    if (out) *out = nullptr;
-    set_error("tw_az_collect: the MCTS self-play kernel is not built yet (SURVEY.md §8a rows 19-22)");
-    return TW_ERR_UNSUPPORTED;
+    if (!env || !policy || !prm || !out) { set_error("tw_az_collect: null argument"); return TW_ERR_INVALID; }
+    *out = nullptr;
+    if (prm->num_episodes == 0) {
+        set_error("Something went wrong. No data in collected data chunks to merge. ");   // collector.rs:41
+        return TW_ERR_EMPTY;
+    }
+    if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_az_collect: precision %u not implemented", prm->precision); return TW_ERR_UNSUPPORTED; }
+    int rc = require_device(); if (rc) return rc;
+
+    MctsArgs ma{};
+    rc = make_env_consts(env, &ma.env); if (rc) return rc;
+    ma.pol = policy->dev;
+    if (ma.pol.obs_size != ma.env.n_cells * ma.env.n_cells) {
+        set_error("index out of bounds: policy obs_size %d != Puzzle obs ids %d", ma.pol.obs_size, ma.env.n_cells * ma.env.n_cells);
+        return TW_ERR_INVALID;
+    }
+    if (ma.pol.n_actions != 4) { set_error("Puzzle has 4 actions, policy has %d", ma.pol.n_actions); return TW_ERR_INVALID; }
+    const uint64_t E = prm->num_episodes;
+    const int t_pad = ma.env.depth0 + 1;
+    const uint64_t cap64 = 5ull + 4ull * prm->num_mcts_searches * (prm->max_expand_depth ? prm->max_expand_depth : 1u);
+    if (cap64 > 0x7fffffffull || (uint64_t)prm->num_mcts_searches * (prm->max_expand_depth ? prm->max_expand_depth : 1u) > 0xffffffffull) {
+        set_error("tw_az_collect: num_mcts_searches x max_expand_depth too large"); return TW_ERR_UNSUPPORTED;
+    }
+    ma.num_episodes = E; ma.episode_offset = prm->episode_offset; ma.seed = prm->seed;
+    ma.num_searches = prm->num_mcts_searches; ma.max_expand_depth = prm->max_expand_depth; ma.C = prm->C;
+    ma.node_cap = (uint32_t)cap64;
+
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    hipStream_t s = current_stream();
+
+    const uint64_t R = E * (uint64_t)t_pad;
+    size_t cur = 0;
+    auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    const size_t o_obs = seg(R * 16), o_lg = seg(R * 16), o_rew = seg(R * 4), o_len = seg(E * 4), o_start = seg(E * 8),
+                 o_total = seg(16), o_scan = seg(scan_scratch_bytes(E)), o_arena = seg(E * cap64 * mcts_node_bytes());
+    size_t free_b = 0, total_b = 0;
+    TW_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (cur > (size_t)(0.9 * (double)total_b)) {
+        set_error("tw_az_collect: %zu bytes of tree arenas + trajectories exceed the device memory (%zu)", cur, total_b);
+        return TW_ERR_UNSUPPORTED;
+    }
+    void *wsp = nullptr;
+    rc = ws_reserve(cur, &wsp); if (rc) return rc;
+    uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
+    ma.out.obs = ws + o_obs; ma.out.logits = reinterpret_cast<float *>(ws + o_lg);
+    ma.out.values = nullptr; ma.out.rewards = reinterpret_cast<float *>(ws + o_rew);
+    ma.out.actions = nullptr; ma.out.perms = nullptr;
+    ma.out.ep_len = reinterpret_cast<uint32_t *>(ws + o_len); ma.out.t_pad = t_pad;
+    uint64_t *ep_start_ws = reinterpret_cast<uint64_t *>(ws + o_start);
+    uint64_t *total_d = reinterpret_cast<uint64_t *>(ws + o_total);
+    ma.eval_count = reinterpret_cast<unsigned long long *>(ws + o_total + 8);
+    ma.arena = reinterpret_cast<MctsNode *>(ws + o_arena);
+
+    EventSet ev; rc = ev.init(); if (rc) return rc;
+    tw_collect_stats st{};
+    TW_HIP(hipMemsetAsync(ws + o_total, 0, 16, s));
+    TW_HIP(hipEventRecord(ev.ev[0], s));
+    rc = launch_mcts_f32(ma, s, &st.rollout_blocks, &st.rollout_threads); if (rc) return rc;
+    TW_HIP(hipEventRecord(ev.ev[1], s));
+    rc = launch_scan(ma.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
+    if (rc) return rc;
+    TW_HIP(hipEventRecord(ev.ev[2], s));
+    uint64_t host_tot[2] = {0, 0};
+    TW_HIP(hipMemcpyAsync(host_tot, ws + o_total, 16, hipMemcpyDeviceToHost, s));
+    TW_HIP(hipStreamSynchronize(s));
+    const uint64_t total = host_tot[0];
+    if (total == 0 || total > R) { set_error("az collect: inconsistent record count %llu (max %llu)", (unsigned long long)total, (unsigned long long)R); return TW_ERR_HIP; }
+
+    tw_collected *c = new tw_collected();
+    c->n_records = total; c->n_episodes = E; c->n_cells = (uint32_t)ma.env.n_cells; c->n_actions = 4; c->is_ppo = 0;
+    size_t ccur = 0;
+    auto cseg = [&](int f, size_t bytes) { c->field_bytes[f] = bytes; size_t o = ccur; ccur = align_up(ccur + bytes, 256); return o; };
+    const size_t c_obs = cseg(TW_F_OBS, total * c->n_cells), c_lg = cseg(TW_F_LOGITS, total * 16), c_prm = cseg(TW_F_PERMS, total),
+                 c_rem = cseg(TW_F_REMAINING, total * 4), c_len = cseg(TW_F_EP_LEN, E * 4), c_start = cseg(TW_F_EP_START, E * 8);
+    hipError_t he = hipMalloc(&c->arena, ccur);
+    if (he != hipSuccess) { delete c; return hip_fail(he, "hipMalloc(compact result)", __FILE__, __LINE__); }
+    uint8_t *ca = reinterpret_cast<uint8_t *>(c->arena);
+    c->field_ptr[TW_F_OBS] = ca + c_obs; c->field_ptr[TW_F_LOGITS] = ca + c_lg; c->field_ptr[TW_F_PERMS] = ca + c_prm;
+    c->field_ptr[TW_F_REMAINING] = ca + c_rem; c->field_ptr[TW_F_EP_LEN] = ca + c_len; c->field_ptr[TW_F_EP_START] = ca + c_start;
+
+#define TW_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { tw_collected_free(c); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
+    TW_HIP_C(hipEventRecord(ev.ev[3], s));
+    rc = launch_finalize_az(ma.out, ep_start_ws, E, ma.env.n_cells, ca + c_obs, reinterpret_cast<float *>(ca + c_lg),
+                            reinterpret_cast<int8_t *>(ca + c_prm), reinterpret_cast<float *>(ca + c_rem), s);
+    if (rc) { tw_collected_free(c); return rc; }
+    TW_HIP_C(hipMemcpyAsync(ca + c_len, ma.out.ep_len, E * 4, hipMemcpyDeviceToDevice, s));
+    TW_HIP_C(hipMemcpyAsync(ca + c_start, ep_start_ws, E * 8, hipMemcpyDeviceToDevice, s));
+    TW_HIP_C(hipEventRecord(ev.ev[4], s));
+    TW_HIP_C(hipStreamSynchronize(s));
+    float ms = 0;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[0], ev.ev[1])); st.ms_rollout = ms;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[1], ev.ev[2])); st.ms_scan = ms;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[3], ev.ev[4])); st.ms_finalize = ms;
+    TW_HIP_C(hipEventElapsedTime(&ms, ev.ev[0], ev.ev[4])); st.ms_total = ms;
+#undef TW_HIP_C
+    st.records = total; st.episodes = E; st.padded_bytes = cur;
+    st.forward_evals = host_tot[1] * (uint64_t)(ma.pol.n_perms > 0 ? ma.pol.n_perms : 1);
+    c->stats = st;
+    *out = c;
+    return TW_OK;
 }

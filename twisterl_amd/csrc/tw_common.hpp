@@ -104,6 +104,66 @@ __host__ __device__ inline float tw_logf(float x)
     return r;
 }
 
+// Deterministic exp (Cephes-style, explicit op order; same sequence in the oracle): used by the
+// masked softmax of predict / full_predict / the MCTS priors (policy.rs:43,118), so that UCB
+// arg-max decisions are bit-reproducible on CPU and GPU.  Within 1 ulp of libm.
+__host__ __device__ inline float tw_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return __builtin_inff();
+    if (x < -103.972077083991796f) return 0.0f;
+    const float fx = __builtin_fmaf(x, 1.44269504088896341f, 0.5f);
+    const float fn = __builtin_floorf(fx);
+    float r = __builtin_fmaf(fn, -0.693359375f, x);
+    r = __builtin_fmaf(fn, 2.12194440e-4f, r);
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, z, r);
+    y = y + 1.0f;
+    const int n = (int)fn;
+    const int n1 = n / 2, n2 = n - n1;
+    const float s1 = __builtin_bit_cast(float, (uint32_t)(n1 + 127) << 23);
+    const float s2 = __builtin_bit_cast(float, (uint32_t)(n2 + 127) << 23);
+    y = y * s1;
+    return y * s2;
+}
+
+// masked softmax without max-subtraction, eps 1e-6 (policy.rs:43-47 / 118-124), 4 actions
+__host__ __device__ inline void masked_softmax4(const float l[4], uint32_t maskbits, float p[4])
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = ((maskbits >> i) & 1u) ? tw_expf(l[i]) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum = sum + p[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = p[i] / (sum + 0.000001f);
+}
+
+// nn::policy::sample (policy.rs:153-167) with rand 0.8.5 WeightedIndex semantics and an injected
+// uniform: cumulative weights of the first n-1 entries, chosen = u*total, index = number of
+// cumulative weights <= chosen; invalid weights -> 0 (the reference prints and returns 0).
+__host__ __device__ inline int sample_weighted(const float *w, int n, float u)
+{
+    if (n <= 0) return 0;
+    float total = 0.0f, cum[8];
+    for (int i = 0; i < n; ++i) {
+        if (!(w[i] >= 0.0f)) return 0;
+        total = total + w[i];
+        if (i < n - 1) cum[i] = total;
+    }
+    if (!(total > 0.0f)) return 0;
+    const float chosen = u * total;
+    int idx = 0;
+    while (idx < n - 1 && cum[idx] <= chosen) ++idx;
+    return idx;
+}
+
 // Gumbel-max over 4 masked logits with injected uniforms (policy.rs:130-151,169-172):
 // argmax_i( l_i - ln(|ln(u_i)|) ), strict '>' => first max wins, NaN never wins.
 __host__ __device__ inline int gumbel_argmax4(const float l[4], const u32x4 w)
@@ -236,6 +296,22 @@ int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, ui
 size_t scan_scratch_bytes(uint64_t n_episodes);
 int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,
                         float gamma, float lambda, const CompactTraj &out, hipStream_t s);
+struct MctsNode;   // tw_mcts.hip
+struct MctsArgs {
+    PuzzleConsts env;
+    PolicyDev    pol;
+    PaddedTraj   out;          // obs, logits (= MCTS probs), rewards (= env.reward() per record), ep_len
+    uint64_t     num_episodes, episode_offset, seed;
+    uint32_t     num_searches, max_expand_depth;
+    float        C;
+    MctsNode    *arena;        // [num_episodes][node_cap]
+    uint32_t     node_cap;
+    unsigned long long *eval_count;   // number of policy evaluations (leaf + root), for the stats
+};
+size_t mcts_node_bytes();
+int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+int launch_finalize_az(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,
+                       uint8_t *obs_out, float *probs_out, int8_t *perms_out, float *remaining_out, hipStream_t s);
 int launch_policy_eval(const PolicyDev &pol, int mode, const int32_t *obs_d, uint32_t n, uint32_t n_obs,
                        const uint8_t *masks_d, const int32_t *perms_d, float *out_actions_d, float *out_values_d,
                        hipStream_t s);

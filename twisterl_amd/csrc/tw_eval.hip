@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) policy_eval_kernel(const PolicyD
             for (int i = 0; i < A; ++i) o[i] = m[i] ? la[i] : -1e10f;                // policy.rs:62
         } else {
             float sum = 0.0f;                                                        // policy.rs:43-47,118-124
-            for (int i = 0; i < A; ++i) { o[i] = m[i] ? expf(la[i]) : 0.0f; }
+            for (int i = 0; i < A; ++i) { o[i] = m[i] ? tw_expf(la[i]) : 0.0f; }
             for (int i = 0; i < A; ++i) sum = sum + o[i];
             for (int i = 0; i < A; ++i) o[i] = o[i] / (sum + 0.000001f);
         }

@@ -1,0 +1,363 @@
+// tw_mcts.hip -- AlphaZero self-play kernel: MCTS over per-episode trees with the leaf evaluations
+// of all episodes batched on the shared MFMA policy engine (gfx950).
+//
+// Replaces AZCollector::single_collect (reference rust/src/collector/az.rs:51-109) and
+// predict_probs_mcts (rust/src/rl/search.rs:104-189: MCTSNode::ucb :29-39, backpropagate :45-53,
+// expand :56-75, next :77-91, next_sample :94-100) over the arena tree of rust/src/rl/tree.rs.
+//
+// Mapping: one lane pair = one episode, exactly as in the rollout kernel.  Every episode owns an
+// arena of 32-byte nodes in HBM.  The workgroup alternates between
+//   (1) a per-lane phase: tree walk (UCB descent), expansion of the node evaluated last, weighted
+//       child sampling, back-propagation -- repeated until the lane reaches a leaf that needs the
+//       network (leaves that are final states need none and are consumed on the spot), or the
+//       search budget of the move is spent (then: visit counts -> probs, action, record, env.step);
+//   (2) ONE collective policy evaluation (Policy::full_predict, nn/policy.rs:102-126) of the 32
+//       leaves of each wave on the MFMA engine, i.e. the reference's one-forward-per-search becomes
+//       one batched forward per search step across all resident episodes.
+// All arithmetic follows the numeric spec of DESIGN.md, so MCTS probs are bit-equal to the oracle.
+#include "tw_engine.hpp"
+
+namespace tw {
+
+struct __attribute__((aligned(16))) MctsNode {   // MCTSNode + Node<T> (search.rs:20-26, tree.rs:18-23)
+    uint64_t board;        // state (nibble-packed); the blank position is recovered from it
+    float    value_sum;
+    uint32_t visit;
+    float    prior;
+    uint32_t parent;       // 0xffffffff = None
+    uint32_t child_base;   // children are contiguous in the arena (expand adds them together)
+    uint8_t  n_children;
+    uint8_t  action;       // action_taken (0xff = None)
+    uint16_t depth;
+};
+static_assert(sizeof(MctsNode) == 32, "MctsNode must be 32 bytes");
+size_t mcts_node_bytes() { return sizeof(MctsNode); }
+
+constexpr uint32_t NONE = 0xffffffffu;
+enum { PH_ROOT = 0, PH_LEAF = 1, PH_DONE = 2 };
+
+__device__ inline int blank_cell(uint64_t b)
+{   // lowest zero nibble (the classic zero-byte trick flags only true zeros below the first borrow)
+    const uint64_t m = (b - 0x1111111111111111ull) & ~b & 0x8888888888888888ull;
+    return (int)(__builtin_ctzll(m) >> 2);
+}
+
+__device__ inline PuzzleLane lane_of(const MctsNode &n, const PuzzleConsts &c)
+{
+    PuzzleLane s; s.board = n.board; const int z = blank_cell(n.board);
+    s.zx = z % c.width; s.zy = z / c.width; s.depth = n.depth;
+    return s;
+}
+
+template <int NT, int NC>
+__global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
+{
+    using Eng = Engine<NT, NC, 8, 32, 0>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Eng eng;
+    eng.begin1(a.pol, lds);
+
+    const PuzzleConsts env = a.env;
+    const int j = eng.j, h = eng.h;
+    const uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);
+    const bool     valid    = e_local < a.num_episodes;
+    const uint64_t e_global = a.episode_offset + e_local;
+    const bool     owner    = valid && h == 0;            // the lane that walks / mutates the tree
+    MctsNode *nodes = a.arena + (valid ? e_local : 0) * (uint64_t)a.node_cap;
+    const uint32_t S = a.num_searches, MED = a.max_expand_depth;
+    const uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
+
+    PuzzleLane st;                                        // the episode's env (az.rs:56-57)
+    st.board = env.ident; st.zx = 0; st.zy = 0; st.depth = 0;
+    if (valid) puzzle_reset(st, env, a.seed, e_global);
+
+    // per-episode search state (meaningful on the owner lane; phase/leaf are mirrored to the partner)
+    int      phase = valid ? PH_ROOT : PH_DONE;
+    uint32_t it = 0, expanded = 0, node = 0, n_nodes = 0;
+    int      t = 0;
+    uint32_t len = 0;
+    float    value = 0.0f;
+    PuzzleLane leaf = st;                                 // state whose evaluation is pending
+    unsigned long long evals = 0;
+
+    eng.begin2();
+
+    while (__syncthreads_or(phase != PH_DONE ? 1 : 0)) {
+        // ---- (2) Policy::full_predict of the pending leaf (policy.rs:102-126) ------------------
+        float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
+        const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
+        const float np = (float)eng.pol.n_perms;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int perm = eng.pol.n_perms > 0 ? pass : -1;
+            int rowoff[NC];
+            eng.rows_of(leaf.board, env.n_cells, perm, rowoff);
+            float lg[4], v;
+            eng.forward(rowoff, lg, v);
+            eng.act_perm(perm, lg);
+            if (eng.pol.n_perms > 0) {
+                vsum = vsum + v / np;                                            // policy.rs:111
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lsum[i] = lsum[i] + lg[i] / np;      // policy.rs:112-114
+            } else {
+                vsum = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lsum[i] = lg[i];
+            }
+        }
+        float probs[4];
+        masked_softmax4(lsum, puzzle_maskbits(leaf, env), probs);
+        const float nn_value = vsum;
+
+        // ---- (1) per-episode tree work on the owner lane ---------------------------------------
+        if (owner && phase != PH_DONE) {
+            ++evals;
+            // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step
+            auto expand = [&](uint32_t idx, const PuzzleLane &s) {
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int act = 0; act < 4; ++act) {
+                    if (!(probs[act] > 0.0f)) continue;
+                    PuzzleLane c = s;
+                    puzzle_step(c, env, act);
+                    MctsNode nn;
+                    nn.board = c.board; nn.value_sum = 0.0f; nn.visit = 0; nn.prior = probs[act];
+                    nn.parent = idx; nn.child_base = 0; nn.n_children = 0; nn.action = (uint8_t)act;
+                    nn.depth = (uint16_t)c.depth;
+                    nodes[n_nodes + cnt] = nn;
+                    ++cnt;
+                }
+                nodes[idx].child_base = n_nodes;
+                nodes[idx].n_children = (uint8_t)cnt;
+                n_nodes += cnt;
+            };
+            // backpropagate (search.rs:45-53)
+            auto backprop = [&](uint32_t idx, float val) {
+                while (idx != NONE) {
+                    MctsNode &n = nodes[idx];
+                    n.value_sum = n.value_sum + val;
+                    n.visit += 1;
+                    idx = n.parent;
+                }
+            };
+
+            if (phase == PH_ROOT) {
+                // root node (search.rs:120-129): visit_count 1, then expand with the root priors
+                MctsNode r;
+                r.board = st.board; r.value_sum = 0.0f; r.visit = 1; r.prior = 0.0f; r.parent = NONE;
+                r.child_base = 0; r.n_children = 0; r.action = 0xff; r.depth = (uint16_t)st.depth;
+                nodes[0] = r; n_nodes = 1;
+                expand(0, st);
+                it = 0;
+            } else {
+                // the leaf just evaluated (search.rs:154-159): expand, sample a child by the priors
+                expand(node, leaf);
+                const MctsNode nd = nodes[node];
+                if (nd.n_children > 0) {
+                    float pri[4];
+                    for (int c = 0; c < nd.n_children; ++c) pri[c] = nodes[nd.child_base + c].prior;
+                    const u32x4 w = rng_draw(a.seed, e_global, it * MED + expanded, STREAM_MCTS | ((uint32_t)t << 8));
+                    node = nd.child_base + (uint32_t)sample_weighted(pri, nd.n_children, u32_to_unit(w.x));
+                }
+                value = nn_value;
+                ++expanded;
+            }
+
+            // run the search loop until a leaf needs the network or the move is finished
+            bool resume_expand = (phase == PH_LEAF);
+            for (;;) {
+                if (!resume_expand) {
+                    if (it == S) {
+                        // ---- move finished: visit counts -> probs (search.rs:166-188) --------------
+                        float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        const MctsNode r = nodes[0];
+                        for (int c = 0; c < r.n_children; ++c) {
+                            const MctsNode ch = nodes[r.child_base + c];
+                            mp[ch.action] = (float)ch.visit;
+                        }
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum = sum + mp[i];
+                        if (sum > 0.0f) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) mp[i] = mp[i] / sum;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) mp[i] = 1.0f / 4.0f;
+                        }
+                        // az.rs:72-81: action = sample(mcts_probs); val = env.reward(); store record
+                        const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
+                        const int action = sample_weighted(mp, 4, u32_to_unit(w.x));
+                        const uint64_t rec = rec_base + (uint64_t)t;
+                        uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int i = 0; i < NC; ++i)
+                            if (i < env.n_cells) pk[i >> 2] |= (uint32_t)(i * env.n_cells + (int)nib(st.board, i)) << (8 * (i & 3));
+                        reinterpret_cast<uint4 *>(a.out.obs)[rec]     = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        reinterpret_cast<float4 *>(a.out.logits)[rec] = make_float4(mp[0], mp[1], mp[2], mp[3]);
+                        a.out.rewards[rec] = puzzle_reward(st, env);
+                        if (puzzle_final(st, env)) { phase = PH_DONE; len = (uint32_t)t + 1u; break; }   // az.rs:84
+                        puzzle_step(st, env, action);                                                   // az.rs:89
+                        ++t;
+                        phase = PH_ROOT; leaf = st;
+                        break;
+                    }
+                    // descend to a leaf by UCB (search.rs:133-138, next :77-91, ucb :29-39)
+                    node = 0;
+                    for (;;) {
+                        const MctsNode n = nodes[node];
+                        if (n.n_children == 0) break;
+                        uint32_t best = NONE; float best_ucb = -__builtin_inff();
+                        const float sq = sqrtf((float)n.visit);
+                        for (int c = 0; c < n.n_children; ++c) {
+                            const MctsNode ch = nodes[n.child_base + c];
+                            const float q = ch.visit == 0 ? 0.0f : ch.value_sum / (float)ch.visit;
+                            float d = sq / ((float)ch.visit + 1.0f);
+                            d = a.C * d;
+                            d = d * ch.prior;
+                            const float u = q + d;
+                            if (u > best_ucb) { best = n.child_base + c; best_ucb = u; }
+                        }
+                        if (best == NONE) break;        // all-NaN UCB: the reference panics here
+                        node = best;
+                    }
+                    value = 0.0f; expanded = 0;
+                }
+                resume_expand = false;
+                // leaf phase (search.rs:143-160)
+                if (expanded < MED) {
+                    const MctsNode n = nodes[node];
+                    const PuzzleLane s = lane_of(n, env);
+                    value = puzzle_reward(s, env);                                   // :146
+                    if (!puzzle_final(s, env)) { phase = PH_LEAF; leaf = s; break; } // :149-155 needs the network
+                }
+                backprop(node, value);                                               // :163
+                ++it;
+            }
+        }
+        // mirror what the partner lane needs for the next collective evaluation
+        phase      = __shfl(phase, j, 64);
+        leaf.board = ((uint64_t)__shfl((uint32_t)(leaf.board >> 32), j, 64) << 32) | (uint64_t)__shfl((uint32_t)leaf.board, j, 64);
+        leaf.zx    = __shfl(leaf.zx, j, 64);
+        leaf.zy    = __shfl(leaf.zy, j, 64);
+        leaf.depth = __shfl(leaf.depth, j, 64);
+    }
+    if (owner) {
+        a.out.ep_len[e_local] = len;
+        atomicAdd(a.eval_count, evals);
+    }
+    eng.end();
+}
+
+template <int NT, int NC>
+static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    constexpr int EPB = 8 * EPW;
+    const uint64_t nb = (a.num_episodes + EPB - 1) / EPB;
+    if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
+    const size_t lds_bytes = engine_lds_floats<NT, 32>(a.pol.obs_size) * sizeof(float);
+    if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
+    static size_t attr_bytes = 0;
+    if (lds_bytes > attr_bytes) {
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL((mcts_f32_kernel<NT, NC>), dim3((unsigned)nb), dim3(512), lds_bytes, s, a);
+    TW_HIP(hipGetLastError());
+    if (blocks) *blocks = (uint32_t)nb;
+    if (threads) *threads = 512;
+    return TW_OK;
+}
+
+template <int NT>
+static int launch_mcts_nt(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    const int nc = a.env.n_cells;
+    if (nc <= 4) return launch_mcts_one<NT, 4>(a, s, blocks, threads);
+    if (nc <= 9) return launch_mcts_one<NT, 9>(a, s, blocks, threads);
+    return launch_mcts_one<NT, 16>(a, s, blocks, threads);
+}
+
+int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    // host-side shape checks: everything the kernel indexes with is validated here
+    const uint64_t need = 5ull + 4ull * a.num_searches * (a.max_expand_depth ? a.max_expand_depth : 1u);
+    if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||
+        a.pol.obs_size > 256 || a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 ||
+        a.out.t_pad < a.env.depth0 + 1 || a.node_cap < need || !a.arena || !a.eval_count) {
+        set_error("mcts: unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d node_cap=%u need=%llu)",
+                  a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad, a.node_cap,
+                  (unsigned long long)need);
+        return TW_ERR_UNSUPPORTED;
+    }
+    switch (a.pol.hidden) {
+        case 32:  return launch_mcts_nt<1>(a, s, blocks, threads);
+        case 64:  return launch_mcts_nt<2>(a, s, blocks, threads);
+        case 128: return launch_mcts_nt<4>(a, s, blocks, threads);
+        case 256: return launch_mcts_nt<8>(a, s, blocks, threads);
+        default:
+            set_error("mcts: hidden size %d not in {32,64,128,256}", a.pol.hidden);
+            return TW_ERR_UNSUPPORTED;
+    }
+}
+
+// ---- AZ finalize: remaining_values + compaction (az.rs:93-106) -------------------------------
+constexpr int AZF_WAVES = 4;
+
+__global__ void __launch_bounds__(AZF_WAVES * 64) finalize_az_kernel(const PaddedTraj in, const uint64_t *ep_start, uint64_t E,
+                                                                     int n_cells, uint8_t *obs_out, float *probs_out,
+                                                                     int8_t *perms_out, float *remaining_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float az_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_pad = in.t_pad;
+    float *sr = az_lds + (size_t)wave * 2 * t_pad;   // rewards | prefix sums (total_vals, az.rs:74)
+    float *sp = sr + t_pad;
+    for (uint64_t e = (uint64_t)blockIdx.x * AZF_WAVES + wave; e < E; e += (uint64_t)gridDim.x * AZF_WAVES) {
+        const int      n   = (int)in.ep_len[e];
+        const uint64_t src = e * (uint64_t)t_pad;
+        const uint64_t dst = ep_start[e];
+        for (int t = lane; t < n; t += 64) sr[t] = in.rewards[src + t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float total = 0.0f;                              // az.rs:64,74-76: total_vals.push(total); total += val
+        for (int t = 0; t < n; ++t) {
+            if (lane == 0) sp[t] = total;
+            total = total + sr[t];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < n; t += 64) {
+            remaining_out[dst + t] = total - sp[t];      // az.rs:93
+            perms_out[dst + t] = (int8_t)-1;             // az.rs:95
+            reinterpret_cast<float4 *>(probs_out)[dst + t] = reinterpret_cast<const float4 *>(in.logits)[src + t];
+        }
+        if (n_cells == 16) {
+            for (int t = lane; t < n; t += 64)
+                reinterpret_cast<uint4 *>(obs_out)[dst + t] = reinterpret_cast<const uint4 *>(in.obs)[src + t];
+        } else {
+            const int nb = n * n_cells;
+            for (int i = lane; i < nb; i += 64) {
+                const int t = i / n_cells, c = i - t * n_cells;
+                obs_out[dst * n_cells + i] = in.obs[(src + t) * 16 + c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_finalize_az(const PaddedTraj &in, const uint64_t *ep_start, uint64_t E, int n_cells, uint8_t *obs_out,
+                       float *probs_out, int8_t *perms_out, float *remaining_out, hipStream_t s)
+{
+    if (E == 0) return TW_OK;
+    const size_t lds_bytes = (size_t)AZF_WAVES * 2 * in.t_pad * sizeof(float);
+    if (lds_bytes > 64 * 1024) { set_error("finalize_az: t_pad %d too large for the LDS tile", in.t_pad); return TW_ERR_UNSUPPORTED; }
+    uint64_t blocks = (E + AZF_WAVES - 1) / AZF_WAVES;
+    if (blocks > 256ull * 16) blocks = 256ull * 16;
+    hipLaunchKernelGGL(finalize_az_kernel, dim3((unsigned)blocks), dim3(AZF_WAVES * 64), lds_bytes, s, in, ep_start, E, n_cells,
+                       obs_out, probs_out, perms_out, remaining_out);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
+}  // namespace tw
