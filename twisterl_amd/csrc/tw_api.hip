@@ -11,6 +11,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -524,9 +525,29 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
 
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
+    // diagnostic builds: TW_ROLLOUT_DBG=16 collects per-wave s_memtime sums (see tw_engine.hpp)
+    unsigned long long *stamps_d = nullptr; size_t stamps_n = 0;
+    if (const char *dbg = getenv("TW_ROLLOUT_DBG"); dbg && atoi(dbg) == 16) {
+        stamps_n = ((E + 127) / 128) * 8 * 10;   // enough for 4- and 8-wave workgroups
+        TW_HIP(hipMalloc((void **)&stamps_d, stamps_n * 8));
+        TW_HIP(hipMemsetAsync(stamps_d, 0, stamps_n * 8, s));
+        ra.stamps = stamps_d;
+    }
     TW_HIP(hipEventRecord(ev.ev[0], s));
     rc = launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads); if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[1], s));
+    if (stamps_d) {
+        std::vector<unsigned long long> hsts(stamps_n);
+        TW_HIP(hipMemcpy(hsts.data(), stamps_d, stamps_n * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(stamps_d);
+        double sum[10] = {0}; size_t waves = stamps_n / 10;
+        for (size_t w = 0; w < waves; ++w) for (int i = 0; i < 10; ++i) sum[i] += (double)hsts[w * 10 + i];
+        const char *names[10] = {"stream_issue", "chunk_prologue", "mfma_groups", "commit+vmcnt", "barrier", "heads",
+                                 "forward_total", "outside_forward", "kernel_total", "steps"};
+        fprintf(stderr, "[tw stamps] per-wave mean cycles (s_memtime ticks):");
+        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.0f", names[i], sum[i] / (double)waves);
+        fprintf(stderr, "\n");
+    }
     rc = launch_scan(ra.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
     if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[2], s));

@@ -287,6 +287,7 @@ struct RolloutArgs {
     PolicyDev    pol;
     PaddedTraj   out;
     uint64_t     num_episodes, episode_offset, seed;
+    unsigned long long *stamps;   // diagnostic builds only (TW_ABLATE, DBG & 16): per-wave cycle sums
 };
 
 // kernel launchers (each returns a TW_* status)

@@ -8,6 +8,7 @@ namespace tw {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 
 constexpr int EPW = 32;            // episodes per wave (MFMA columns)
@@ -27,13 +28,36 @@ __device__ __forceinline__ void glds16(const float *gsrc, float *lds_dst)
                  : "memory");
 }
 
+// ReLU as ONE v_max_f32 (hipcc lowers `x > 0 ? x : 0` to a canonicalising v_max plus the v_max).
+// IEEE mode: max(0, NaN) = 0, like the reference's `if x > 0.0 { x } else { 0.0 }` (layers.rs:89-91).
+// The result feeds an MFMA operand; hipcc pads no hazard wait states for an asm output, so the
+// VALU-write -> MFMA-read states (s_nop 1) are inside the string.
+__device__ __forceinline__ float relu1(float x)
+{
+    float y;
+    asm("v_max_f32 %0, 0, %1\n\ts_nop 1" : "=v"(y) : "v"(x));
+    return y;
+}
+
+// Two f32 adds in one VALU instruction (IEEE-exact per element).  Inline asm because hipcc's
+// pre-emit peephole un-packs v_pk_add_f32 that sits in the shadow of an MFMA.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int NT> struct Tiles { static constexpr int NQ = (NT + 3) / 4; };
 
-// LDS carve (floats): W[2][KC*NQ*128] | T[2][n_rows*LSTR] | b1[NT*32] | wh8[NT*32*8]
+// LDS carve (floats): W[2][KC*NQ*128] | T[2][n_rows*LSTR] | b1[2][NT*16] | wh[9][2][NT*16] | bh8[8] |
+//                     obs_perms u8[n_perms][obs_size] | act_perms u8[n_perms][4]
+constexpr int MAX_LDS_PERMS = 4;   // twist tables kept in LDS (more twists fall back to global reads)
 template <int NT, int KC>
 __host__ __device__ inline size_t engine_lds_floats(int obs_size)
 {
-    return (size_t)2 * KC * Tiles<NT>::NQ * 128 + (size_t)2 * (obs_size + 2) * (KC + 4) + (size_t)NT * 32 * 9;
+    return (size_t)2 * KC * Tiles<NT>::NQ * 128 + (size_t)2 * (obs_size + 2) * (KC + 4) + (size_t)NT * 32 * 10 + 8 +
+           (size_t)MAX_LDS_PERMS * ((obs_size + 3) / 4 + 1);
 }
 
 // MFMA row i of row-tile r carries hidden unit hid(r,i) = 32r + 2g + h with
@@ -57,10 +81,21 @@ struct Engine {
     PolicyDev pol;
     int tid, lane, wave, j, h;
     int n_rows, bias_row, zero_row, n_chunks, tbuf, cur;
-    float *lds_w, *lds_t, *lds_b1, *lds_wh;
+    float *lds_w, *lds_t, *lds_b1, *lds_wh, *lds_bh;
+    const uint8_t *perm_obs, *perm_act;   // twist tables: LDS copies when n_perms <= MAX_LDS_PERMS
     __amdgpu_buffer_rsrc_t rs_emb;
     f32x4 tst[TITER];   // table chunk in flight (registers)
     f32x4 tsb;          // bias-row piece (threads 0..KC/4-1)
+    // DBG & 16: s_memtime sums [0] stream issue, [1] chunk prologue, [2] MFMA groups, [3] commit+wait, [4] barrier, [5] heads
+    unsigned long long stamp[6];
+    __device__ __forceinline__ unsigned long long now() const
+    {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    }
 
     __device__ __forceinline__ void stream_issue(int chunk, int buf)
     {
@@ -74,17 +109,42 @@ struct Engine {
                 glds16(src, lds_w + buf * WCHUNK + piece * 256);
             }
         }
-        // table chunk: rows 0..obs_size-1 (+ bias row by threads 0..KC/4-1) to registers
+        // table chunk: rows 0..obs_size-1 (+ bias row) to registers.  The loads are UNCONDITIONAL on
+        // purpose: a predicated load makes hipcc branch around it and wait vmcnt(0) per load (one L2
+        // round trip each); rows past the table are dropped by the descriptor's bounds check (read 0)
+        // and never committed.
 #pragma unroll
         for (int it = 0; it < TITER; ++it) {
             const int idx = tid + it * THREADS, row = idx / (KC / 4), q = idx % (KC / 4);
-            if (row < pol.obs_size)
-                tst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_emb, (row * pol.emb + q * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
+            tst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_emb, (row * pol.emb + q * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
         }
-        if (tid < KC / 4)
+        tsb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs_emb, (bias_row * pol.emb + (tid % (KC / 4)) * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
+    }
+
+    // One stream operation of the next chunk (op < NOPS): DMA pieces first, then table loads, then
+    // the bias piece.  Issued one at a time between MFMAs so the VMEM queue never sees a burst.
+    static constexpr int NDMA = (WPIECES + NW - 1) / NW;
+    static constexpr int NOPS = NDMA + TITER + 1;
+    __device__ __forceinline__ void stream_op(int chunk, int buf, int op)
+    {
+        if constexpr (DBG & 4) return;
+        if (op < NDMA) {
+            const int piece = wave + NW * op;
+            if (piece < WPIECES) {
+                const float *src = pol.w1p + (size_t)chunk * WCHUNK + piece * 256 + lane * 4;
+                glds16(src, lds_w + buf * WCHUNK + piece * 256);
+            }
+        } else if (op < NDMA + TITER) {
+            const int it = op - NDMA;
+            const int idx = tid + it * THREADS, row = idx / (KC / 4), q = idx % (KC / 4);
+            tst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_emb, (row * pol.emb + q * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
+        } else {
             tsb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rs_emb, (bias_row * pol.emb + tid * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
+                rs_emb, (bias_row * pol.emb + (tid % (KC / 4)) * 4) * (int)sizeof(float), chunk * KC * (int)sizeof(float), 0));
+        }
     }
 
     __device__ __forceinline__ void stream_commit(int buf)
@@ -122,12 +182,29 @@ struct Engine {
         lds_t  = lds + 2 * WCHUNK;                     // [2][n_rows*LSTR]
         lds_b1 = lds_t + 2 * n_rows * LSTR;
         lds_wh = lds_b1 + NT * 32;
+        lds_bh = lds_wh + NT * 32 * 9;
         tbuf = n_rows * LSTR;
-        for (int i = tid; i < NT * 32; i += THREADS) lds_b1[i] = pol.b1[i];
-        for (int i = tid; i < NT * 32 * 8; i += THREADS) lds_wh[i] = pol.wh8[i];
+        // head operands re-laid so that a lane's next four k-steps are one 16-byte word:
+        //   b1[h][m] = b1[2m + h];  wh[c][h][m] = wh8[2m + h][c] for c < 8;  wh[8][.][.] = 0 (lanes j >= 8)
+        for (int i = tid; i < NT * 32; i += THREADS) lds_b1[(i & 1) * (NT * 16) + (i >> 1)] = pol.b1[i];
+        for (int i = tid; i < NT * 32 * 8; i += THREADS) {
+            const int n = i >> 3, c = i & 7;
+            lds_wh[(c * 2 + (n & 1)) * (NT * 16) + (n >> 1)] = pol.wh8[i];
+        }
+        for (int i = tid; i < NT * 32; i += THREADS) lds_wh[8 * 2 * (NT * 16) + i] = 0.0f;
+        if (tid < 8) lds_bh[tid] = pol.bh8[tid];
+        perm_obs = pol.obs_perms; perm_act = pol.act_perms;
+        if (pol.n_perms > 0 && pol.n_perms <= MAX_LDS_PERMS) {
+            uint8_t *po = reinterpret_cast<uint8_t *>(lds_bh + 8);
+            uint8_t *pa = po + MAX_LDS_PERMS * ((pol.obs_size + 3) / 4) * 4;
+            for (int i = tid; i < pol.n_perms * pol.obs_size; i += THREADS) po[i] = pol.obs_perms[i];
+            for (int i = tid; i < pol.n_perms * 4; i += THREADS) pa[i] = pol.act_perms[i];
+            perm_obs = po; perm_act = pa;
+        }
         if (tid < 2 * LSTR) lds_t[(tid / LSTR) * tbuf + zero_row * LSTR + (tid % LSTR)] = 0.0f;   // zero rows, never restaged
         rs_emb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pol.emb_rows), 0,
                                                    n_rows * pol.emb * (int)sizeof(float), 0x00020000);
+        if constexpr (DBG & 16) for (int i = 0; i < 6; ++i) stamp[i] = 0;
         stream_issue(0, 0);
     }
     // Part 2: commit chunk 0.  The caller's next workgroup barrier publishes it.
@@ -149,7 +226,7 @@ struct Engine {
             int row = zero_row;
             if (i < n_cells) {
                 const int id = i * n_cells + (int)nib(board, i);
-                row = perm >= 0 ? (int)pol.obs_perms[perm * pol.obs_size + id] : id;
+                row = perm >= 0 ? (int)perm_obs[perm * pol.obs_size + id] : id;
             }
             rowoff[i] = row * LSTR + h * (KC / 2);
         }
@@ -169,7 +246,11 @@ struct Engine {
         // ---- EmbeddingBag (layers.rs:56-62,82-84) fused into common Linear (layers.rs:31-37) --
         for (int c = 0; c < n_chunks; ++c) {
             // run the streams one chunk ahead (wrapping to chunk 0 of the next forward)
-            stream_issue(c + 1 == n_chunks ? 0 : c + 1, cur ^ 1);
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+            if constexpr (DBG & 16) t0 = now();
+            const int next_chunk = c + 1 == n_chunks ? 0 : c + 1;
+            if constexpr (NG < 2) stream_issue(next_chunk, cur ^ 1);      // no room to spread
+            if constexpr (DBG & 16) t1 = now();
 
             const float *tb = lds_t + cur * tbuf;
             const float *wl = lds_w + cur * WCHUNK + (h * NQ * 32 + j) * 4;   // A operand base of this lane
@@ -188,20 +269,36 @@ struct Engine {
             };
 
             // prologue: B operands of group 0 (exposed once per chunk) and the first A operands
-            f32x4 bq = *gather_ptr(0, 0);
-            if constexpr (!(DBG & 1))
+            // (the f32 MFMA executes on the SIMD's f32 FMA lanes, so VALU work does not overlap it:
+            //  the four add chains go through v_pk_add_f32, two chains per instruction, IEEE-exact)
+            f32x4 bq;
+            {
+                const f32x4 r0 = *gather_ptr(0, 0);
+                f32x2 lo = __builtin_shufflevector(r0, r0, 0, 1), hi = __builtin_shufflevector(r0, r0, 2, 3);
+                if constexpr (!(DBG & 1))
 #pragma unroll
-                for (int q = 1; q <= NC; ++q) bq = bq + *gather_ptr(q, 0);
-            if (pol.emb_relu)
+                    for (int q = 1; q <= NC; ++q) {
+                        const f32x4 rq = *gather_ptr(q, 0);
+                        lo = pk_add(lo, __builtin_shufflevector(rq, rq, 0, 1));
+                        hi = pk_add(hi, __builtin_shufflevector(rq, rq, 2, 3));
+                    }
+                bq[0] = lo[0]; bq[1] = lo[1]; bq[2] = hi[0]; bq[3] = hi[1];
+            }
+            if (pol.emb_relu) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bq[u] = bq[u] > 0.0f ? bq[u] : 0.0f;
+                for (int u = 0; u < 4; ++u) bq[u] = relu1(bq[u]);
+            } else {
+                asm volatile("s_nop 1" : "+v"(bq));      // asm VALU result -> MFMA operand wait states
+            }
             f32x4 aw[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) aw[q] = *a_ptr(0, q);
+            if constexpr (DBG & 16) t2 = now();
 
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                f32x4 nb, rd[NC + 1];
+                f32x4 rd[NC + 1];
+                f32x2 nlo, nhi;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const int u = m / NT, r = m % NT;               // k-step 4g+u, row-tile r
@@ -211,6 +308,14 @@ struct Engine {
                     if constexpr (!(DBG & 2))
                         if ((r % 4 == 3 || r == NT - 1) && !(g == NG - 1 && u == 3))
                             aw[r / 4] = *a_ptr(4 * g + u + 1, r / 4);
+                    // stream of the next chunk: one VMEM op every SPACING slots over the first NG-1 groups
+                    if constexpr (NG >= 2) {
+                        constexpr int SPAN = (NG - 1) * M, SPACING = SPAN / NOPS > 0 ? SPAN / NOPS : 1;
+                        const int slot = g * M + m;
+                        if (slot % SPACING == 0 && slot / SPACING < NOPS) stream_op(next_chunk, cur ^ 1, slot / SPACING);
+                        if (SPAN < NOPS && slot == SPAN - 1)                   // more ops than slots: flush the rest
+                            for (int op = SPAN; op < NOPS; ++op) stream_op(next_chunk, cur ^ 1, op);
+                    }
                     // gather of the next group: reads, then (LAT slots later) four independent adds
                     if (g + 1 < NG) {
 #pragma unroll
@@ -218,22 +323,37 @@ struct Engine {
                             if (rd_slot(q) == m) rd[q] = *gather_ptr(q, g + 1);
 #pragma unroll
                         for (int q = 0; q <= ((DBG & 1) ? 0 : NC); ++q)
-                            if (add_slot(q) == m) nb = (q == 0) ? rd[0] : nb + rd[q];
+                            if (add_slot(q) == m) {
+                                const f32x2 qlo = __builtin_shufflevector(rd[q], rd[q], 0, 1);
+                                const f32x2 qhi = __builtin_shufflevector(rd[q], rd[q], 2, 3);
+                                if (q == 0) { nlo = qlo; nhi = qhi; } else { nlo = pk_add(nlo, qlo); nhi = pk_add(nhi, qhi); }
+                            }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (g + 1 < NG) {
-                    if (pol.emb_relu)
+                    bq[0] = nlo[0]; bq[1] = nlo[1]; bq[2] = nhi[0]; bq[3] = nhi[1];
+                    if (pol.emb_relu) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) nb[u] = nb[u] > 0.0f ? nb[u] : 0.0f;
-                    bq = nb;
+                        for (int u = 0; u < 4; ++u) bq[u] = relu1(bq[u]);
+                    } else {
+                        asm volatile("s_nop 1" : "+v"(bq));
+                    }
                 }
             }
+            if constexpr (DBG & 16) t3 = now();
             stream_commit(cur ^ 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
+            if constexpr (DBG & 16) t4 = now();
             __syncthreads();     // chunk c fully consumed by every wave; chunk c+1 (DMA + ds_write) landed
             cur ^= 1;
+            if constexpr (DBG & 16) {
+                const unsigned long long t5 = now();
+                stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3; stamp[4] += t5 - t4;
+            }
         }
+        unsigned long long th0 = 0;
+        if constexpr (DBG & 16) th0 = now();
 
         if constexpr (DBG & 8) {
             value = 0.0f;
@@ -246,27 +366,33 @@ struct Engine {
         f32x16 hacc;
 #pragma unroll
         for (int g = 0; g < 16; ++g) hacc[g] = 0.0f;
-        // one per-lane LDS base each (kept opaque so every access is base + immediate offset; explicit
-        // LDS address space: an opaque GENERIC pointer would turn these into flat loads)
-        lds_cfloat *b1_lane = (lds_cfloat *)(lds_b1 + h);
-        lds_cfloat *wh_lane = (lds_cfloat *)(lds_wh + h * 8 + (j & 7));
-        asm volatile("" : "+v"(b1_lane), "+v"(wh_lane));
+        // per lane: b1 of its half, and its head-weight row (lanes j >= 8 read the zero row)
+        lds_cfloat *b1_lane = (lds_cfloat *)(lds_b1 + h * (NT * 16));
+        lds_cfloat *wh_lane = (lds_cfloat *)(lds_wh + ((j < 8 ? j : 8) * 2 + h) * (NT * 16));
+        asm volatile("" : "+v"(b1_lane), "+v"(wh_lane));   // opaque: every access = base + immediate
+        // register g of row-tile r holds hidden unit 32r + 2g + h = element 16r + g of this lane's half
+        f32x4 hb[2], hw[2];
+        hb[0] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(b1_lane);
+        hw[0] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(wh_lane);
 #pragma unroll
-        for (int r = 0; r < NT; ++r) {
+        for (int blk = 0; blk < NT * 4; ++blk) {           // 4 accumulator registers per block
+            const int r = blk >> 2, g0 = (blk & 3) * 4, cb = blk & 1, nb = cb ^ 1;
+            if (blk + 1 < NT * 4) {
+                hb[nb] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(b1_lane + 4 * (blk + 1));
+                hw[nb] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(wh_lane + 4 * (blk + 1));
+            }
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int n0 = 32 * r + 2 * g;   // hidden unit n = n0 + h
-                float hv = acc[r][g] + b1_lane[n0];
-                if (pol.common_relu) hv = hv > 0.0f ? hv : 0.0f;
-                const float awl = wh_lane[n0 * 8];
-                const float aw  = j < 8 ? awl : 0.0f;
-                hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, hv, hacc, 0, 0, 0);
+            for (int g = 0; g < 4; ++g) {
+                float hv = acc[r][g0 + g] + hb[cb][g];
+                if (pol.common_relu) hv = relu1(hv);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(hw[cb][g], hv, hacc, 0, 0, 0);
             }
         }
         // rows 0..3 (logits) sit in registers 0..3 of lane (j,0); row 4 (value) in register 0 of lane (j,1)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lg[i] = __shfl(hacc[i], j, 64) + pol.bh8[i];
-        value = __shfl(hacc[0], j + 32, 64) + pol.bh8[4];
+        for (int i = 0; i < 4; ++i) lg[i] = __shfl(hacc[i], j, 64) + lds_bh[i];
+        value = __shfl(hacc[0], j + 32, 64) + lds_bh[4];
+        if constexpr (DBG & 16) stamp[5] += now() - th0;
     }
 
     // logits'[i] = logits[act_perm[i]]  (policy.rs:95-97)
@@ -276,7 +402,7 @@ struct Engine {
         const float l0 = lg[0], l1 = lg[1], l2 = lg[2], l3 = lg[3];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int src = pol.act_perms[perm * 4 + i];
+            const int src = perm_act[perm * 4 + i];
             lg[i] = src == 0 ? l0 : (src == 1 ? l1 : (src == 2 ? l2 : l3));
         }
     }

@@ -64,6 +64,8 @@ __global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutAr
 
     eng.begin2();
     // (the barrier inside __syncthreads_or publishes LDS buffer 0 and the b1/wh8/zero-row stores)
+    unsigned long long ts_fwd = 0, ts_rest = 0, ts_mark = 0, ts_k0 = 0;
+    if constexpr (DBG & 16) { ts_mark = eng.now(); ts_k0 = ts_mark; }
 
     while (__syncthreads_or(alive ? 1 : 0)) {
         // ---- observe (puzzle.rs:183-185) + twist of the obs ids (policy.rs:67-83) -------------
@@ -76,7 +78,9 @@ __global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutAr
         eng.rows_of(st.board, env.n_cells, perm, rowoff);
 
         float lg[4]; float value;
+        if constexpr (DBG & 16) { const unsigned long long n0 = eng.now(); ts_rest += n0 - ts_mark; ts_mark = n0; }
         eng.forward(rowoff, lg, value);
+        if constexpr (DBG & 16) { const unsigned long long n0 = eng.now(); ts_fwd += n0 - ts_mark; ts_mark = n0; }
 
         float rew = 0.0f; int action = t & 3;
         if constexpr (!(DBG & 8)) {
@@ -108,6 +112,13 @@ __global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutAr
         }
     }
     if (valid && h == 0) a.out.ep_len[e_local] = len;
+    if constexpr (DBG & 16) {
+        if (eng.lane == 0 && a.stamps) {
+            unsigned long long *o = a.stamps + ((size_t)blockIdx.x * NW + eng.wave) * 10;
+            for (int i = 0; i < 6; ++i) o[i] = eng.stamp[i];
+            o[6] = ts_fwd; o[7] = ts_rest; o[8] = eng.now() - ts_k0; o[9] = (unsigned long long)t;
+        }
+    }
     eng.end();
 }
 
@@ -147,6 +158,12 @@ template <int NT, int NC>
 static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     const int g = geom_sel();
+#ifdef TW_ABLATE
+    if constexpr (NT == 8 && NC == 16) {
+        const char *d = getenv("TW_ROLLOUT_DBG");
+        if (d && atoi(d) == 16 && g == 2) return launch_geom<NT, NC, 4, 32, 16>(a, s, blocks, threads);
+    }
+#endif
     if (g == 1) return launch_geom<NT, NC, 4, 16>(a, s, blocks, threads);
     if (g == 2) return launch_geom<NT, NC, 4, 32>(a, s, blocks, threads);   // diagnostic: one wave per SIMD
 #ifdef TW_ABLATE
@@ -159,6 +176,7 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
             case 3: return launch_geom<NT, NC, 8, 32, 3>(a, s, blocks, threads);
             case 4: return launch_geom<NT, NC, 8, 32, 4>(a, s, blocks, threads);
             case 8: return launch_geom<NT, NC, 8, 32, 8>(a, s, blocks, threads);
+            case 16: return launch_geom<NT, NC, 8, 32, 16>(a, s, blocks, threads);
             default: break;
         }
     }
