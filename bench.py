@@ -33,6 +33,19 @@ BYTES_PER_RECORD = {16: 58, 9: 51}
 PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0}     # MI355X_MICROARCH.md: f32 MFMA (=vector) / dense f16 MFMA
 
 
+def measured_traffic_per_record():
+    """HBM bytes per record of the rollout kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        for k, v in d.items():
+            if "rollout" in k:
+                return float(v["bytes_per_record"])
+    except Exception:
+        pass
+    return None
+
+
 def synthetic_weights(n2: int, seed: int = 0):
     """torch default-init weights of BasicPolicy(obs n2*n2 -> 512 -> 256 -> 4|1) under
     torch.manual_seed(seed), exported in the reference layout (src/twisterl/nn/utils.py:17-79)."""
@@ -168,6 +181,7 @@ def main():
     if rank == 0:
         kern_s = float(np.mean(ms_rollout)) * 1e-3
         rec_per_launch = records / args.steps
+        tpr = measured_traffic_per_record() if (args.puzzle == 15 and args.precision == "fp32") else None
         achieved = rec_per_launch * FLOP_PER_RECORD[n2] / kern_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
         out = {
@@ -192,7 +206,10 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "kernel": "tw::rollout_f32_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
+                "frac": achieved / peak,
+                # HBM bytes per launch: PMC-measured bytes/record (profiles/r01_hbm_traffic.json) x records of this launch
+                "traffic": (tpr * rec_per_launch) if tpr is not None else None,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in profiles/ (FETCH x2 per the gfx950 note)",
                 "kernel_ms": kern_s * 1e3, "flop_per_record": FLOP_PER_RECORD[n2],
                 "hbm_bytes_per_record": BYTES_PER_RECORD[n2],
                 "hbm_frac": rec_per_launch * BYTES_PER_RECORD[n2] / kern_s / 8e12,

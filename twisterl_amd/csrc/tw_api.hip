@@ -55,7 +55,7 @@ static int require_device()
 }
 
 // ---------------------------------------------------------------------------------- workspace
-// Padded trajectory buffers are large (E * t_pad * 42 B) and have the same size every
+// Padded trajectory buffers are large (E * t_pad * 48 B) and have the same size every
 // iteration of the trainer, so they are cached per device instead of hipMalloc'ed per call.
 struct Workspace {
     void *ptr = nullptr; size_t cap = 0; int device = -1;
@@ -510,15 +510,12 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     const uint64_t R = E * (uint64_t)t_pad;
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
-    const size_t o_obs = seg(R * 16), o_lg = seg(R * 16), o_val = seg(R * 4), o_rew = seg(R * 4), o_act = seg(R),
-                 o_prm = seg(R), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
+    const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
                  o_scan = seg(scan_scratch_bytes(E));
     void *wsp = nullptr;
     rc = ws_reserve(cur, &wsp); if (rc) return rc;
     uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
-    ra.out.obs = ws + o_obs; ra.out.logits = reinterpret_cast<float *>(ws + o_lg);
-    ra.out.values = reinterpret_cast<float *>(ws + o_val); ra.out.rewards = reinterpret_cast<float *>(ws + o_rew);
-    ra.out.actions = ws + o_act; ra.out.perms = reinterpret_cast<int8_t *>(ws + o_prm);
+    ra.out.rec = reinterpret_cast<PaddedRec *>(ws + o_rec);
     ra.out.ep_len = reinterpret_cast<uint32_t *>(ws + o_len); ra.out.t_pad = t_pad;
     uint64_t *ep_start_ws = reinterpret_cast<uint64_t *>(ws + o_start);
     uint64_t *total_d = reinterpret_cast<uint64_t *>(ws + o_total);
@@ -630,7 +627,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     const uint64_t R = E * (uint64_t)t_pad;
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
-    const size_t o_obs = seg(R * 16), o_lg = seg(R * 16), o_rew = seg(R * 4), o_len = seg(E * 4), o_start = seg(E * 8),
+    const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(16), o_scan = seg(scan_scratch_bytes(E)), o_arena = seg(E * cap64 * mcts_node_bytes());
     size_t free_b = 0, total_b = 0;
     TW_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -641,9 +638,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     void *wsp = nullptr;
     rc = ws_reserve(cur, &wsp); if (rc) return rc;
     uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
-    ma.out.obs = ws + o_obs; ma.out.logits = reinterpret_cast<float *>(ws + o_lg);
-    ma.out.values = nullptr; ma.out.rewards = reinterpret_cast<float *>(ws + o_rew);
-    ma.out.actions = nullptr; ma.out.perms = nullptr;
+    ma.out.rec = reinterpret_cast<PaddedRec *>(ws + o_rec);
     ma.out.ep_len = reinterpret_cast<uint32_t *>(ws + o_len); ma.out.t_pad = t_pad;
     uint64_t *ep_start_ws = reinterpret_cast<uint64_t *>(ws + o_start);
     uint64_t *total_d = reinterpret_cast<uint64_t *>(ws + o_total);

@@ -260,17 +260,36 @@ struct PolicyDev {
     const uint8_t *act_perms; // [n_perms][n_actions]
 };
 
-// padded (episode-major) trajectory workspace written by the rollout kernel
-struct PaddedTraj {
-    uint8_t *obs;      // [E][t_pad][16]  obs ids, zero padded to 16
-    float   *logits;   // [E][t_pad][4]
-    float   *values;   // [E][t_pad]
-    float   *rewards;  // [E][t_pad]
-    uint8_t *actions;  // [E][t_pad]
-    int8_t  *perms;    // [E][t_pad]
-    uint32_t *ep_len;  // [E]
-    int32_t  t_pad;
+// padded (episode-major) trajectory workspace written by the rollout / MCTS kernels: ONE 48-byte
+// record per (episode, t), so every episode has a single active cache line that the XCD's L2 merges
+// completely before it is written back (six separate arrays measured 4.6x write amplification).
+struct __attribute__((aligned(16))) PaddedRec {
+    uint8_t obs[16];     // obs ids, zero padded to 16
+    float   logits[4];   // PPO: masked logits; AZ: MCTS probs
+    float   value;       // PPO only
+    float   reward;      // env.reward() of the recorded state
+    uint8_t action;      // PPO only
+    int8_t  perm;        // -1 = None
+    uint8_t pad[6];
 };
+static_assert(sizeof(PaddedRec) == 48, "PaddedRec must be 48 bytes");
+
+struct PaddedTraj {
+    PaddedRec *rec;      // [E][t_pad]
+    uint32_t  *ep_len;   // [E]
+    int32_t    t_pad;
+};
+
+__device__ inline void store_rec(PaddedRec *dst, const uint32_t (&obs4)[4], const float (&lg)[4], float value,
+                                 float reward, int action, int perm)
+{
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    d[0] = make_uint4(obs4[0], obs4[1], obs4[2], obs4[3]);
+    d[1] = make_uint4(__builtin_bit_cast(uint32_t, lg[0]), __builtin_bit_cast(uint32_t, lg[1]),
+                      __builtin_bit_cast(uint32_t, lg[2]), __builtin_bit_cast(uint32_t, lg[3]));
+    d[2] = make_uint4(__builtin_bit_cast(uint32_t, value), __builtin_bit_cast(uint32_t, reward),
+                      (uint32_t)(action & 0xff) | ((uint32_t)(perm & 0xff) << 8), 0u);
+}
 
 // compact output
 struct CompactTraj {

@@ -7,7 +7,7 @@
 //    GAE recurrence exactly as written in rust/src/collector/ppo.rs:82-92 (sequential in t,
 //    no contraction: the library is built with -ffp-contract=off), and copies every field of
 //    the episode into its compact slot with coalesced loads/stores.  HBM-bound byte moving;
-//    algorithmic traffic = N^2+34 B written + N^2+26 B read per record.
+//    algorithmic traffic = N^2+34 B written + one 48-B padded record read per record.
 #include "tw_common.hpp"
 
 namespace tw {
@@ -146,7 +146,10 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
         const int      n     = (int)in.ep_len[e];
         const uint64_t src   = e * (uint64_t)t_pad;
         const uint64_t dst   = ep_start[e];
-        for (int t = lane; t < n; t += 64) { sr[t] = in.rewards[src + t]; sv[t] = in.values[src + t]; }
+        for (int t = lane; t < n; t += 64) {
+            const uint4 w = reinterpret_cast<const uint4 *>(in.rec + src + t)[2];
+            sv[t] = __builtin_bit_cast(float, w.x); sr[t] = __builtin_bit_cast(float, w.y);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // GAE (ppo.rs:82-92): every lane walks the same chain (LDS broadcast reads); lane 0 stores
@@ -170,18 +173,19 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
             out.rewards[dst + t] = sr[t];
             out.advs[dst + t]    = sa[t];
             out.rets[dst + t]    = st[t];
-            out.actions[dst + t] = in.actions[src + t];
-            out.perms[dst + t]   = in.perms[src + t];
-            reinterpret_cast<float4 *>(out.logits)[dst + t] = reinterpret_cast<const float4 *>(in.logits)[src + t];
+            const uint4 w = reinterpret_cast<const uint4 *>(in.rec + src + t)[2];
+            out.actions[dst + t] = (uint8_t)(w.z & 0xffu);
+            out.perms[dst + t]   = (int8_t)((w.z >> 8) & 0xffu);
+            reinterpret_cast<uint4 *>(out.logits)[dst + t] = reinterpret_cast<const uint4 *>(in.rec + src + t)[1];
         }
         if (n_cells == 16) {
             for (int t = lane; t < n; t += 64)
-                reinterpret_cast<uint4 *>(out.obs)[dst + t] = reinterpret_cast<const uint4 *>(in.obs)[src + t];
+                reinterpret_cast<uint4 *>(out.obs)[dst + t] = reinterpret_cast<const uint4 *>(in.rec + src + t)[0];
         } else {
             const int nb = n * n_cells;
             for (int i = lane; i < nb; i += 64) {
                 const int t = i / n_cells, c = i - t * n_cells;
-                out.obs[dst * n_cells + i] = in.obs[(src + t) * 16 + c];
+                out.obs[dst * n_cells + i] = in.rec[src + t].obs[c];
             }
         }
         __builtin_amdgcn_wave_barrier();

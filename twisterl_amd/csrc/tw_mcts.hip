@@ -192,9 +192,7 @@ __global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
 #pragma unroll
                         for (int i = 0; i < NC; ++i)
                             if (i < env.n_cells) pk[i >> 2] |= (uint32_t)(i * env.n_cells + (int)nib(st.board, i)) << (8 * (i & 3));
-                        reinterpret_cast<uint4 *>(a.out.obs)[rec]     = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                        reinterpret_cast<float4 *>(a.out.logits)[rec] = make_float4(mp[0], mp[1], mp[2], mp[3]);
-                        a.out.rewards[rec] = puzzle_reward(st, env);
+                        store_rec(a.out.rec + rec, pk, mp, 0.0f, puzzle_reward(st, env), 0, -1);
                         if (puzzle_final(st, env)) { phase = PH_DONE; len = (uint32_t)t + 1u; break; }   // az.rs:84
                         puzzle_step(st, env, action);                                                   // az.rs:89
                         ++t;
@@ -317,7 +315,7 @@ __global__ void __launch_bounds__(AZF_WAVES * 64) finalize_az_kernel(const Padde
         const int      n   = (int)in.ep_len[e];
         const uint64_t src = e * (uint64_t)t_pad;
         const uint64_t dst = ep_start[e];
-        for (int t = lane; t < n; t += 64) sr[t] = in.rewards[src + t];
+        for (int t = lane; t < n; t += 64) sr[t] = in.rec[src + t].reward;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float total = 0.0f;                              // az.rs:64,74-76: total_vals.push(total); total += val
@@ -330,16 +328,16 @@ __global__ void __launch_bounds__(AZF_WAVES * 64) finalize_az_kernel(const Padde
         for (int t = lane; t < n; t += 64) {
             remaining_out[dst + t] = total - sp[t];      // az.rs:93
             perms_out[dst + t] = (int8_t)-1;             // az.rs:95
-            reinterpret_cast<float4 *>(probs_out)[dst + t] = reinterpret_cast<const float4 *>(in.logits)[src + t];
+            reinterpret_cast<uint4 *>(probs_out)[dst + t] = reinterpret_cast<const uint4 *>(in.rec + src + t)[1];
         }
         if (n_cells == 16) {
             for (int t = lane; t < n; t += 64)
-                reinterpret_cast<uint4 *>(obs_out)[dst + t] = reinterpret_cast<const uint4 *>(in.obs)[src + t];
+                reinterpret_cast<uint4 *>(obs_out)[dst + t] = reinterpret_cast<const uint4 *>(in.rec + src + t)[0];
         } else {
             const int nb = n * n_cells;
             for (int i = lane; i < nb; i += 64) {
                 const int t = i / n_cells, c = i - t * n_cells;
-                obs_out[dst * n_cells + i] = in.obs[(src + t) * 16 + c];
+                obs_out[dst * n_cells + i] = in.rec[src + t].obs[c];
             }
         }
         __builtin_amdgcn_wave_barrier();

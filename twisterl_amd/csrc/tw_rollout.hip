@@ -100,12 +100,7 @@ __global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutAr
 #pragma unroll
                 for (int i = 0; i < NC; ++i)
                     if (i < env.n_cells) pk[i >> 2] |= (uint32_t)(i * env.n_cells + (int)nib(st.board, i)) << (8 * (i & 3));
-                reinterpret_cast<uint4 *>(a.out.obs)[rec]      = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                reinterpret_cast<float4 *>(a.out.logits)[rec]  = make_float4(lg[0], lg[1], lg[2], lg[3]);
-                a.out.values[rec]  = value;
-                a.out.rewards[rec] = rew;
-                a.out.actions[rec] = (uint8_t)action;
-                a.out.perms[rec]   = (int8_t)perm;
+                store_rec(a.out.rec + rec, pk, lg, value, rew, action, perm);
             }
             if (puzzle_final(st, env)) { alive = false; len = (uint32_t)t + 1u; }
             else { puzzle_step(st, env, action); ++t; }
