@@ -21,6 +21,7 @@
  *                                                         rust/src/python_interface/collector.rs:147-151,
  *                                                         rust/src/collector/ppo.rs:108-126
  *   tw_az_collect          ... -> AZCollector::collect    rust/src/collector/az.rs:112-130
+ *   tw_evaluate / tw_solve evaluate_py / solve_py          rust/src/python_interface/env.rs:180-207
  *   tw_collected_*         PyCollectedData getters        rust/src/python_interface/collector.rs:55-136
  *   tw_last_error          anyhow::Error -> PyRuntimeError rust/src/python_interface/error_mapping.rs:20-33
  */
@@ -173,12 +174,33 @@ typedef struct {
     uint32_t merge_order;
 } tw_az_params;
 
+/* solve / evaluate (rust/src/rl/solve.rs:73-101, rust/src/rl/evaluate.rs:22-89; PyO3 functions
+ * collector.solve / collector.evaluate, rust/src/python_interface/env.rs:180-207) */
+typedef struct {
+    uint32_t deterministic;       /* argmax (1) or weighted sample (0) of the action probs          */
+    uint32_t num_searches;        /* best-of-N attempts per episode                                  */
+    uint32_t num_mcts_searches;   /* 0: Policy::predict.  > 0 (MCTS-guided) is not built: UNSUPPORTED */
+    float    C;
+    uint32_t max_expand_depth;
+    uint64_t seed;                /* the reference accepts and ignores `seed` (evaluate.rs:29)       */
+    uint32_t precision;
+} tw_solve_params;
+
 typedef struct tw_collected tw_collected;
 
 int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy,
                    const tw_ppo_params *params, tw_collected **out);
 int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
                   const tw_az_params *params, tw_collected **out);
+
+/* evaluate(): reset + best-of-num_searches solve for episodes [episode_offset, +num_episodes);
+ * returns the success rate and the mean total reward, accumulated in episode order. */
+int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, const tw_solve_params *params,
+                uint64_t num_episodes, uint64_t episode_offset, float *success_rate, float *mean_reward);
+/* solve(): best of num_searches attempts from the CURRENT state of `env` (which is not modified).
+ * actions_out (capacity actions_cap, may be NULL) receives the best attempt's actions. */
+int tw_solve(const tw_puzzle *env, const tw_policy *policy, const tw_solve_params *params,
+             float *success, float *reward, uint8_t *actions_out, uint32_t actions_cap, uint32_t *n_actions);
 
 /* Fields of the result (device-resident, compact, in the order params.merge_order asked for) */
 enum {

@@ -86,6 +86,12 @@ class _AZParams(C.Structure):
                 ("det_math", C.c_int)]
 
 
+class _SolveParams(C.Structure):
+    _fields_ = [("deterministic", C.c_int), ("num_searches", C.c_uint32), ("num_mcts_searches", C.c_uint32),
+                ("C", C.c_float), ("max_expand_depth", C.c_uint32), ("seed", C.c_uint64), ("arith", C.c_int),
+                ("det_math", C.c_int)]
+
+
 _lib = None
 
 
@@ -410,6 +416,26 @@ def mcts_probs(env: Puzzle, policy: Policy, num_mcts_searches, Cc, max_expand_de
     lib().two_mcts_probs(C.byref(env.p), C.byref(policy.pol), num_mcts_searches, Cc, max_expand_depth,
                          arith, seed, episode, t, pr)
     return [float(x) for x in pr]
+
+
+def solve(env: Puzzle, policy: Policy, deterministic, num_searches, num_mcts_searches=0, Cc=1.41, max_expand_depth=1,
+          seed=0, episode=0, arith=ARITH_REF, det_math=False):
+    """rl/solve.rs:73-101 from the env's current state -> ((success, reward), actions)"""
+    prm = _SolveParams(int(deterministic), num_searches, num_mcts_searches, Cc, max_expand_depth, seed, arith, int(det_math))
+    acts = (C.c_int64 * (env.depth + 2))()
+    s, r = C.c_float(), C.c_float()
+    lib().two_solve.restype = C.c_int
+    n = lib().two_solve(C.byref(env.p), C.byref(policy.pol), C.byref(prm), C.c_uint64(episode), C.byref(s), C.byref(r), acts)
+    return (float(s.value), float(r.value)), [int(acts[i]) for i in range(n)]
+
+
+def evaluate(env: Puzzle, policy: Policy, num_episodes, deterministic, num_searches, num_mcts_searches=0, seed=0, Cc=1.41,
+             max_expand_depth=1, arith=ARITH_REF, det_math=False):
+    """rl/evaluate.rs:22-89 -> (success_rate, mean_reward)"""
+    prm = _SolveParams(int(deterministic), num_searches, num_mcts_searches, Cc, max_expand_depth, seed, arith, int(det_math))
+    s, r = C.c_float(), C.c_float()
+    lib().two_evaluate(C.byref(env.p), C.byref(policy.pol), C.byref(prm), C.c_uint64(num_episodes), C.byref(s), C.byref(r))
+    return float(s.value), float(r.value)
 
 
 def replay(env: Puzzle, actions):

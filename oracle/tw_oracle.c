@@ -833,6 +833,86 @@ int two_az_collect(const two_puzzle *env, const two_policy *pol, const two_az_pa
 }
 
 /* ===================================================================================== */
+/* solve / evaluate (rl/solve.rs, rl/evaluate.rs)                                        */
+/* ===================================================================================== */
+/* single_solve (solve.rs:17-71); `key` = RNG episode key of this attempt */
+static int single_solve(two_puzzle *env, const two_policy *pol, const two_solve_params *prm, uint64_t key,
+                        float *success, float *total_out, int64_t *actions)
+{
+    const int n_cells = (int)(env->width * env->height);
+    const int A = pol->n_actions;
+    float total_val = 0.0f; int n = 0; uint32_t t = 0;
+    while (!two_puzzle_is_final(env)) {                                          /* :30 */
+        float val = two_puzzle_reward(env);                                      /* :31 */
+        int64_t obs[TWO_MAX_CELLS]; uint8_t masks[4]; float probs[256], v;
+        two_puzzle_observe(env, obs); two_puzzle_masks(env, masks);
+        total_val = total_val + val;                                             /* :34 */
+        if (prm->num_mcts_searches == 0) {                                       /* :37-38 predict */
+            int perm = -1;
+            if (pol->n_perms > 0) {
+                uint32_t w[4]; rng_draw(prm->seed, key, t, TWO_STREAM_PERM, w);
+                perm = (int)u32_below(w[0], (uint32_t)pol->n_perms);
+            }
+            two_policy_predict(pol, obs, n_cells, masks, perm, prm->arith, probs, &v);
+        } else {                                                                 /* :41-47 */
+            two_mcts_probs(env, pol, prm->num_mcts_searches, prm->C, prm->max_expand_depth, prm->arith,
+                           prm->seed, key, t, probs);
+        }
+        int action;
+        if (prm->deterministic) action = two_argmax(probs, A);                   /* :50-51 */
+        else {
+            uint32_t w[4]; rng_draw(prm->seed, key, t, TWO_STREAM_SOLVE, w);
+            action = two_sample_weighted(probs, A, u32_to_unit(w[0]));           /* :53 */
+        }
+        two_puzzle_step(env, action);                                            /* :56 */
+        actions[n++] = action;                                                   /* :58 */
+        ++t;
+    }
+    total_val = total_val + two_puzzle_reward(env);                              /* :65-66 */
+    *success = two_puzzle_solved(env) ? 1.0f : 0.0f;                             /* :68 */
+    *total_out = total_val;
+    return n;
+}
+
+/* solve (solve.rs:73-101): best of num_searches attempts by (success, total) tuple order, strict > */
+int two_solve(const two_puzzle *env, const two_policy *pol, const two_solve_params *prm, uint64_t episode,
+              float *success_out, float *reward_out, int64_t *actions_out)
+{
+    const int saved = g_det_exp; g_det_exp = prm->det_math;
+    float best_s = 0.0f, best_r = -INFINITY; int best_n = 0;
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(env->depth + 2));
+    for (uint32_t a = 0; a < prm->num_searches; ++a) {
+        two_puzzle e = *env;                                                     /* :85 clone */
+        float s, r;
+        int n = single_solve(&e, pol, prm, episode * (uint64_t)prm->num_searches + a, &s, &r, tmp);
+        if (s > best_s || (s == best_s && r > best_r)) {                         /* :95 tuple '>' */
+            best_s = s; best_r = r; best_n = n;
+            if (actions_out) memcpy(actions_out, tmp, sizeof(int64_t) * (size_t)n);
+        }
+    }
+    free(tmp);
+    g_det_exp = saved;
+    *success_out = best_s; *reward_out = best_r;
+    return best_n;
+}
+
+/* evaluate (evaluate.rs:22-89), serial accumulation order (:36-52) */
+void two_evaluate(const two_puzzle *env, const two_policy *pol, const two_solve_params *prm, uint64_t num_episodes,
+                  float *success_rate_out, float *mean_reward_out)
+{
+    float successes = 0.0f, rewards = 0.0f;
+    for (uint64_t e = 0; e < num_episodes; ++e) {
+        two_puzzle p = *env;
+        two_puzzle_reset(&p, prm->seed, e);                                      /* :39 */
+        float s, r;
+        two_solve(&p, pol, prm, e, &s, &r, NULL);
+        successes = successes + s; rewards = rewards + r;
+    }
+    *success_rate_out = successes / (float)num_episodes;
+    *mean_reward_out = rewards / (float)num_episodes;
+}
+
+/* ===================================================================================== */
 /* replay helper for replay-parity tests                                                 */
 /* ===================================================================================== */
 void two_replay(const two_puzzle *start, const int64_t *actions, size_t n,

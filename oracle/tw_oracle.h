@@ -30,7 +30,8 @@ enum {
     TWO_STREAM_GUMBEL   = 1, /* sample_from_logits uniforms           (policy.rs:169-172)  */
     TWO_STREAM_PERM     = 2, /* Policy::get_perm_id                   (policy.rs:67-77)    */
     TWO_STREAM_AZ_ACT   = 3, /* AZCollector root action sample        (az.rs:72)           */
-    TWO_STREAM_MCTS     = 4  /* MCTSTree::next_sample                 (search.rs:94-100)   */
+    TWO_STREAM_MCTS     = 4, /* MCTSTree::next_sample                 (search.rs:94-100)   */
+    TWO_STREAM_SOLVE    = 5  /* single_solve action sample            (solve.rs:50-54)     */
 };
 void two_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* deterministic natural log used by the "exact" sampler (same spec as the HIP kernel) */
@@ -174,6 +175,25 @@ void two_mcts_probs(const two_puzzle *root, const two_policy *pol, uint32_t num_
                     uint64_t episode, uint32_t t, float *probs_out);
 
 void two_collected_free(two_collected *c);
+
+/* ---- solve / evaluate (rl/solve.rs:17-101, rl/evaluate.rs:22-89) --------------------- */
+typedef struct {
+    int      deterministic;       /* argmax vs weighted sample of the probs (solve.rs:50-54)     */
+    uint32_t num_searches;        /* best-of-N attempts (solve.rs:84-98)                          */
+    uint32_t num_mcts_searches;   /* 0: policy.predict; >0: predict_probs_mcts (solve.rs:37-48)   */
+    float    C;
+    uint32_t max_expand_depth;
+    uint64_t seed;
+    int      arith;
+    int      det_math;
+} two_solve_params;
+/* solve() from the env's CURRENT state; `episode` keys the RNG (attempt a uses episode*N + a).
+ * actions_out must hold at least depth+1 entries; returns the number of actions of the best attempt */
+int two_solve(const two_puzzle *env, const two_policy *pol, const two_solve_params *prm, uint64_t episode,
+              float *success_out, float *reward_out, int64_t *actions_out);
+/* evaluate(): reset (seed, episode e) + solve per episode, means in episode order */
+void two_evaluate(const two_puzzle *env, const two_policy *pol, const two_solve_params *prm, uint64_t num_episodes,
+                  float *success_rate_out, float *mean_reward_out);
 
 /* replay: apply `actions` from `start` (set_state semantics for depth unless depth0>=0),
  * recording for each of the n+1 visited states obs ids, masks, reward, is_final, board. */

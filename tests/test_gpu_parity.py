@@ -243,6 +243,34 @@ def test_az_reference_style_consumer(tw, oracle):
     assert all(abs(sum(p) - 1.0) < 1e-5 for p in probs)
 
 
+# ------------------------------------------------------------------------------ evaluate / solve
+@pytest.mark.parametrize("w,diff,emb,hidden,twists", [(3, 4, 32, 32, False), (3, 6, 64, 64, True), (4, 5, 512, 256, False)])
+def test_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, hidden, twists):
+    """collector.evaluate / collector.solve (python_interface/env.rs:180-207 over rl/evaluate.rs, rl/solve.rs):
+    same (success_rate, mean_reward) and the same best action list as the oracle, bit for bit."""
+    n2 = w * w
+    gp, op = _pair(oracle, n2, 4, emb, hidden, twists=twists, scale=3.0)
+    genv, oenv = tw.env.Puzzle(w, w, diff, 2, 256), oracle.Puzzle(w, w, diff, 2, 256)
+    for det, ns in ((True, 1), (False, 1), (False, 5)):
+        g = tw.collector.evaluate(genv, gp, num_episodes=100, deterministic=det, num_searches=ns, num_mcts_searches=0,
+                                  seed=7, C=1.41, max_expand_depth=1, num_cores=32)
+        o = oracle.evaluate(oenv, op, 100, det, ns, seed=7, arith=oracle.ARITH_CHAIN, det_math=True)
+        assert f32_bits(g[0]) == f32_bits(o[0]) and f32_bits(g[1]) == f32_bits(o[1]), (det, ns, g, o)
+    # solve from a given state (Algorithm.solve: env.set_state(state) then solve, rl/algorithm.py:226-246)
+    rng = np.random.default_rng(1)
+    start = oracle.Puzzle(w, w, diff, 2, 256); start.reset(seed=9, episode=3)
+    state = start.get_state()
+    genv.set_state(state); oenv.set_state(state)
+    before = genv.get_state()
+    for det, ns in ((True, 1), (False, 8)):
+        (gs, gr), gact = tw.collector.solve(genv, gp, det, ns, 0, 1.41, 1, seed=5)
+        (os_, or_), oact = oracle.solve(oenv, op, det, ns, seed=5, arith=oracle.ARITH_CHAIN, det_math=True)
+        assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact
+    assert genv.get_state() == before                        # the env passed in is not mutated (solve.rs:85)
+    with pytest.raises(RuntimeError, match="not built"):
+        tw.collector.evaluate(genv, gp, 4, True, 1, 10, 0, 1.41, 1, 1)
+
+
 # ------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_puzzle8_65k(tw, oracle):
     """BASELINE config 2 size (65,536 envs): determinism, replay parity on a sample, GAE parity on

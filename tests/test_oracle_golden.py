@@ -388,3 +388,26 @@ def test_mcts_visit_counts_sum_to_searches(oracle):
     assert all((p == 0.0) for p, m in zip(probs, legal) if not m)
     # counts are multiples of 1/50: every search back-propagates through exactly one root child
     assert all(abs(p * 50 - round(p * 50)) < 1e-4 for p in probs)
+
+
+# ------------------------------------------------------------------ solve / evaluate (rl/solve.rs, rl/evaluate.rs)
+def test_solve_and_evaluate_semantics(oracle):
+    pol = _tiny_policy(oracle)
+    # an already-final env: no step is taken, total = reward of the final state (solve.rs:30,65-66)
+    done = oracle.Puzzle(3, 3, 0, 2, 256); done.reset()
+    (s, r), acts = oracle.solve(done, pol, True, 1)
+    assert (s, r, acts) == (1.0, 1.0, [])
+    # one move from solved with depth left: best-of-N keeps the better (success, reward) tuple
+    env = oracle.Puzzle(3, 3, 1, 2, 256); env.set_state([1, 0, 2, 3, 4, 5, 6, 7, 8])
+    (s1, r1), a1 = oracle.solve(env, pol, False, 1, seed=2)
+    (s8, r8), a8 = oracle.solve(env, pol, False, 16, seed=2)
+    assert (s8, r8) >= (s1, r1) and env.get_state() == [1, 0, 2, 3, 4, 5, 6, 7, 8]
+    if s8 == 1.0:      # replay the returned actions: they must solve the board
+        q = env.clone()
+        for a in a8:
+            q.step(a)
+        assert q.solved() and abs(r8 - (1.0 - 0.5 / 256 * len(a8))) < 1e-5
+    # evaluate = mean over episodes of reset + solve; difficulty 0 => always solved, reward 1
+    assert oracle.evaluate(oracle.Puzzle(3, 3, 0, 2, 256), pol, 10, True, 1) == (1.0, 1.0)
+    sr, mr = oracle.evaluate(oracle.Puzzle(3, 3, 3, 2, 256), pol, 40, False, 4, seed=1)
+    assert 0.0 <= sr <= 1.0 and -0.6 <= mr <= 1.0

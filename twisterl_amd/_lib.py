@@ -62,6 +62,11 @@ class AZParams(C.Structure):
                 ("seed", C.c_uint64), ("precision", C.c_uint32), ("merge_order", C.c_uint32)]
 
 
+class SolveParams(C.Structure):
+    _fields_ = [("deterministic", C.c_uint32), ("num_searches", C.c_uint32), ("num_mcts_searches", C.c_uint32),
+                ("C", C.c_float), ("max_expand_depth", C.c_uint32), ("seed", C.c_uint64), ("precision", C.c_uint32)]
+
+
 class CollectStats(C.Structure):
     _fields_ = [("ms_rollout", C.c_float), ("ms_scan", C.c_float), ("ms_finalize", C.c_float),
                 ("ms_total", C.c_float), ("records", C.c_uint64), ("episodes", C.c_uint64),
@@ -107,6 +112,10 @@ SYMBOLS = {
                                      C.POINTER(C.c_float)]),
     "tw_ppo_collect": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(PPOParams), C.POINTER(_VP)]),
     "tw_az_collect": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(AZParams), C.POINTER(_VP)]),
+    "tw_evaluate": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(SolveParams), C.c_uint64, C.c_uint64,
+                              C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tw_solve": (C.c_int, [_VP, _VP, C.POINTER(SolveParams), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                           C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint32)]),
     "tw_collected_num_records": (C.c_uint64, [_VP]),
     "tw_collected_num_episodes": (C.c_uint64, [_VP]),
     "tw_collected_num_cells": (C.c_uint32, [_VP]),

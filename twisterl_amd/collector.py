@@ -9,12 +9,15 @@ zero-copy for trainers that can take tensors.
 from __future__ import annotations
 
 import ctypes as C
+import ctypes as _c
 
 import numpy as np
 
 from . import _lib
 from .env import get_env_desc
 from .nn import Policy
+
+ctypes_u8 = _c.c_uint8
 
 _FIELD_DTYPES = {
     _lib.TW_F_OBS: np.uint8, _lib.TW_F_LOGITS: np.float32, _lib.TW_F_PERMS: np.int8,
@@ -323,3 +326,44 @@ class AZCollector(PyBaseCollector):
         out = C.c_void_p()
         _lib.check(_lib.lib().tw_az_collect(C.byref(desc), policy._handle(), C.byref(prm), C.byref(out)))
         return CollectedData._from_device(_DeviceResult(out.value))
+
+
+def _solve_params(deterministic, num_searches, num_mcts_searches, C_, max_expand_depth, seed, precision="fp32"):
+    import os
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little")
+    return _lib.SolveParams(int(bool(deterministic)), _u("num_searches", num_searches),
+                            _u("num_mcts_searches", num_mcts_searches), float(C_), _u("max_expand_depth", max_expand_depth),
+                            int(seed) & (2**64 - 1), _lib.PRECISIONS[precision])
+
+
+def solve(py_env, policy: Policy, deterministic, num_searches, num_mcts_searches, C, max_expand_depth, *, seed=None):
+    """solve(py_env, policy, deterministic, num_searches, num_mcts_searches, C, max_expand_depth)
+    -> ((success, reward), actions)   (python_interface/env.rs:180-191 over rl/solve.rs:73-101).
+    Best of `num_searches` greedy/sampled roll-outs from the env's CURRENT state; the env is not modified."""
+    get_env_desc(py_env)
+    if not isinstance(policy, Policy):
+        raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
+    prm = _solve_params(deterministic, num_searches, num_mcts_searches, C, max_expand_depth, seed)
+    cap = int(py_env.depth) + 2
+    acts = (ctypes_u8 * cap)()
+    s, r, n = _c.c_float(), _c.c_float(), _c.c_uint32()
+    _lib.check(_lib.lib().tw_solve(py_env._h, policy._handle(), _c.byref(prm), _c.byref(s), _c.byref(r), acts, cap, _c.byref(n)))
+    return (float(s.value), float(r.value)), [int(acts[i]) for i in range(n.value)]
+
+
+def evaluate(py_env, policy: Policy, num_episodes, deterministic, num_searches, num_mcts_searches, seed, C, max_expand_depth,
+             num_cores):
+    """evaluate(py_env, policy, num_episodes, deterministic, num_searches, num_mcts_searches, seed, C,
+    max_expand_depth, num_cores) -> (success_rate, mean_reward)   (python_interface/env.rs:194-207 over
+    rl/evaluate.rs:22-89).  `seed` keys the episode scrambles and action draws (the reference ignores it);
+    `num_cores` is accepted for compatibility."""
+    desc = get_env_desc(py_env)
+    if not isinstance(policy, Policy):
+        raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
+    _u("num_cores", num_cores)
+    prm = _solve_params(deterministic, num_searches, num_mcts_searches, C, max_expand_depth, seed)
+    s, r = _c.c_float(), _c.c_float()
+    _lib.check(_lib.lib().tw_evaluate(_c.byref(desc), policy._handle(), _c.byref(prm), _u("num_episodes", num_episodes), 0,
+                                      _c.byref(s), _c.byref(r)))
+    return float(s.value), float(r.value)

@@ -693,3 +693,112 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     *out = c;
     return TW_OK;
 }
+
+// ====================================================================================== solve / evaluate
+namespace {
+
+// runs the attempts and reduces best-of-N per episode on the host in the reference's order
+int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_params *prm, uint64_t n_episodes,
+              uint64_t episode_offset, bool from_state, const tw_puzzle *start, int max_steps, bool want_actions,
+              std::vector<float> &best_s, std::vector<float> &best_r, std::vector<uint8_t> &best_actions)
+{
+    if (prm->num_mcts_searches != 0) {
+        set_error("solve/evaluate with num_mcts_searches > 0 (MCTS-guided inference) is not built on the HIP path yet");
+        return TW_ERR_UNSUPPORTED;
+    }
+    if (prm->num_searches == 0) { best_s.assign(n_episodes, 0.0f); best_r.assign(n_episodes, -__builtin_inff()); return TW_OK; }
+    if (prm->precision != TW_PREC_F32_EXACT) { set_error("solve: precision %u not implemented", prm->precision); return TW_ERR_UNSUPPORTED; }
+    SolveArgs sa{};
+    sa.env = envc; sa.pol = policy->dev;
+    if (sa.pol.obs_size != envc.n_cells * envc.n_cells) {
+        set_error("index out of bounds: policy obs_size %d != Puzzle obs ids %d", sa.pol.obs_size, envc.n_cells * envc.n_cells);
+        return TW_ERR_INVALID;
+    }
+    if (sa.pol.n_actions != 4) { set_error("Puzzle has 4 actions, policy has %d", sa.pol.n_actions); return TW_ERR_INVALID; }
+    const uint64_t N = prm->num_searches, A = n_episodes * N;
+    sa.num_attempts = A; sa.episode_offset = episode_offset; sa.seed = prm->seed;
+    sa.num_searches = prm->num_searches; sa.deterministic = prm->deterministic ? 1u : 0u;
+    sa.from_state = from_state ? 1u : 0u;
+    if (from_state) {
+        uint64_t b = 0;
+        for (size_t i = 0; i < start->state.size(); ++i) {
+            if (start->state[i] < 0 || start->state[i] > 15) { set_error("solve: tile value %lld does not fit a nibble", (long long)start->state[i]); return TW_ERR_UNSUPPORTED; }
+            b |= (uint64_t)start->state[i] << (4 * i);
+        }
+        sa.start_board = b; sa.start_zx = (int)start->zx; sa.start_zy = (int)start->zy; sa.start_depth = (int)start->depth;
+    }
+    sa.t_pad = max_steps > 0 ? max_steps : 1;
+
+    hipStream_t s = current_stream();
+    size_t cur = 0;
+    auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    const size_t o_s = seg(A * 4), o_r = seg(A * 4), o_n = seg(A * 4), o_a = seg(want_actions ? A * (size_t)sa.t_pad : 0);
+    uint8_t *buf = nullptr;
+    TW_HIP(hipMalloc((void **)&buf, cur ? cur : 256));
+    sa.success = reinterpret_cast<float *>(buf + o_s); sa.total = reinterpret_cast<float *>(buf + o_r);
+    sa.n_steps = reinterpret_cast<uint32_t *>(buf + o_n); sa.actions = want_actions ? buf + o_a : nullptr;
+    int rc = launch_solve_f32(sa, s);
+    std::vector<float> hs(A), hr(A); std::vector<uint32_t> hn(A);
+    hipError_t e = hipSuccess;
+    if (rc == TW_OK) {
+        e = hipMemcpyAsync(hs.data(), sa.success, A * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(hr.data(), sa.total, A * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(hn.data(), sa.n_steps, A * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (rc != TW_OK || e != hipSuccess) { (void)hipFree(buf); return rc != TW_OK ? rc : hip_fail(e, "solve readback", __FILE__, __LINE__); }
+    best_s.assign(n_episodes, 0.0f); best_r.assign(n_episodes, -__builtin_inff());
+    std::vector<uint64_t> best_att(n_episodes, (uint64_t)-1);
+    for (uint64_t ep = 0; ep < n_episodes; ++ep)
+        for (uint64_t a = 0; a < N; ++a) {        // solve.rs:84-98: `if next_val.0 > best.0` on (success, total) tuples
+            const uint64_t i = ep * N + a;
+            if (hs[i] > best_s[ep] || (hs[i] == best_s[ep] && hr[i] > best_r[ep])) { best_s[ep] = hs[i]; best_r[ep] = hr[i]; best_att[ep] = i; }
+        }
+    if (want_actions && n_episodes == 1 && best_att[0] != (uint64_t)-1) {
+        const uint64_t i = best_att[0];
+        best_actions.resize(hn[i]);
+        if (hn[i]) e = hipMemcpy(best_actions.data(), sa.actions + i * (uint64_t)sa.t_pad, hn[i], hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(buf);
+    if (e != hipSuccess) return hip_fail(e, "solve actions readback", __FILE__, __LINE__);
+    return TW_OK;
+}
+
+}  // namespace
+
+extern "C" int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, const tw_solve_params *prm,
+                           uint64_t num_episodes, uint64_t episode_offset, float *success_rate, float *mean_reward)
+{
+    if (!env || !policy || !prm || !success_rate || !mean_reward) { set_error("tw_evaluate: null argument"); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+    PuzzleConsts envc; rc = make_env_consts(env, &envc); if (rc) return rc;
+    if (num_episodes == 0) { *success_rate = __builtin_nanf(""); *mean_reward = __builtin_nanf(""); return TW_OK; }   // 0/0 (evaluate.rs:52)
+    std::vector<float> bs, br; std::vector<uint8_t> acts;
+    rc = run_solve(envc, policy, prm, num_episodes, episode_offset, false, nullptr, envc.depth0 + 1, false, bs, br, acts);
+    if (rc) return rc;
+    float successes = 0.0f, rewards = 0.0f;       // serial accumulation, episode order (evaluate.rs:36-52)
+    for (uint64_t e = 0; e < num_episodes; ++e) { successes = successes + bs[e]; rewards = rewards + br[e]; }
+    *success_rate = successes / (float)num_episodes;
+    *mean_reward = rewards / (float)num_episodes;
+    return TW_OK;
+}
+
+extern "C" int tw_solve(const tw_puzzle *env, const tw_policy *policy, const tw_solve_params *prm, float *success,
+                        float *reward, uint8_t *actions_out, uint32_t actions_cap, uint32_t *n_actions)
+{
+    if (!env || !policy || !prm || !success || !reward) { set_error("tw_solve: null argument"); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+    tw_puzzle_desc d; tw_puzzle_get_desc(env, &d);
+    PuzzleConsts envc; rc = make_env_consts(&d, &envc); if (rc) return rc;
+    if (env->depth > 4096) { set_error("tw_solve: depth %lld too large", (long long)env->depth); return TW_ERR_UNSUPPORTED; }
+    std::vector<float> bs, br; std::vector<uint8_t> acts;
+    rc = run_solve(envc, policy, prm, 1, 0, true, env, (int)env->depth + 1, true, bs, br, acts);
+    if (rc) return rc;
+    *success = bs[0]; *reward = br[0];
+    if (n_actions) *n_actions = (uint32_t)acts.size();
+    if (actions_out) {
+        if (acts.size() > actions_cap) { set_error("tw_solve: %zu actions, caller's buffer holds %u", acts.size(), actions_cap); return TW_ERR_INVALID; }
+        if (!acts.empty()) memcpy(actions_out, acts.data(), acts.size());
+    }
+    return TW_OK;
+}

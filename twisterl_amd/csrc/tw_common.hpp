@@ -35,7 +35,8 @@ enum : uint32_t {
     STREAM_GUMBEL   = 1,  // sample_from_logits uniforms         (policy.rs:169-172)
     STREAM_PERM     = 2,  // Policy::get_perm_id                 (policy.rs:67-77)
     STREAM_AZ_ACT   = 3,  // AZCollector root action sample      (az.rs:72)
-    STREAM_MCTS     = 4   // MCTSTree::next_sample               (search.rs:94-100)
+    STREAM_MCTS     = 4,  // MCTSTree::next_sample               (search.rs:94-100)
+    STREAM_SOLVE    = 5   // single_solve action sample          (solve.rs:50-54)
 };
 
 struct u32x4 { uint32_t x, y, z, w; };
@@ -316,6 +317,22 @@ int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, ui
 size_t scan_scratch_bytes(uint64_t n_episodes);
 int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,
                         float gamma, float lambda, const CompactTraj &out, hipStream_t s);
+struct SolveArgs {
+    PuzzleConsts env;
+    PolicyDev    pol;
+    uint64_t     num_attempts;     // episodes x num_searches
+    uint64_t     episode_offset, seed;
+    uint32_t     num_searches, deterministic;
+    uint32_t     from_state;       // 1: every attempt starts from (start_board, start_depth) -- solve()
+    uint64_t     start_board; int32_t start_zx, start_zy, start_depth;
+    float       *success;          // [num_attempts] 1.0 / 0.0
+    float       *total;            // [num_attempts] summed rewards (solve.rs:25-34,65-66)
+    uint32_t    *n_steps;          // [num_attempts]
+    uint8_t     *actions;          // [num_attempts][t_pad] or null
+    int32_t      t_pad;
+};
+int launch_solve_f32(const SolveArgs &a, hipStream_t s);
+
 struct MctsNode;   // tw_mcts.hip
 struct MctsArgs {
     PuzzleConsts env;
