@@ -282,7 +282,9 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     size_t cur = 0;
     auto seg = [&](size_t bytes) { Seg s{cur, bytes}; cur = align_up(cur + bytes, 256); return s; };
     const uint32_t NQ = (NT + 3) / 4;     // float4 groups of row-tiles per (k, i)
+    const size_t T16_SLOT = 21 * 256;     // floats per 16-column table chunk image (tw_engine.hpp R3_TSLOT)
     const Seg s_emb = seg((size_t)(OS + 2) * E * 4), s_w1p = seg((size_t)E * NQ * 128 * 4), s_b1 = seg((size_t)H * 4),
+              s_t16 = seg((size_t)(E / 16) * T16_SLOT * 4),
               s_wh8 = seg((size_t)H * 8 * 4), s_bh8 = seg(8 * 4), s_w1 = seg((size_t)E * H * 4), s_wa = seg((size_t)H * A * 4),
               s_ba = seg((size_t)A * 4), s_wv = seg((size_t)H * 4), s_bv = seg(4),
               s_op = seg((size_t)(d->n_perms ? d->n_perms : 1) * OS), s_ap = seg((size_t)(d->n_perms ? d->n_perms : 1) * A);
@@ -300,6 +302,14 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
                     w1p[(((size_t)k * NQ + q) * 32 + i) * 4 + cc] =
                         r < NT ? c.weights[(size_t)k * H + hid_row((int)r, (int)i)] : 0.0f;
                 }
+    // Engine3 table image: chunk c, row r, position p of 20: p<8 -> column 16c+2p (even k), p<16 -> 16c+2(p-8)+1, else 0
+    float *t16 = reinterpret_cast<float *>(img.data() + s_t16.off);
+    for (uint32_t ch = 0; ch < E / 16; ++ch)
+        for (uint32_t r = 0; r < OS + 2; ++r)
+            for (uint32_t pp = 0; pp < 16; ++pp) {
+                const uint32_t k = pp < 8 ? 2 * pp : 2 * (pp - 8) + 1;
+                t16[(size_t)ch * T16_SLOT + (size_t)r * 20 + pp] = emb[(size_t)r * E + ch * 16 + k];
+            }
     memcpy(img.data() + s_b1.off, c.bias, (size_t)H * 4);
     float *wh8 = reinterpret_cast<float *>(img.data() + s_wh8.off);
     float *bh8 = reinterpret_cast<float *>(img.data() + s_bh8.off);
@@ -336,6 +346,7 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     pd.emb_relu = d->emb_apply_relu ? 1 : 0; pd.common_relu = c.apply_relu ? 1 : 0;
     pd.emb_rows = reinterpret_cast<const float *>(base + s_emb.off);
     pd.w1p = reinterpret_cast<const float *>(base + s_w1p.off);
+    pd.t_img16 = reinterpret_cast<const float *>(base + s_t16.off);
     pd.b1 = reinterpret_cast<const float *>(base + s_b1.off);
     pd.wh8 = reinterpret_cast<const float *>(base + s_wh8.off);
     pd.bh8 = reinterpret_cast<const float *>(base + s_bh8.off);
@@ -522,29 +533,9 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
 
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
-    // diagnostic builds: TW_ROLLOUT_DBG=16 collects per-wave s_memtime sums (see tw_engine.hpp)
-    unsigned long long *stamps_d = nullptr; size_t stamps_n = 0;
-    if (const char *dbg = getenv("TW_ROLLOUT_DBG"); dbg && atoi(dbg) == 16) {
-        stamps_n = ((E + 127) / 128) * 8 * 10;   // enough for 4- and 8-wave workgroups
-        TW_HIP(hipMalloc((void **)&stamps_d, stamps_n * 8));
-        TW_HIP(hipMemsetAsync(stamps_d, 0, stamps_n * 8, s));
-        ra.stamps = stamps_d;
-    }
     TW_HIP(hipEventRecord(ev.ev[0], s));
     rc = launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads); if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[1], s));
-    if (stamps_d) {
-        std::vector<unsigned long long> hsts(stamps_n);
-        TW_HIP(hipMemcpy(hsts.data(), stamps_d, stamps_n * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(stamps_d);
-        double sum[10] = {0}; size_t waves = stamps_n / 10;
-        for (size_t w = 0; w < waves; ++w) for (int i = 0; i < 10; ++i) sum[i] += (double)hsts[w * 10 + i];
-        const char *names[10] = {"stream_issue", "chunk_prologue", "mfma_groups", "commit+vmcnt", "barrier", "heads",
-                                 "forward_total", "outside_forward", "kernel_total", "steps"};
-        fprintf(stderr, "[tw stamps] per-wave mean cycles (s_memtime ticks):");
-        for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.0f", names[i], sum[i] / (double)waves);
-        fprintf(stderr, "\n");
-    }
     rc = launch_scan(ra.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
     if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[2], s));

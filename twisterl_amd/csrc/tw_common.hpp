@@ -246,8 +246,9 @@ struct PolicyDev {
     int32_t obs_size, emb, hidden, n_actions, n_perms;
     int32_t emb_relu, common_relu;
     // f32 image ("exact" mode)
-    const float *emb_rows;   // [(obs_size+2)][emb]: rows 0..obs_size-1 vectors, row obs_size = bias, row obs_size+1 = 0
+    const float *emb_rows;   // [(obs_size+2)][emb]: rows 0..obs_size-1 vectors, row obs_size = bias, row obs_size+1 = 0 (evaluate kernel)
     const float *w1p;        // [emb][NQ][32][4]: W1[k][hid(4q+c, i)] (MFMA A-operand image, see tw_rollout.hip)
+    const float *t_img16;    // [emb/16][21*256]: table chunk images exactly as they sit in LDS (Engine3, see tw_engine.hpp)
     const float *b1;         // [hidden] natural order
     const float *wh8;        // [hidden][8]: cols 0..3 action weights, col 4 value weight, rest 0
     const float *bh8;        // [8]: action bias 0..3, value bias 4
@@ -307,7 +308,6 @@ struct RolloutArgs {
     PolicyDev    pol;
     PaddedTraj   out;
     uint64_t     num_episodes, episode_offset, seed;
-    unsigned long long *stamps;   // diagnostic builds only (TW_ABLATE, DBG & 16): per-wave cycle sums
 };
 
 // kernel launchers (each returns a TW_* status)

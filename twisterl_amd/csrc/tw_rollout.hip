@@ -12,23 +12,22 @@
 //   * the network is evaluated TRANSPOSED: h1^T[hidden x 32 episodes] = W1^T . h0^T on
 //     v_mfma_f32_32x32x2_f32, episode = MFMA column = lane&31.  The B operand of k-step s is ONE
 //     f32 per lane: h0[episode][2s + (lane>>5)], which the lane computes itself as the EmbeddingBag
-//     gather-sum (bias + sum over cells of table[id][k], in cell order) from a KC-column chunk of
+//     gather-sum (bias + sum over cells of table[id][k], in cell order) from a 16-column chunk of
 //     the table held in LDS.  The chunk image is column-permuted ([even k | odd k]) so the four
-//     k-steps a lane handles next sit in ONE 16-byte word: one ds_read_b128 per cell feeds four
-//     independent add chains.  Row stride KC+4 floats: (16i+tile)*(KC+4) mod 64 takes 16 distinct
-//     16-byte bank slots for the 16 tiles of a cell (conflict-free; equal tiles broadcast).
-//   * the inner loop is software-pipelined by hand: while the 4*NT MFMAs of one group of four
-//     k-steps issue, the gather of the NEXT group is interleaved between them (issue order pinned
-//     with sched_barrier), so one wave alone can keep its SIMD's matrix pipe busy.
+//     k-steps a lane handles next sit in ONE 16-byte word: one ds_read_b128 per cell feeds four add
+//     chains.  Row stride 20 floats: (16i+tile)*20 mod 64 takes 16 distinct 16-byte bank slots for
+//     the 16 tiles of a cell (conflict-free; equal tiles broadcast).
 //   * an f32 MFMA chain IS a k-ordered fmaf chain, so the result is bit-equal to the oracle's
 //     TWO_ARITH_CHAIN forward; rows of W1 are fed in an order (hid()) that makes the accumulator
 //     registers come out in natural hidden order for the head product, which consumes the
 //     accumulators directly as its B operand (no LDS round trip, no shuffles).
-//   * both weight streams are double-buffered in LDS, one barrier per 32-column chunk: the W1
-//     chunk arrives by LDS-DMA (global_load_lds_dwordx4, its image is lane-linear), the padded
-//     table chunk through registers (loads issued before the chunk's MFMAs, ds_write after).
-//     The streams run ahead across timesteps (chunk 0 of step t+1 is fetched during chunk 15 of t).
+//   * both weight streams are pure LDS-DMA (global_load_lds_dwordx4 via inline asm) into a ring of
+//     three slots, two chunks ahead, spread between the MFMAs; the inner loop is software-pipelined
+//     by hand across chunk boundaries (issue order pinned with sched_barrier, chunk body branch-free),
+//     so nothing but the barrier itself sits between the last MFMA of a chunk and the first of the next.
 //   * heads: [4 logits + value] x hidden on the same MFMA shape (rows 5..31 are zero).
+//   * the f32-input MFMA executes on the SIMD's f32 FMA lanes, so the gather's VALU adds do NOT overlap
+//     it: the practical ceiling is MFMA cycles + add cycles (~0.85 of the MFMA-only peak).
 #include "tw_engine.hpp"
 
 #include <cstdlib>
@@ -36,16 +35,13 @@
 
 namespace tw {
 
-// Geometry variants (template parameters NW = waves per workgroup, KC = embedding columns per LDS chunk):
-//   NW=8, KC=32: one 512-thread workgroup per CU (147 KB LDS) -- default
-//   NW=4, KC=16: two 256-thread workgroups per CU; NW=4, KC=32: one-wave-per-SIMD diagnostic
-template <int NT, int NC, int NW, int KC, int DBG = 0>
-__global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutArgs a)
+template <int NT, int NC, int DBG = 0>
+__global__ void __launch_bounds__(512, 2) rollout_f32_kernel(const RolloutArgs a)
 {
-    using Eng = Engine<NT, NC, NW, KC, DBG>;
+    using Eng = Engine3<NT, NC, DBG>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
-    eng.begin1(a.pol, lds);                               // first weight chunk loads overlap the scramble below
+    eng.begin1(a.pol, lds);                               // first weight chunks stream in while the scramble runs
 
     const PuzzleConsts env = a.env;
     const int j = eng.j, h = eng.h;
@@ -63,9 +59,7 @@ __global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutAr
     const uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
 
     eng.begin2();
-    // (the barrier inside __syncthreads_or publishes LDS buffer 0 and the b1/wh8/zero-row stores)
-    unsigned long long ts_fwd = 0, ts_rest = 0, ts_mark = 0, ts_k0 = 0;
-    if constexpr (DBG & 16) { ts_mark = eng.now(); ts_k0 = ts_mark; }
+    // (the barrier inside __syncthreads_or publishes the first two ring slots and the LDS constants)
 
     while (__syncthreads_or(alive ? 1 : 0)) {
         // ---- observe (puzzle.rs:183-185) + twist of the obs ids (policy.rs:67-83) -------------
@@ -78,9 +72,7 @@ __global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutAr
         eng.rows_of(st.board, env.n_cells, perm, rowoff);
 
         float lg[4]; float value;
-        if constexpr (DBG & 16) { const unsigned long long n0 = eng.now(); ts_rest += n0 - ts_mark; ts_mark = n0; }
         eng.forward(rowoff, lg, value);
-        if constexpr (DBG & 16) { const unsigned long long n0 = eng.now(); ts_fwd += n0 - ts_mark; ts_mark = n0; }
 
         float rew = 0.0f; int action = t & 3;
         if constexpr (!(DBG & 8)) {
@@ -107,76 +99,46 @@ __global__ void __launch_bounds__(NW * 64, 2) rollout_f32_kernel(const RolloutAr
         }
     }
     if (valid && h == 0) a.out.ep_len[e_local] = len;
-    if constexpr (DBG & 16) {
-        if (eng.lane == 0 && a.stamps) {
-            unsigned long long *o = a.stamps + ((size_t)blockIdx.x * NW + eng.wave) * 10;
-            for (int i = 0; i < 6; ++i) o[i] = eng.stamp[i];
-            o[6] = ts_fwd; o[7] = ts_rest; o[8] = eng.now() - ts_k0; o[9] = (unsigned long long)t;
-        }
-    }
     eng.end();
 }
 
-template <int NT, int NC, int NW, int KC, int DBG = 0>
+template <int NT, int NC, int DBG = 0>
 static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    constexpr int EPB = NW * EPW, THREADS = NW * 64;
+    constexpr int EPB = 8 * EPW, THREADS = 512;
     const uint64_t nb = (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = engine_lds_floats<NT, KC>(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;   // per instantiation: raise the dynamic-LDS limit above the 64 KiB default
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, NW, KC, DBG>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, NW, KC, DBG>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, DBG>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = THREADS;
     return TW_OK;
 }
 
-// TW_ROLLOUT_GEOM selects the geometry (default 8x32; 4x16 and the diagnostic 4x32 for A/B runs)
-static int geom_sel()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("TW_ROLLOUT_GEOM");
-        v = (e && strcmp(e, "4x16") == 0) ? 1 : ((e && strcmp(e, "4x32") == 0) ? 2 : 0);
-    }
-    return v;
-}
-
 template <int NT, int NC>
 static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    const int g = geom_sel();
-#ifdef TW_ABLATE
+#ifdef TW_ABLATE   // timing-only ablation builds: TW_ROLLOUT_DBG = 1 | 2 | 4 | 8 (see tw_engine.hpp)
     if constexpr (NT == 8 && NC == 16) {
         const char *d = getenv("TW_ROLLOUT_DBG");
-        if (d && atoi(d) == 16 && g == 2) return launch_geom<NT, NC, 4, 32, 16>(a, s, blocks, threads);
-    }
-#endif
-    if (g == 1) return launch_geom<NT, NC, 4, 16>(a, s, blocks, threads);
-    if (g == 2) return launch_geom<NT, NC, 4, 32>(a, s, blocks, threads);   // diagnostic: one wave per SIMD
-#ifdef TW_ABLATE
-    if constexpr (NT == 8 && NC == 16) {
-        const char *d = getenv("TW_ROLLOUT_DBG");
-        const int dbg = d ? atoi(d) : 0;
-        switch (dbg) {
-            case 1: return launch_geom<NT, NC, 8, 32, 1>(a, s, blocks, threads);
-            case 2: return launch_geom<NT, NC, 8, 32, 2>(a, s, blocks, threads);
-            case 3: return launch_geom<NT, NC, 8, 32, 3>(a, s, blocks, threads);
-            case 4: return launch_geom<NT, NC, 8, 32, 4>(a, s, blocks, threads);
-            case 8: return launch_geom<NT, NC, 8, 32, 8>(a, s, blocks, threads);
-            case 16: return launch_geom<NT, NC, 8, 32, 16>(a, s, blocks, threads);
+        switch (d ? atoi(d) : 0) {
+            case 1: return launch_geom<NT, NC, 1>(a, s, blocks, threads);
+            case 2: return launch_geom<NT, NC, 2>(a, s, blocks, threads);
+            case 4: return launch_geom<NT, NC, 4>(a, s, blocks, threads);
+            case 8: return launch_geom<NT, NC, 8>(a, s, blocks, threads);
             default: break;
         }
     }
 #endif
-    return launch_geom<NT, NC, 8, 32>(a, s, blocks, threads);
+    return launch_geom<NT, NC>(a, s, blocks, threads);
 }
 
 template <int NT>

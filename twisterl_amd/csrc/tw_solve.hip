@@ -13,7 +13,7 @@ namespace tw {
 template <int NT, int NC>
 __global__ void __launch_bounds__(512, 2) solve_f32_kernel(const SolveArgs a)
 {
-    using Eng = Engine<NT, NC, 8, 32, 0>;
+    using Eng = Engine3<NT, NC, 0>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -84,7 +84,7 @@ static int launch_solve_one(const SolveArgs &a, hipStream_t s)
     constexpr int EPB = 8 * EPW;
     const uint64_t nb = (a.num_attempts + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
-    const size_t lds_bytes = engine_lds_floats<NT, 32>(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("solve: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
