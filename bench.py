@@ -127,7 +127,8 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.lib().tw_set_device(local_rank))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # under torchrun the distributed path runs even at N=1
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -145,7 +146,7 @@ def main():
 
     def step(i):
         seed = 1000 + i
-        if world > 1:
+        if use_dist:
             merged, data = collect_sharded(coll, env, policy, seed=seed, dst=0)
             n = len(data)
             del merged

@@ -184,6 +184,34 @@ def test_reference_style_attribute_access(tw, oracle):
     assert len(data.obs) == n + 1 and data.actions[-1] == 1 and data.perms[-1] == -1
 
 
+def test_zero_copy_torch_views_and_single_rank_gather(tw, oracle):
+    """to_torch() aliases the device buffers (no copy); the sharded-collect path run with a
+    one-rank process group gives the reference merge order."""
+    import torch
+    gp, _ = _pair(oracle, 9, 9, 32, 32)
+    env = tw.env.Puzzle(3, 3, 5, 2, 256)
+    d = tw.collector.PPOCollector(200, 0.99, 0.95, 1).collect(env, gp, seed=3)
+    t = d.to_torch()
+    a = d.to_numpy()
+    assert t["obs"].is_cuda and t["obs"].dtype == torch.uint8 and tuple(t["logits"].shape) == a["logits"].shape
+    for k in ("obs", "logits", "values", "actions", "advs", "rets", "perms", "ep_len"):
+        assert np.array_equal(t[k].cpu().numpy(), a[k]), k
+    assert t["values"].data_ptr() == d.device_arrays()["values"].__cuda_array_interface__["data"][0]
+    # one-rank "sharded" collect == plain collect in merge order
+    import os
+    import torch.distributed as dist
+    from twisterl_amd.dist import collect_sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        merged, local = collect_sharded(tw.collector.PPOCollector(200, 0.99, 0.95, 1), env, gp, seed=3)
+        for k in ("obs", "logits", "values", "actions", "advs", "rets"):
+            assert np.array_equal(merged[k].cpu().numpy(), a[k]), k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_errors(tw, oracle):
     gp, _ = _pair(oracle, 9, 8, 32, 32)
     with pytest.raises(RuntimeError, match="No data in collected data chunks to merge"):
