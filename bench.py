@@ -206,7 +206,7 @@ def main():
                 "envs_per_gpu": args.envs, "records_per_step": rec_per_launch * world, "parallelism": f"episodes sharded x{world}",
             },
             "roofline": {
-                "bound": "mfma", "kernel": "tw::rollout_f32_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "bound": "mfma", "kernel": "tw::rollout_f32_kernel" if args.precision == "fp32" else "tw::rollout_f16_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 # HBM bytes per launch: PMC-measured bytes/record (profiles/r01_hbm_traffic.json) x records of this launch
                 "traffic": (tpr * rec_per_launch) if tpr is not None else None,

@@ -20,6 +20,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libtw_oracle.so")
 
 ARITH_REF = 0    # reference order: un-fused multiply/add, k-ordered, bias last
 ARITH_CHAIN = 1  # fused-multiply-add chain (what an f32 MFMA computes), bias last
+ARITH_F16 = 2    # f16-rounded weights/activations, wide accumulation, f32 biases (the HIP library's precision="fp16" mode)
 
 MAX_CELLS = 64
 MAX_LAYERS = 8
@@ -133,6 +134,14 @@ def philox4x32_10(ctr, key):
     o = (C.c_uint32 * 4)()
     lib().two_philox4x32_10(c, k, o)
     return [int(x) for x in o]
+
+
+def round_f16(x: float) -> float:
+    """f32 -> binary16 (RNE) -> f32, as used by the ARITH_F16 forward"""
+    f = lib().two_round_f16
+    f.restype = C.c_float
+    f.argtypes = [C.c_float]
+    return float(f(C.c_float(x)))
 
 
 def logf_det(x: float) -> float:

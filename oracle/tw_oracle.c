@@ -232,9 +232,40 @@ static inline float relu_f(float x) { return x > 0.0f ? x : 0.0f; } /* layers.rs
 
 /* Linear::forward (layers.rs:31-37): out = W*x + b (+ReLU).  nalgebra's gemv walks the
  * columns of the column-major W: out = col0*x0; out += col_k*x_k; bias added afterwards. */
+/* f32 -> IEEE binary16 (round to nearest even) -> f32: the rounding v_cvt_pk_f16_f32 and the host-side
+ * (_Float16) conversion of the HIP library's f16 weight image apply. */
+float two_round_f16(float x)
+{
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return x;                                   /* inf / nan */
+    if (a >= 0x477ff000u) { u = sign | 0x7f800000u; memcpy(&x, &u, 4); return x; }   /* >= 65520 -> inf */
+    if (a < 0x38800000u) {                                            /* below 2^-14: f16 subnormal, quantum 2^-24 */
+        const float q = rintf(fabsf(x) * 16777216.0f) / 16777216.0f;
+        return sign ? -q : q;
+    }
+    const uint32_t rem = a & 0x1fffu;
+    a &= ~0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (a & 0x2000u))) a += 0x2000u;
+    a |= sign; memcpy(&x, &a, 4);
+    return x;
+}
+
 static void linear_forward(const two_linear *l, const float *x, float *out, int arith)
 {
     const int n_out = l->out, n_in = l->in;
+    if (arith == TWO_ARITH_F16) {
+        /* f16 inputs and weights, exact products, wide accumulation, f32 bias (tw_engine16.hpp) */
+        for (int o = 0; o < n_out; ++o) {
+            double acc = 0.0;
+            for (int k = 0; k < n_in; ++k)
+                acc += (double)two_round_f16(l->w[(size_t)k * n_out + o]) * (double)two_round_f16(x[k]);
+            float v = (float)acc + l->b[o];
+            out[o] = l->relu ? relu_f(v) : v;
+        }
+        return;
+    }
     if (arith == TWO_ARITH_CHAIN) {
         for (int o = 0; o < n_out; ++o) out[o] = 0.0f;
         for (int k = 0; k < n_in; ++k) {
@@ -282,8 +313,17 @@ static int sequential_forward(const two_linear *layers, int n, const float *in, 
 }
 
 /* EmbeddingBag::forward (layers.rs:56-86) */
-static int embbag_forward(const two_embbag *e, const int64_t *obs, int n_obs, float *out)
+static int embbag_forward(const two_embbag *e, const int64_t *obs, int n_obs, float *out, int arith)
 {
+    if (arith == TWO_ARITH_F16 && e->obs_ndim == 1) {
+        for (int k = 0; k < e->vec_len; ++k) {
+            double acc = 0.0;
+            for (int i = 0; i < n_obs; ++i) acc += (double)two_round_f16(e->vectors[(size_t)obs[i] * e->vec_len + k]);
+            float v = (float)acc + e->bias[k];
+            out[k] = e->relu ? relu_f(v) : v;
+        }
+        return e->bias_len;
+    }
     for (int k = 0; k < e->bias_len; ++k) out[k] = e->bias[k];
     if (e->obs_ndim == 1) {
         for (int i = 0; i < n_obs; ++i) {
@@ -316,7 +356,7 @@ void two_policy_raw_predict(const two_policy *pol, const int64_t *obs, int n_obs
         use = pobs;
     }
     float h0[TWO_MAX_WIDTH], h1[TWO_MAX_WIDTH], hv[TWO_MAX_WIDTH], ha[TWO_MAX_WIDTH];
-    int n0 = embbag_forward(&pol->emb, use, n_obs, h0);
+    int n0 = embbag_forward(&pol->emb, use, n_obs, h0, arith);
     int n1 = sequential_forward(pol->common, pol->n_common, h0, n0, h1, arith);   /* :86 */
     int nv = sequential_forward(pol->value, pol->n_value, h1, n1, hv, arith);     /* :89 */
     float vsum = 0.0f;

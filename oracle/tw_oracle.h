@@ -92,8 +92,13 @@ typedef struct {
  *  TWO_ARITH_REF   -- reference order: k-ordered, un-fused multiply then add, bias last
  *                     (nalgebra gemv, layers.rs:32)
  *  TWO_ARITH_CHAIN -- k-ordered fused multiply-add chain from 0, bias last; this is the
- *                     order an f32 MFMA accumulates in, so the HIP "exact" mode is bit-equal */
-enum { TWO_ARITH_REF = 0, TWO_ARITH_CHAIN = 1 };
+ *                     order an f32 MFMA accumulates in, so the HIP "exact" mode is bit-equal
+ *  TWO_ARITH_F16   -- table rows, weights and layer inputs rounded to binary16 (RNE), products exact,
+ *                     accumulation in double, biases and outputs f32: the spec of the HIP library's
+ *                     TW_PREC_F16 mode (v_mfma_f32_32x32x16_f16 accumulates in f32 in a hardware-defined
+ *                     order, so that mode matches this one to f32 rounding, not bit for bit) */
+enum { TWO_ARITH_REF = 0, TWO_ARITH_CHAIN = 1, TWO_ARITH_F16 = 2 };
+float two_round_f16(float x);
 
 /* Policy::_raw_predict (policy.rs:79-100); perm < 0 means None */
 void two_policy_raw_predict(const two_policy *pol, const int64_t *obs, int n_obs, int perm,

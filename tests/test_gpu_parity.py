@@ -335,3 +335,97 @@ def test_full_size_properties_puzzle8_65k(tw, oracle):
     tail = int(L[-1])
     for k in ("obs", "logits", "values", "actions", "advs", "rets"):
         assert np.array_equal(m[k][:tail], a[k][-tail:]) and np.array_equal(m[k][tail:], a[k][:-tail]), k
+
+
+# ------------------------------------------------------------------------------ f16-input MFMA mode
+def _check_f16_collect(oracle, a, op, w, h, diff, seed, n_perms, episodes, gamma=0.995, lam=0.995):
+    """Per-record parity of a precision="fp16" collect (merge_order=False) with the oracle, independent of
+    sampling: env transitions / obs / masks / rewards / twist draws BIT-EXACT by replaying the GPU's
+    actions; logits and values within 1e-4 of the oracle's ARITH_F16 forward on the same record; the
+    action BIT-EXACT = the oracle's Gumbel-max on the GPU's own logits with the spec's uniforms; GAE
+    bit-exact on the GPU's own values.  Returns the largest logit/value deviation seen."""
+    n2 = w * h
+    L = a["ep_len"].astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(L)])
+    worst = 0.0
+    for e in episodes:
+        s, n = int(starts[e]), int(L[e])
+        p = oracle.Puzzle(w, h, diff, 2, 256)
+        p.reset(seed=seed, episode=int(e))
+        obs, masks, rew, fin, _ = oracle.replay(p, a["actions"][s:s + n - 1].astype(np.int64))
+        assert np.array_equal(obs, a["obs"][s:s + n].astype(np.int64))
+        assert np.array_equal(f32_bits(rew), f32_bits(a["rewards"][s:s + n]))
+        assert fin[-1] and not fin[:-1].any()
+        assert np.all((a["logits"][s:s + n] == np.float32(-1e10)) == ~masks.astype(bool))
+        advs, rets = oracle.gae(a["rewards"][s:s + n], a["values"][s:s + n], gamma, lam)
+        assert np.array_equal(f32_bits(advs), f32_bits(a["advs"][s:s + n]))
+        assert np.array_equal(f32_bits(rets), f32_bits(a["rets"][s:s + n]))
+        for t in range(n):
+            perm = -1
+            if n_perms:
+                perm = (oracle.philox4x32_10([e & 0xFFFFFFFF, e >> 32, t, 2], [seed & 0xFFFFFFFF, seed >> 32])[0] * n_perms) >> 32
+            assert int(a["perms"][s + t]) == perm
+            lo, vo = op.forward(obs[t].tolist(), masks[t].tolist(), perm=perm, arith=oracle.ARITH_F16)
+            lg = a["logits"][s + t]
+            # typical deviation 1e-6 (f32 accumulation order inside the MFMA); when that last-bit difference
+            # flips the f16 rounding of one hidden activation (2^-11 relative) a logit moves by up to ~3e-5
+            np.testing.assert_allclose(lg, lo, atol=1e-4, rtol=1e-5)
+            assert abs(float(a["values"][s + t]) - vo) <= 1e-4 * max(1.0, abs(vo))
+            worst = max(worst, float(np.max(np.abs(lg - np.asarray(lo, np.float32)))), abs(float(a["values"][s + t]) - vo))
+            u = [(x >> 8) / 16777216.0 for x in oracle.philox4x32_10([e & 0xFFFFFFFF, e >> 32, t, 1], [seed & 0xFFFFFFFF, seed >> 32])]
+            assert int(a["actions"][s + t]) == oracle.sample_from_logits(lg, u, det_log=True)
+    return worst
+
+
+@pytest.mark.parametrize("w,h,diff,emb,hidden,E,twists", [
+    (3, 3, 5, 32, 32, 300, False),      # Puzzle-8, one stage, ragged workgroup tail
+    (3, 3, 12, 64, 64, 129, True),      # two stages, twists
+    (2, 2, 3, 96, 32, 64, False),       # three stages (ring wrap), 2x2 board
+    (3, 2, 4, 128, 128, 70, False),     # non-square board (6 cells padded to 9 chunks)
+    (4, 4, 6, 512, 256, 256, True),     # Puzzle-15 at the benchmark's network size, with twists
+])
+def test_ppo_collect_f16_mode(tw, oracle, w, h, diff, emb, hidden, E, twists):
+    """precision="fp16" (BASELINE config 2: 'MLP policy fp16, bit-exact state check vs CPU')."""
+    n2 = w * h
+    if twists and w != h:
+        pytest.skip("transpose twist needs a square board")
+    gp, op = _pair(oracle, n2, 1, emb, hidden, twists=twists)
+    genv = tw.env.Puzzle(w, h, diff, 2, 256)
+    oenv = oracle.Puzzle(w, h, diff, 2, 256)
+    coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32},
+                                     seed=13, merge_order=False, precision="fp16")
+    a = coll.collect(genv, gp, seed=13).to_numpy()
+    b = coll.collect(genv, gp, seed=13).to_numpy()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k                       # deterministic
+    worst = _check_f16_collect(oracle, a, op, w, h, diff, 13, 2 if twists else 0, range(E))
+    # whole-collect comparison with the oracle running the same spec: identical wherever no Gumbel near-tie
+    # flipped an action (the f32 accumulation order inside the MFMA is the only difference)
+    o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=13, arith=oracle.ARITH_F16, det_log=True, merge_order=False)
+    same = 0
+    L = a["ep_len"].astype(np.int64); starts = np.concatenate([[0], np.cumsum(L)])
+    Lo = o.ep_len.astype(np.int64); so = np.concatenate([[0], np.cumsum(Lo)])
+    for e in range(E):
+        if L[e] == Lo[e] and np.array_equal(a["actions"][starts[e]:starts[e + 1]].astype(np.int64), o.actions[so[e]:so[e + 1]]):
+            same += 1
+            np.testing.assert_allclose(a["rets"][starts[e]:starts[e + 1]], o.additional_data["rets"][so[e]:so[e + 1]], atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(a["advs"][starts[e]:starts[e + 1]], o.additional_data["advs"][so[e]:so[e + 1]], atol=2e-5, rtol=1e-5)
+    assert same >= 0.98 * E, (same, E, worst)
+
+
+def test_f16_mode_errors_and_full_size_sample(tw, oracle):
+    """65,536 Puzzle-8 envs in the f16 mode (BASELINE config 2): record-count identities and the per-record
+    replay parity on a sample; unsupported shapes fail loudly."""
+    gp, op = _pair(oracle, 9, 0, 512, 256)
+    env = tw.env.Puzzle(3, 3, 32, 2, 256)
+    a = tw.collector.PPOCollector(65536, 0.995, 0.995, 32, merge_order=False, precision="fp16").collect(env, gp, seed=21).to_numpy()
+    L = a["ep_len"].astype(np.int64)
+    assert L.sum() == a["obs"].shape[0] and L.min() >= 1 and L.max() <= 65
+    rng = np.random.default_rng(1)
+    _check_f16_collect(oracle, a, op, 3, 3, 32, 21, 0, [int(e) for e in rng.choice(65536, size=24, replace=False)])
+    # a twist that does not map cells to cells has no f16 image
+    arrs = make_policy_arrays(9, seed=0, emb=32, hidden=32)
+    bad = list(range(81)); bad[0], bad[9] = bad[9], bad[0]
+    pol = amd_policy(arrs, [bad], [[0, 1, 2, 3]])
+    with pytest.raises(RuntimeError, match="f16"):
+        tw.collector.PPOCollector(4, 0.9, 0.9, 1, precision="fp16").collect(tw.env.Puzzle(3, 3, 2, 2, 256), pol)

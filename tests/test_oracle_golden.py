@@ -411,3 +411,25 @@ def test_solve_and_evaluate_semantics(oracle):
     assert oracle.evaluate(oracle.Puzzle(3, 3, 0, 2, 256), pol, 10, True, 1) == (1.0, 1.0)
     sr, mr = oracle.evaluate(oracle.Puzzle(3, 3, 3, 2, 256), pol, 40, False, 4, seed=1)
     assert 0.0 <= sr <= 1.0 and -0.6 <= mr <= 1.0
+
+
+def test_round_f16_matches_numpy_float16(oracle):
+    """The ARITH_F16 rounding is IEEE binary16 round-to-nearest-even (numpy's float16 cast)."""
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.normal(size=2000).astype(np.float32), (rng.normal(size=500) * 1e-6).astype(np.float32),
+                         (rng.normal(size=500) * 3e4).astype(np.float32),
+                         np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e-8, 5.96e-8, 2.98e-8, 6.1e-5, 1.0009765625, 1.00048828125], np.float32)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).astype(np.float32)
+    got = np.array([oracle.round_f16(float(x)) for x in xs], np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_f16_forward_close_to_f32_forward(oracle):
+    from tests.util import make_policy_arrays, oracle_policy
+    op = oracle_policy(oracle, make_policy_arrays(9, seed=4, emb=64, hidden=32))
+    obs = [i * 9 + v for i, v in enumerate([3, 1, 2, 0, 4, 5, 6, 7, 8])]
+    l32, v32 = op.forward(obs, [True] * 4, arith=oracle.ARITH_REF)
+    l16, v16 = op.forward(obs, [True] * 4, arith=oracle.ARITH_F16)
+    assert np.max(np.abs(np.asarray(l32) - np.asarray(l16))) < 5e-3 and abs(v32 - v16) < 5e-3
+    assert not np.array_equal(np.asarray(l32, np.float32), np.asarray(l16, np.float32))

@@ -288,6 +288,37 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
               s_wh8 = seg((size_t)H * 8 * 4), s_bh8 = seg(8 * 4), s_w1 = seg((size_t)E * H * 4), s_wa = seg((size_t)H * A * 4),
               s_ba = seg((size_t)A * 4), s_wv = seg((size_t)H * 4), s_bv = seg(4),
               s_op = seg((size_t)(d->n_perms ? d->n_perms : 1) * OS), s_ap = seg((size_t)(d->n_perms ? d->n_perms : 1) * A);
+    // ---- f16 image (Engine16, tw_engine16.hpp): available when obs ids are cell*n+tile with n <= 16 and
+    //      every twist maps cells to cells (true for any symmetry of a cell-wise one-hot encoding)
+    uint32_t n16 = 1; while (n16 * n16 < OS) ++n16;
+    bool f16_ok = n16 * n16 == OS && n16 <= 16 && d->n_perms <= 4 && A <= 4;
+    std::vector<uint8_t> srcmap((size_t)(d->n_perms + 1) * 16, 0), vmap((size_t)(d->n_perms + 1) * 256, 0xFF);
+    if (f16_ok) {
+        for (uint32_t c2 = 0; c2 < n16; ++c2) { srcmap[c2] = (uint8_t)c2; for (uint32_t v2 = 0; v2 < n16; ++v2) vmap[c2 * 16 + v2] = (uint8_t)v2; }
+        for (uint32_t p = 0; p < d->n_perms && f16_ok; ++p) {
+            std::vector<int> cm(n16, -1), seen(n16, 0);
+            for (uint32_t sc = 0; sc < n16 && f16_ok; ++sc) {
+                for (uint32_t v2 = 0; v2 < n16; ++v2) {
+                    const uint32_t id2 = (uint32_t)d->obs_perms[(size_t)p * OS + sc * n16 + v2];
+                    if (v2 == 0) cm[sc] = (int)(id2 / n16);
+                    else if ((int)(id2 / n16) != cm[sc]) { f16_ok = false; break; }
+                }
+                if (f16_ok) { if (seen[cm[sc]]) f16_ok = false; seen[cm[sc]] = 1; }
+            }
+            if (!f16_ok) break;
+            for (uint32_t sc = 0; sc < n16; ++sc) {
+                const uint32_t tc = (uint32_t)cm[sc];
+                srcmap[(size_t)(p + 1) * 16 + tc] = (uint8_t)sc;
+                for (uint32_t v2 = 0; v2 < n16; ++v2)
+                    vmap[((size_t)(p + 1) * 16 + tc) * 16 + v2] = (uint8_t)((uint32_t)d->obs_perms[(size_t)p * OS + sc * n16 + v2] % n16);
+            }
+        }
+    }
+    const uint32_t nc16 = !f16_ok ? 0u : (n16 <= 4 ? 4u : (n16 <= 9 ? 9u : 16u));
+    const uint32_t SP16 = nc16 + 2 * NT, NKT = E / 32;
+    const Seg s_st16 = seg(f16_ok ? (size_t)NKT * SP16 * 1024 : 0), s_hd16 = seg(f16_ok ? (size_t)NT * 2048 : 0),
+              s_eb16 = seg((size_t)NKT * 32 * 4), s_b116 = seg((size_t)NT * 32 * 4), s_bh16 = seg(8 * 4),
+              s_src16 = seg(srcmap.size()), s_vm16 = seg(vmap.size());
     std::vector<uint8_t> img(cur, 0);
     float *emb = reinterpret_cast<float *>(img.data() + s_emb.off);
     memcpy(emb, d->emb_vectors, (size_t)OS * E * 4);
@@ -331,6 +362,52 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
         for (uint32_t i = 0; i < A; ++i) img[s_ap.off + (size_t)p * A + i] = (uint8_t)d->act_perms[(size_t)p * A + i];
     }
 
+    if (f16_ok) {
+        auto put16 = [&](size_t byte_off, float x) { const _Float16 hx = (_Float16)x; memcpy(img.data() + byte_off, &hx, 2); };
+        auto rho = [](uint32_t r, uint32_t hh2) { return 8 * (r >> 2) + 4 * hh2 + (r & 3); };   // accumulator register -> tile row
+        for (uint32_t kt = 0; kt < NKT; ++kt) {
+            const size_t sbase = s_st16.off + (size_t)kt * SP16 * 1024;
+            for (uint32_t l = 0; l < 64; ++l)
+                for (uint32_t jx = 0; jx < 8; ++jx) {
+                    const uint32_t hh2 = l >> 5, row = l & 31;
+                    for (uint32_t c2 = 0; c2 < nc16; ++c2) {               // table chunk = cell c2, k slot = tile value
+                        const uint32_t val = 8 * hh2 + jx;
+                        const uint32_t kte = (kt + 1) % NKT;                // the table part of stage kt belongs to the NEXT tile (pipeline)
+                        const float x = (c2 < n16 && val < n16) ? d->emb_vectors[(size_t)(c2 * n16 + val) * E + 32 * kte + row] : 0.0f;
+                        put16(sbase + (size_t)c2 * 1024 + l * 16 + jx * 2, x);
+                    }
+                    for (uint32_t ht = 0; ht < NT; ++ht)
+                        for (uint32_t m = 0; m < 2; ++m) {                 // W1 chunk: k slot (hh2, jx) = embedding row of register 8m+jx
+                            const uint32_t k = 32 * kt + rho(8 * m + jx, hh2);
+                            put16(sbase + (size_t)(nc16 + ht * 2 + m) * 1024 + l * 16 + jx * 2, c.weights[(size_t)k * H + 32 * ht + row]);
+                        }
+                }
+        }
+        for (uint32_t ht = 0; ht < NT; ++ht)
+            for (uint32_t m = 0; m < 2; ++m)
+                for (uint32_t l = 0; l < 64; ++l)
+                    for (uint32_t jx = 0; jx < 8; ++jx) {
+                        const uint32_t hh2 = l >> 5, row = l & 31, hid = 32 * ht + rho(8 * m + jx, hh2);
+                        float x = 0.0f;
+                        if (row < 8) { if ((row & 3) < A) x = a.weights[(size_t)hid * A + (row & 3)]; }
+                        else if (row == 8 || row == 12) x = v.weights[hid];
+                        put16(s_hd16.off + (size_t)(ht * 2 + m) * 1024 + l * 16 + jx * 2, x);
+                    }
+        float *eb16 = reinterpret_cast<float *>(img.data() + s_eb16.off);
+        for (uint32_t kt = 0; kt < NKT; ++kt)
+            for (uint32_t hh2 = 0; hh2 < 2; ++hh2)
+                for (uint32_t r = 0; r < 16; ++r) eb16[(kt * 2 + hh2) * 16 + r] = d->emb_bias[32 * kt + rho(r, hh2)];
+        float *b116 = reinterpret_cast<float *>(img.data() + s_b116.off);
+        for (uint32_t ht = 0; ht < NT; ++ht)
+            for (uint32_t hh2 = 0; hh2 < 2; ++hh2)
+                for (uint32_t r = 0; r < 16; ++r) b116[(ht * 2 + hh2) * 16 + r] = c.bias[32 * ht + rho(r, hh2)];
+        float *bh16 = reinterpret_cast<float *>(img.data() + s_bh16.off);
+        for (uint32_t i = 0; i < A; ++i) bh16[i] = a.bias[i];
+        bh16[4] = v.bias[0];
+        memcpy(img.data() + s_src16.off, srcmap.data(), srcmap.size());
+        memcpy(img.data() + s_vm16.off, vmap.data(), vmap.size());
+    }
+
     tw_policy *pol = new tw_policy();
     hipError_t e = hipGetDevice(&pol->device);
     if (e == hipSuccess) e = hipMalloc(&pol->arena, img.size());
@@ -357,6 +434,12 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     pd.bv = reinterpret_cast<const float *>(base + s_bv.off);
     pd.obs_perms = base + s_op.off;
     pd.act_perms = base + s_ap.off;
+    pd.f16_nc = (int)nc16;
+    pd.stage16 = base + s_st16.off; pd.head16 = base + s_hd16.off;
+    pd.ebias16 = reinterpret_cast<const float *>(base + s_eb16.off);
+    pd.b1img16 = reinterpret_cast<const float *>(base + s_b116.off);
+    pd.bh16 = reinterpret_cast<const float *>(base + s_bh16.off);
+    pd.srcmap16 = base + s_src16.off; pd.vmap16 = base + s_vm16.off;
     return pol;
 }
 
@@ -499,7 +582,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
         set_error("Something went wrong. No data in collected data chunks to merge. ");   // collector.rs:41
         return TW_ERR_EMPTY;
     }
-    if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_ppo_collect: precision %u not implemented", prm->precision); return TW_ERR_UNSUPPORTED; }
+    if (prm->precision != TW_PREC_F32_EXACT && prm->precision != TW_PREC_F16) { set_error("tw_ppo_collect: unknown precision %u", prm->precision); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
 
     RolloutArgs ra{};
@@ -534,7 +617,9 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
     TW_HIP(hipEventRecord(ev.ev[0], s));
-    rc = launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads); if (rc) return rc;
+    rc = prm->precision == TW_PREC_F16 ? launch_rollout_f16(ra, s, &st.rollout_blocks, &st.rollout_threads)
+                                       : launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads);
+    if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[1], s));
     rc = launch_scan(ra.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
     if (rc) return rc;

@@ -260,6 +260,15 @@ struct PolicyDev {
     const float *bv;         // [1]
     const uint8_t *obs_perms; // [n_perms][obs_size] (ids < 256)
     const uint8_t *act_perms; // [n_perms][n_actions]
+    // f16-input image (TW_PREC_F16, Engine16 in tw_engine16.hpp); f16_nc == 0: not available for this policy
+    int32_t f16_nc;           // table chunks per stage (n_cells padded to 4 / 9 / 16)
+    const uint8_t *stage16;   // [emb/32][(f16_nc + 2*hidden/32) KiB]: per 32 embedding dims, table chunks then W1 chunks (MFMA A operands)
+    const uint8_t *head16;    // [hidden/32][2][1 KiB]: head A operands
+    const float   *ebias16;   // [emb/32][2][16]: embedding bias in accumulator-register order per lane half
+    const float   *b1img16;   // [hidden/32][2][16]
+    const float   *bh16;      // [8]: action bias 0..3, value bias 4
+    const uint8_t *srcmap16;  // [(n_perms+1)][16]: source cell of target chunk c under twist p-1 (p = 0: identity)
+    const uint8_t *vmap16;    // [(n_perms+1)][16][16]: value of the twisted id inside chunk c, 15-bit clean (< 16)
 };
 
 // padded (episode-major) trajectory workspace written by the rollout / MCTS kernels: ONE 48-byte
@@ -312,6 +321,7 @@ struct RolloutArgs {
 
 // kernel launchers (each returns a TW_* status)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, uint64_t *ep_start,
                 uint64_t *total /*device*/, void *scratch, size_t scratch_bytes, hipStream_t s);
 size_t scan_scratch_bytes(uint64_t n_episodes);

@@ -1,0 +1,158 @@
+// tw_rollout16.hip -- fused PPO rollout kernel, f16-input MFMA policy forward (TW_PREC_F16), gfx950.
+//
+// Same path as tw_rollout.hip (reference rust/src/collector/ppo.rs:54-80 with envs/puzzle.rs and
+// nn/policy.rs:56-100,169-172), same RNG keys, same record format; only the policy arithmetic differs
+// (see tw_engine16.hpp for the numeric spec and the MFMA mapping).  One workgroup = 4 waves = 256
+// episodes; each lane carries the state of TWO episodes (column j of tile 0 and of tile 1); lane half h
+// samples, records and draws the twist for tile h and hands action and twist to the other half with one
+// cross-half shuffle each.
+#include "tw_engine16.hpp"
+
+namespace tw {
+
+template <int NHT, int NC>
+__global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a)
+{
+    using Eng = Engine16<NHT, NC>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds16[];
+    Eng eng;
+    eng.begin1(a.pol, lds16);
+
+    const PuzzleConsts env = a.env;
+    const int j = eng.j, hh = eng.hh;
+    // this lane half owns tile hh: episode (wave, hh, j)
+    const uint64_t e_own   = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * 64 + hh * 32 + j);
+    const bool     v_own   = e_own < a.num_episodes;
+    const uint64_t eg_own  = a.episode_offset + e_own;
+
+    PuzzleLane own;
+    own.board = env.ident; own.zx = 0; own.zy = 0; own.depth = 0;
+    if (v_own) puzzle_reset(own, env, a.seed, eg_own);
+    // both halves keep both episodes' state (the one-hot operands of both tiles are built on every lane)
+    PuzzleLane st0, st1;
+    {
+        PuzzleLane oth;
+        oth.board = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(own.board >> 32), 32, 64) << 32) |
+                    (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)own.board, 32, 64);
+        oth.zx = __shfl_xor(own.zx, 32, 64); oth.zy = __shfl_xor(own.zy, 32, 64); oth.depth = __shfl_xor(own.depth, 32, 64);
+        st0 = hh ? oth : own; st1 = hh ? own : oth;
+    }
+    const bool v_oth = __shfl_xor(v_own ? 1 : 0, 32, 64) != 0;
+    bool alive0 = hh ? v_oth : v_own, alive1 = hh ? v_own : v_oth;
+    int      t = 0;
+    uint32_t len_own = 0;
+    const uint64_t rec_base = e_own * (uint64_t)a.out.t_pad;
+
+    eng.begin2();
+    while (__syncthreads_or((alive0 || alive1) ? 1 : 0)) {
+        // ---- twist draw for the own tile (policy.rs:67-77), exchanged with the other half --------
+        int perm_own = -1;
+        if (eng.pol.n_perms > 0) {
+            const u32x4 w = rng_draw(a.seed, eg_own, (uint32_t)t, STREAM_PERM);
+            perm_own = (int)u32_below(w.x, (uint32_t)eng.pol.n_perms);
+        }
+        const int perm_oth = __shfl_xor(perm_own, 32, 64);
+        const int perm0 = hh ? perm_oth : perm_own, perm1 = hh ? perm_own : perm_oth;
+        typename Eng::OneHots oh;
+        eng.onehots(st0.board, perm0, oh.w0);
+        eng.onehots(st1.board, perm1, oh.w1);
+
+        f32x16 out0, out1;
+        eng.forward(oh, out0, out1);
+
+        // ---- own tile: head bias, act-perm, mask, reward, Gumbel-max (policy.rs:56-65,169-172) ---
+        const float *bh = reinterpret_cast<const float *>(lds16 + Eng::O_BH);
+        float lg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[i] = (hh ? out1[i] : out0[i]) + bh[i];
+        const float value = (hh ? out1[4] : out0[4]) + bh[4];
+        const PuzzleLane &mine = hh ? st1 : st0;
+        eng.act_perm(perm_own, lg);
+        const uint32_t mb = puzzle_maskbits(mine, env);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[i] = ((mb >> i) & 1u) ? lg[i] : -1e10f;
+        const float rew = puzzle_reward(mine, env);
+        const u32x4 gw = rng_draw(a.seed, eg_own, (uint32_t)t, STREAM_GUMBEL);
+        const int act_own = gumbel_argmax4(lg, gw);
+        const bool alive_own = hh ? alive1 : alive0;
+        if (alive_own) {
+            uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (i < env.n_cells) pk[i >> 2] |= (uint32_t)(i * env.n_cells + (int)nib(mine.board, i)) << (8 * (i & 3));
+            store_rec(a.out.rec + rec_base + (uint64_t)t, pk, lg, value, rew, act_own, perm_own);
+        }
+        const int act_oth = __shfl_xor(act_own, 32, 64);
+        const int act0 = hh ? act_oth : act_own, act1 = hh ? act_own : act_oth;
+        // ---- is_final / step for both tiles (ppo.rs:78-79) ----------------------------------------
+        if (alive0) {
+            if (puzzle_final(st0, env)) { alive0 = false; if (!hh) len_own = (uint32_t)t + 1u; }
+            else puzzle_step(st0, env, act0);
+        }
+        if (alive1) {
+            if (puzzle_final(st1, env)) { alive1 = false; if (hh) len_own = (uint32_t)t + 1u; }
+            else puzzle_step(st1, env, act1);
+        }
+        ++t;
+    }
+    if (v_own) a.out.ep_len[e_own] = len_own;
+    eng.end();
+}
+
+template <int NHT, int NC>
+static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    using Eng = Engine16<NHT, NC>;
+    const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
+    if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout16: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
+    const size_t lds_bytes = engine16_lds_bytes<NHT, NC>();
+    if (lds_bytes > 159 * 1024) { set_error("rollout16: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
+    static size_t attr_bytes = 0;
+    if (lds_bytes > attr_bytes) {
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f16_kernel<NHT, NC>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_bytes = lds_bytes;
+    }
+    hipLaunchKernelGGL((rollout_f16_kernel<NHT, NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
+    TW_HIP(hipGetLastError());
+    if (blocks) *blocks = (uint32_t)nb;
+    if (threads) *threads = Eng::THREADS;
+    return TW_OK;
+}
+
+template <int NHT>
+static int launch16_nc(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    switch (a.pol.f16_nc) {
+        case 4:  return launch16<NHT, 4>(a, s, blocks, threads);
+        case 9:  return launch16<NHT, 9>(a, s, blocks, threads);
+        case 16: return launch16<NHT, 16>(a, s, blocks, threads);
+        default: set_error("rollout16: bad chunk count %d", a.pol.f16_nc); return TW_ERR_UNSUPPORTED;
+    }
+}
+
+int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    if (a.pol.f16_nc == 0) {
+        set_error("precision f16: this policy has no f16 image (needs obs ids of the form cell*n+tile with n <= 16, at most %d "
+                  "twists, and twists that map cells to cells)", E16_MAXP);
+        return TW_ERR_UNSUPPORTED;
+    }
+    if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
+        a.pol.emb % 32 != 0 || a.pol.emb < 32 || a.pol.emb > 32 * E16_MAX_KT || a.env.n_cells > a.pol.f16_nc || a.out.t_pad < a.env.depth0 + 1) {
+        set_error("rollout16: unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d)",
+                  a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad);
+        return TW_ERR_UNSUPPORTED;
+    }
+    switch (a.pol.hidden) {
+        case 32:  return launch16_nc<1>(a, s, blocks, threads);
+        case 64:  return launch16_nc<2>(a, s, blocks, threads);
+        case 128: return launch16_nc<4>(a, s, blocks, threads);
+        case 256: return launch16_nc<8>(a, s, blocks, threads);
+        default:
+            set_error("rollout16: hidden size %d not in {32,64,128,256}", a.pol.hidden);
+            return TW_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace tw
