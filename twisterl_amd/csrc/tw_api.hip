@@ -315,7 +315,7 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
         }
     }
     const uint32_t nc16 = !f16_ok ? 0u : (n16 <= 4 ? 4u : (n16 <= 9 ? 9u : 16u));
-    const uint32_t SP16 = nc16 + 2 * NT, NKT = E / 32;
+    const uint32_t SP16 = (nc16 + 2 * NT + 3) / 4 * 4, NKT = E / 32;     // stage image padded to whole rounds of 4 DMA pieces (Engine16::SBYTES)
     const Seg s_st16 = seg(f16_ok ? (size_t)NKT * SP16 * 1024 : 0), s_hd16 = seg(f16_ok ? (size_t)NT * 2048 : 0),
               s_eb16 = seg((size_t)NKT * 32 * 4), s_b116 = seg((size_t)NT * 32 * 4), s_bh16 = seg(8 * 4),
               s_src16 = seg(srcmap.size()), s_vm16 = seg(vmap.size());

@@ -31,6 +31,8 @@
 #pragma once
 #include "tw_engine.hpp"
 
+#include <type_traits>
+
 namespace tw {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -44,37 +46,49 @@ template <int NHT, int NC>
 __host__ __device__ constexpr size_t engine16_lds_bytes()
 {
     return 160 + (size_t)(E16_MAXP + 1) * (16 + 256) + 32 + 64 + (size_t)NHT * 128 + (size_t)E16_MAX_KT * 128 +
-           (size_t)NHT * 2048 + (size_t)NC * 1024 + (size_t)3 * (NC + 2 * NHT) * 1024;
+           (size_t)NHT * 2048 + (size_t)NC * 1024 + (size_t)3 * ((NC + 2 * NHT + 3) / 4) * 4096;
 }
 
 template <int NHT, int NC>
 struct Engine16 {
     static constexpr int NW = 4, THREADS = 256, EPB = 256, D = 3;
     static constexpr int SP     = NC + 2 * NHT;              // 1-KiB pieces per stage
-    static constexpr int SBYTES = SP * 1024;
-    static constexpr int NOPS   = (SP + NW - 1) / NW;        // DMA ops per wave per stage
+    static constexpr int NOPS   = (SP + NW - 1) / NW;        // DMA ops per wave per stage (one piece each)
+    static constexpr int SBYTES = NOPS * NW * 1024;          // stage image / ring slot, padded to whole rounds of NW pieces
     // LDS map (small tables first: their offsets fit the 16-bit ds offset field)
     static constexpr uint32_t O_OH = 0, O_SRC = 160, O_VMAP = O_SRC + (E16_MAXP + 1) * 16, O_ACT = O_VMAP + (E16_MAXP + 1) * 256,
                               O_BH = O_ACT + 32, O_B1 = O_BH + 64, O_EBIAS = O_B1 + NHT * 128, O_HEAD = O_EBIAS + E16_MAX_KT * 128,
                               O_T0 = O_HEAD + NHT * 2048, O_RING = O_T0 + NC * 1024;
     static_assert(O_RING + 3 * SBYTES == engine16_lds_bytes<NHT, NC>(), "LDS map");
 
-    struct Pipe { h16x8 a[D], x0[D], x1[D]; };               // operand reads in flight for the next D MFMA pairs
-    struct OneHots { uint32_t w0[(NC + 3) / 4], w1[(NC + 3) / 4]; };   // byte c = 16 * one-hot table index of chunk c (tile 0 / 1)
+    struct Pipe { h16x8 a[D], x0[D], x1[D]; f32x16 eb; };    // operand reads in flight for the next D MFMA pairs; next embedding bias
+    struct OneHots { uint32_t a0[NC], a1[NC]; };             // LDS address of the one-hot fragment of chunk c (tile 0 / 1)
 
     PolicyDev pol;
     int tid, lane, wave, j, hh, n_kt, rp;
+#ifdef TW_ABLATE   // diagnostic build: per-wave cycle stamps (s_memtime), summed into tw::g_stamps16 at kernel end
+    unsigned long long st[8];      // 0 pre 1 prologue 2 stage bodies 3 vmcnt wait 4 stage barrier 5 heads 6 post 7 step barrier
+#define TW_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define TW_ACC(i, a, b) st[i] += (b) - (a)
+#else
+#define TW_STAMP(var)
+#define TW_ACC(i, a, b)
+#endif
     uint8_t *lg_;                  // LDS base, generic
+    uint32_t lds_u32, voff;        // LDS base as an M0 value; per-lane global byte offset of this wave's DMA piece
     lds_cu8 *L;                    // LDS base, address space 3
     h16x2 emb_lim, common_lim;
 
-    __device__ __forceinline__ void stream_op(int stage, int slot, int op)
+    // One DMA op = this wave's 1-KiB piece (wave + NW*op) of a stage: global (SGPR base + per-lane VGPR offset) -> LDS
+    // (M0 = wave-uniform destination, the hardware adds lane*16).  Inline asm: see glds16() in tw_engine.hpp.
+    __device__ __forceinline__ void stream_op(const uint8_t *stage_base, uint32_t slot_m0, int op) const
     {
-        int piece = wave + NW * op;
-        piece = piece < SP ? piece : SP - 1;                 // branch-free: past the end repeat the last piece
-        const uint8_t *src = pol.stage16 + (size_t)stage * SBYTES + piece * 1024 + lane * 16;
-        glds16(reinterpret_cast<const float *>(src), reinterpret_cast<float *>(lg_ + O_RING + slot * SBYTES + piece * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                     :: "v"(voff), "s"(slot_m0 + (uint32_t)op * (NW * 1024u)), "s"(stage_base + (size_t)op * (NW * 1024))
+                     : "memory");     // m0 is not saved: nothing hipcc emits for gfx950 in this kernel keeps a value in it
     }
+    __device__ __forceinline__ const uint8_t *stage_ptr(int stage) const { return pol.stage16 + (size_t)stage * SBYTES; }
+    __device__ __forceinline__ uint32_t slot_m0(int slot) const { return lds_u32 + O_RING + (uint32_t)slot * SBYTES + (uint32_t)wave * 1024u; }
 
     __device__ __forceinline__ void begin1(const PolicyDev &p, uint8_t *lds)
     {
@@ -83,6 +97,8 @@ struct Engine16 {
         j = lane & 31; hh = lane >> 5;
         n_kt = pol.emb / 32;
         lg_ = lds; L = (lds_cu8 *)lds;
+        lds_u32 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds);
+        voff = (uint32_t)wave * 1024u + (uint32_t)lane * 16u;
         const _Float16 zl = (_Float16)0.0f, ml = (_Float16)(-__builtin_inff());
         emb_lim    = pol.emb_relu ? h16x2{zl, zl} : h16x2{ml, ml};
         common_lim = pol.common_relu ? h16x2{zl, zl} : h16x2{ml, ml};
@@ -107,25 +123,24 @@ struct Engine16 {
         for (int i = tid; i < n_kt * 32; i += THREADS) reinterpret_cast<float *>(lds + O_EBIAS)[i] = pol.ebias16[i];
         // stages 0 and 1 of the first forward into slots 0 and 1
 #pragma unroll
-        for (int op = 0; op < NOPS; ++op) { stream_op(0, 0, op); stream_op(n_kt > 1 ? 1 : 0, 1, op); }
+        for (int op = 0; op < NOPS; ++op) { stream_op(stage_ptr(0), slot_m0(0), op); stream_op(stage_ptr(n_kt > 1 ? 1 : 0), slot_m0(1), op); }
         rp = 0;
     }
     __device__ __forceinline__ void begin2() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __device__ __forceinline__ void end() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-    // one-hot table indices (x16, one byte per chunk) of one episode under twist perm (-1 = none)
-    __device__ __forceinline__ void onehots(uint64_t board, int perm, uint32_t (&w)[(NC + 3) / 4]) const
+    // LDS addresses of the one-hot B fragments of one episode under twist perm (-1 = none): 2*NC registers per
+    // lane, computed once per timestep, so that a fragment read in the MFMA loop is ONE instruction
+    __device__ __forceinline__ void onehots(uint64_t board, int perm, uint32_t (&w)[NC]) const
     {
         const int pi = perm + 1;
-#pragma unroll
-        for (int q = 0; q < (NC + 3) / 4; ++q) w[q] = 0u;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const uint32_t src = L[O_SRC + pi * 16 + c];
             const uint32_t v   = nib(board, (int)src);
             const uint32_t v2  = L[O_VMAP + (pi * 16 + c) * 16 + v];
             const uint32_t pos = v2 ^ ((uint32_t)hh << 3);
-            w[c >> 2] |= ((pos < 8u ? pos : 8u) * 16u) << (8 * (c & 3));
+            w[c] = O_OH + (pos < 8u ? pos : 8u) * 16u;
         }
     }
 
@@ -154,128 +169,166 @@ struct Engine16 {
     {
         return *(const __attribute__((address_space(3))) h16x8 *)(L + off);
     }
-    __device__ __forceinline__ h16x8 ldoh(const uint32_t (&w)[(NC + 3) / 4], int c) const
-    {
-        return ld8(O_OH + ((w[c >> 2] >> (8 * (c & 3))) & 0xffu));
-    }
     // Embedding MFMA with the accumulator in ARCHITECTURAL VGPRs (inline asm, "v" constraints): the 2*NHT*16
     // common-layer accumulators fill the AGPR file; given the choice hipcc parks these two tiles there as well
     // and swaps common-layer tiles out and back every stage.  hipcc pads no hazard states around inline asm:
     // the chain e0 -> e0 is always separated by the other tile's MFMA (>= 32 cycles, more than any XDL->SrcC
     // requirement), operands come from ds_read (s_waitcnt is inserted for asm operands), and the first VALU
     // read of the result is at least one MFMA pair later (phase()) or behind explicit s_nops (prologue).
-    static __device__ __forceinline__ void mfma_v(f32x16 &d, const h16x8 a, const h16x8 b, bool first)
+    // The first MFMA of a chain takes the embedding bias (f32, accumulator-register order) as its C operand.
+    static __device__ __forceinline__ void mfma_v(f32x16 &d, const h16x8 a, const h16x8 b, bool first, const f32x16 &c0)
     {
-        if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+        if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c0));
         else       asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
-    // one B register: accumulator registers (2q, 2q+1) of fragment m, plus bias, optional ReLU, to f16
+    // one B register: accumulator registers (2q, 2q+1) of fragment m (+ bias), optional ReLU, to f16
+    template <bool BIAS>
     static __device__ __forceinline__ void cvt_unit(const f32x16 &e, const f32x16 &bias, int m, int q, h16x2 lim, h16x8 &dst)
     {
-        const f32x2 v = {e[8 * m + 2 * q] + bias[8 * m + 2 * q], e[8 * m + 2 * q + 1] + bias[8 * m + 2 * q + 1]};
+        f32x2 v = {e[8 * m + 2 * q], e[8 * m + 2 * q + 1]};
+        if (BIAS) v = pk_add(v, f32x2{bias[8 * m + 2 * q], bias[8 * m + 2 * q + 1]});
         h16x2 p = __builtin_convertvector(v, h16x2);
         p = __builtin_elementwise_max(p, lim);
         dst[2 * q] = p[0]; dst[2 * q + 1] = p[1];
     }
 
-    // One phase of the software pipeline.
-    //   E_P: NC embedding MFMA pairs of tile `ke` (A operands at baseE + 1 KiB * c, B = one-hots), results
-    //        converted into (B0, B1) -- in the shadow of the M pairs when M_P, else right after the loop;
-    //   M_P: 2*NHT common-layer MFMA pairs with the CURRENT (B0, B1) (A operands at baseM + 1 KiB * q);
-    //   NEXT: which operands to prefetch for the first D pairs of the following phase: 0 none, 1 its E pairs
-    //        (A at nbase, one-hots), 2 its M pairs (A at nbase);  STREAM: issue this wave's DMA ops of stage sg
-    //        into slot s2, then wait for them and pass the stage barrier.
-    template <bool E_P, bool M_P, bool FIRST, int NEXT, bool STREAM>
-    __device__ __forceinline__ void phase(int ke, uint32_t baseE, uint32_t baseM, uint32_t nbase, int sg, int s2,
-                                          const OneHots &oh_in, f32x16 (&acc0)[NHT], f32x16 (&acc1)[NHT],
-                                          h16x8 (&B0)[2], h16x8 (&B1)[2], Pipe &pp)
-    {
-        constexpr int NE = E_P ? NC : 0, NM = M_P ? 2 * NHT : 0, NP = NE + NM;
-        // the one-hot bytes are loop invariant over the stages: keep hipcc from hoisting the 2*NC byte extracts
-        // (and their registers) out of the stage loop
-        OneHots oh = oh_in;
-#pragma unroll
-        for (int q = 0; q < (NC + 3) / 4; ++q) asm volatile("" : "+v"(oh.w0[q]), "+v"(oh.w1[q]));
-        constexpr int UPP = !M_P ? 16 : (NM > 1 ? (16 + NM - 2) / (NM - 1) : 16);   // conversion units per M pair (from pair 1)
-        h16x8 A[NP + D], X0[NE + D], X1[NE + D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            A[d] = pp.a[d];
-            if (E_P) { X0[d] = pp.x0[d]; X1[d] = pp.x1[d]; }
+    // Pair order of a phase: two embedding pairs (three LDS reads each) per common-layer pair (one read) until
+    // the embedding pairs are used up -- an even LDS load instead of a burst -- keeping the last common-layer
+    // pairs for the shadow of the accumulator conversion.  code(i) = 2*index + (1 if embedding pair).
+    template <bool E_P, bool M_P> struct Sched {
+        static constexpr int NE = E_P ? NC : 0, NM = M_P ? 2 * NHT : 0, NP = NE + NM;
+        static constexpr int KEEP = NM < 8 ? NM : 8;
+        static constexpr int code(int i)
+        {
+            int e = 0, m = 0;
+            for (int k = 0; k <= i; ++k) {
+                bool take_e = false;
+                if (e >= NE) take_e = false;
+                else if (m >= NM || NM - m <= KEEP) take_e = true;
+                else take_e = (k % 3) != 2;
+                if (k == i) return take_e ? e * 2 + 1 : m * 2;
+                if (take_e) ++e; else ++m;
+            }
+            return 0;
         }
+        static constexpr int last_e()   // position of the last embedding pair (-1: none)
+        {
+            int r = -1;
+            for (int i = 0; i < NP; ++i) if (code(i) & 1) r = i;
+            return r;
+        }
+    };
+
+    // One phase of the software pipeline.
+    //   E_P: NC embedding MFMA pairs (A operands at baseE + 1 KiB * c, B = one-hots, C of the first = pp.eb), results
+    //        converted into (Bn0, Bn1) -- in the shadow of the trailing M pairs when M_P, else right after the loop;
+    //   M_P: 2*NHT common-layer MFMA pairs with (Bc0, Bc1) (A operands at baseM + 1 KiB * q);
+    //   NEXT: prefetch the operands of the first D pairs of the following stage (pair order Sched<true, true>,
+    //        embedding A operands at nbase, common-layer ones at nbase + NC KiB) and the embedding bias of tile ke_next;
+    //   STREAM: issue this wave's DMA ops of stage sg into slot s2, then wait for them and pass the stage barrier.
+    template <bool E_P, bool M_P, bool FIRST, int NEXT, bool STREAM>
+    __device__ __forceinline__ void phase(int ke_next, uint32_t baseE, uint32_t baseM, uint32_t nbase, int sg, int s2,
+                                          const OneHots &oh, f32x16 (&acc0)[NHT], f32x16 (&acc1)[NHT],
+                                          const h16x8 (&Bc0)[2], const h16x8 (&Bc1)[2], h16x8 (&Bn0)[2], h16x8 (&Bn1)[2], Pipe &pp)
+    {
+        TW_STAMP(t_in);
+        using S = Sched<E_P, M_P>;
+        using SN = Sched<true, true>;
+        constexpr int NP = S::NP, LE = S::last_e();
+        constexpr int MAFTER = NP - 1 - LE;                                     // common-layer pairs behind the last embedding pair
+        constexpr int UPP = !M_P ? 16 : (MAFTER > 1 ? (16 + MAFTER - 2) / (MAFTER - 1) : 16);
+        const uint8_t *g_stage = stage_ptr(sg);
+        const uint32_t m0_slot = slot_m0(s2);
+        h16x8 A[NP + D], X0[NP + D], X1[NP + D];                                // indexed by POSITION in the pair order
+#pragma unroll
+        for (int d = 0; d < D; ++d) { A[d] = pp.a[d]; X0[d] = pp.x0[d]; X1[d] = pp.x1[d]; }
+        const f32x16 eb = pp.eb;
         f32x16 zero16;
 #pragma unroll
         for (int g = 0; g < 16; ++g) zero16[g] = 0.0f;
-        f32x16 e0, e1, ebv = zero16;
-        h16x8 Bn0[2], Bn1[2];
+        f32x16 e0, e1;
         auto unit = [&](int u) {      // u in [0,16): tile u>>3, fragment (u>>2)&1, register u&3
-            if ((u >> 3) == 0) cvt_unit(e0, ebv, (u >> 2) & 1, u & 3, emb_lim, Bn0[(u >> 2) & 1]);
-            else               cvt_unit(e1, ebv, (u >> 2) & 1, u & 3, emb_lim, Bn1[(u >> 2) & 1]);
+            if ((u >> 3) == 0) cvt_unit<false>(e0, zero16, (u >> 2) & 1, u & 3, emb_lim, Bn0[(u >> 2) & 1]);
+            else               cvt_unit<false>(e1, zero16, (u >> 2) & 1, u & 3, emb_lim, Bn1[(u >> 2) & 1]);
         };
         int op = 0, udone = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            // ---- operand reads of pair p + D
+            // ---- operand reads of position p + D (one-hots first: the A operand's arrival then covers all three)
             const int pn = p + D;
             if (pn < NP) {
-                A[pn] = ld8((pn < NE ? baseE + pn * 1024 : baseM + (pn - NE) * 1024));
-                if (pn < NE) { X0[pn] = ldoh(oh.w0, pn); X1[pn] = ldoh(oh.w1, pn); }
+                const int cd = S::code(pn), ix = cd >> 1;
+                if (cd & 1) {
+#if defined(TW_EXP) && (TW_EXP == 1 || TW_EXP == 3)      // timing experiment: no one-hot reads
+                    X0[pn] = X0[pn - D]; X1[pn] = X1[pn - D];
+#else
+                    X0[pn] = ld8(oh.a0[ix]); X1[pn] = ld8(oh.a1[ix]);
+#endif
+                    A[pn] = ld8(baseE + ix * 1024);
+                } else A[pn] = ld8(baseM + ix * 1024);
             } else if (NEXT != 0) {
-                const int q = pn - NP;
-                A[pn] = ld8(nbase + q * 1024);
-                if (NEXT == 1) { X0[NE + q] = ldoh(oh.w0, q); X1[NE + q] = ldoh(oh.w1, q); }
+                const int cd = SN::code(pn - NP), ix = cd >> 1;
+                if (cd & 1) { X0[pn] = ld8(oh.a0[ix]); X1[pn] = ld8(oh.a1[ix]); A[pn] = ld8(nbase + ix * 1024); }
+                else A[pn] = ld8(nbase + (NC + ix) * 1024);
             }
-            if (E_P && M_P && p == NE) ebv = ld16(O_EBIAS + (uint32_t)(ke * 2 + hh) * 64u);
+            if (NEXT != 0 && p == NP - 1) pp.eb = ld16(O_EBIAS + (uint32_t)(ke_next * 2 + hh) * 64u);
             __builtin_amdgcn_sched_barrier(0);
+            const int cd = S::code(p), ix = cd >> 1;
+            const bool is_e = cd & 1;
             // ---- first MFMA of the pair
-            if (p < NE) mfma_v(e0, A[p], X0[p], p == 0);
+            if (is_e) mfma_v(e0, A[p], X0[p], ix == 0, eb);
             else {
-                const int q = p - NE, ht = q >> 1, m = q & 1;
-                acc0[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], B0[m], (FIRST && m == 0) ? zero16 : acc0[ht], 0, 0, 0);
+                const int ht = ix >> 1, m = ix & 1;
+                acc0[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], Bc0[m], (FIRST && m == 0) ? zero16 : acc0[ht], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- side work A: DMA
             if (STREAM) {
                 constexpr int SPREAD = NP * 5 / 8 > 0 ? NP * 5 / 8 : 1;          // all ops within the first 5/8 of the phase
-                while (op < NOPS && op * SPREAD / NOPS <= p) { stream_op(sg, s2, op); ++op; }
+#if defined(TW_EXP) && (TW_EXP == 2 || TW_EXP == 3)      // timing experiment: no weight streaming
+                op = NOPS;
+#endif
+                while (op < NOPS && op * SPREAD / NOPS <= p) { stream_op(g_stage, m0_slot, op); ++op; }
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- second MFMA of the pair
-            if (p < NE) mfma_v(e1, A[p], X1[p], p == 0);
+            if (is_e) mfma_v(e1, A[p], X1[p], ix == 0, eb);
             else {
-                const int q = p - NE, ht = q >> 1, m = q & 1;
-                acc1[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], B1[m], (FIRST && m == 0) ? zero16 : acc1[ht], 0, 0, 0);
+                const int ht = ix >> 1, m = ix & 1;
+                acc1[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], Bc1[m], (FIRST && m == 0) ? zero16 : acc1[ht], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- side work B: conversion of the embedding tile computed in this phase
-            if (E_P && M_P && p > NE) {
-                const int lim = (p - NE) * UPP < 16 ? (p - NE) * UPP : 16;
+#if defined(TW_EXP) && TW_EXP == 3      // timing experiment: no conversion in the shadow
+            if (false) {
+#else
+            if (E_P && M_P && p > LE + 1) {
+#endif
+                const int lim = (p - LE - 1) * UPP < 16 ? (p - LE - 1) * UPP : 16;
                 for (; udone < lim; ++udone) unit(udone);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (E_P) {
-            if (!M_P) {
-                ebv = ld16(O_EBIAS + (uint32_t)(ke * 2 + hh) * 64u);
-                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // XDL write -> VALU read of e0/e1 (asm MFMA: no automatic padding)
-            }
+            // XDL write -> VALU read of e0/e1 (asm MFMA: no automatic padding).  The accumulators are operands of
+            // the asm so that the conversions below cannot be scheduled in front of the wait states.
+            if (!M_P || MAFTER < 1) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(e0), "+v"(e1));
 #pragma unroll
             for (int u = 0; u < 16; ++u) if (u >= udone) unit(u);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) { B0[m] = Bn0[m]; B1[m] = Bn1[m]; }
         }
         if (NEXT != 0) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                pp.a[d] = A[NP + d];
-                if (NEXT == 1) { pp.x0[d] = X0[NE + d]; pp.x1[d] = X1[NE + d]; }
-            }
+            for (int d = 0; d < D; ++d) { pp.a[d] = A[NP + d]; pp.x0[d] = X0[NP + d]; pp.x1[d] = X1[NP + d]; }
         }
         if (STREAM) {
 #pragma unroll
-            for (; op < NOPS; ++op) stream_op(sg, s2, op);
+            for (; op < NOPS; ++op) stream_op(g_stage, m0_slot, op);
+            TW_STAMP(t_b);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage sg have landed
+            TW_STAMP(t_w);
             __syncthreads();
+            TW_STAMP(t_s);
+            TW_ACC(2, t_in, t_b); TW_ACC(3, t_b, t_w); TW_ACC(4, t_w, t_s);
         }
     }
 
@@ -283,32 +336,40 @@ struct Engine16 {
     __device__ __forceinline__ void forward(const OneHots &oh, f32x16 &out0, f32x16 &out1)
     {
         f32x16 acc0[NHT], acc1[NHT];
-        h16x8 B0[2], B1[2];
+        h16x8 Ba0[2], Ba1[2], Bb0[2], Bb1[2];                   // B fragments of the current / next embedding tile (ping-pong)
         Pipe pp;
         const uint32_t lo = (uint32_t)lane * 16u;
         auto slot_base = [&](int s) { return O_RING + (uint32_t)s * SBYTES + lo; };
         auto stage_of = [&](int kt) { int sg = kt + 2; if (sg >= n_kt) sg -= n_kt; if (sg >= n_kt) sg -= n_kt; return sg; };
+        auto tile_of  = [&](int kt) { return kt < n_kt ? kt : 0; };   // embedding tile computed in stage kt-1 (the last stage's is discarded)
         int s0 = rp;
-        // prologue: embedding tile 0 from the resident copy (its first D operand reads are exposed)
+        TW_STAMP(t_p0);
+        // prologue: embedding tile 0 from the resident copy (its bias and first D operand reads are exposed)
+        pp.eb = ld16(O_EBIAS + (uint32_t)hh * 64u);
 #pragma unroll
-        for (int d = 0; d < D; ++d) { pp.a[d] = ld8(O_T0 + lo + d * 1024); pp.x0[d] = ldoh(oh.w0, d); pp.x1[d] = ldoh(oh.w1, d); }
-        phase<true, false, false, 1, false>(0, O_T0 + lo, 0, slot_base(s0), 0, 0, oh, acc0, acc1, B0, B1, pp);
-        // every iteration: embedding MFMAs of tile kt+1, then common-layer MFMAs of tile kt.  (In the last
-        // iteration the embedding part runs on tile 0 again and is discarded: one uniform loop body keeps
-        // the register allocation of the 512-register kernel simple; 3 % of the MFMAs.)
-        {
+        for (int d = 0; d < D; ++d) { pp.x0[d] = ld8(oh.a0[d]); pp.x1[d] = ld8(oh.a1[d]); pp.a[d] = ld8(O_T0 + lo + d * 1024); }
+        phase<true, false, false, 1, false>(tile_of(1), O_T0 + lo, 0, slot_base(s0), 0, 0, oh, acc0, acc1, Ba0, Ba1, Ba0, Ba1, pp);
+        TW_STAMP(t_p1);
+        TW_ACC(1, t_p0, t_p1);
+        // every stage: embedding MFMAs of tile kt+1 interleaved with the common-layer MFMAs of tile kt.  (In the
+        // last stage the embedding part runs on tile 0 again and is discarded: one uniform loop body keeps the
+        // register allocation of the 512-register kernel simple; 3 % of the MFMAs.)  Two stages per loop trip:
+        // the B fragments ping-pong between (Ba) and (Bb) without copies.
+        auto stage = [&](auto first, int kt, const h16x8 (&c0)[2], const h16x8 (&c1)[2], h16x8 (&n0)[2], h16x8 (&n1)[2]) {
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
-            phase<true, true, true, 1, true>(n_kt > 1 ? 1 : 0, slot_base(s0), slot_base(s0) + NC * 1024, slot_base(s1), stage_of(0), s2,
-                                             oh, acc0, acc1, B0, B1, pp);
+            phase<true, true, decltype(first)::value, 1, true>(tile_of(kt + 2), slot_base(s0), slot_base(s0) + NC * 1024, slot_base(s1),
+                                                               stage_of(kt), s2, oh, acc0, acc1, c0, c1, n0, n1, pp);
             s0 = s1;
+        };
+        stage(std::true_type{}, 0, Ba0, Ba1, Bb0, Bb1);
+        int kt = 1;
+        for (; kt + 1 < n_kt; kt += 2) {
+            stage(std::false_type{}, kt, Bb0, Bb1, Ba0, Ba1);
+            stage(std::false_type{}, kt + 1, Ba0, Ba1, Bb0, Bb1);
         }
-        for (int kt = 1; kt < n_kt; ++kt) {
-            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
-            phase<true, true, false, 1, true>(kt + 1 < n_kt ? kt + 1 : 0, slot_base(s0), slot_base(s0) + NC * 1024, slot_base(s1),
-                                              stage_of(kt), s2, oh, acc0, acc1, B0, B1, pp);
-            s0 = s1;
-        }
+        if (kt < n_kt) stage(std::false_type{}, kt, Bb0, Bb1, Ba0, Ba1);
         rp = s0;
+        TW_STAMP(t_h0);
         // heads: h1 = relu(acc + b1) in f16 is the B operand, hidden index in accumulator-register order
         f32x16 h0, h1;
 #pragma unroll
@@ -321,12 +382,17 @@ struct Engine16 {
                 const h16x8 a = ld8(O_HEAD + (uint32_t)(ht * 2 + m) * 1024u + lo);
                 h16x8 b0, b1;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { cvt_unit(acc0[ht], cb, m, q, common_lim, b0); cvt_unit(acc1[ht], cb, m, q, common_lim, b1); }
+                for (int q = 0; q < 4; ++q) { cvt_unit<true>(acc0[ht], cb, m, q, common_lim, b0); cvt_unit<true>(acc1[ht], cb, m, q, common_lim, b1); }
                 h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, h0, 0, 0, 0);
                 h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, h1, 0, 0, 0);
             }
         }
         out0 = h0; out1 = h1;
+#ifdef TW_ABLATE
+        asm volatile("" :: "v"(h0), "v"(h1));
+#endif
+        TW_STAMP(t_h1);
+        TW_ACC(5, t_h0, t_h1);
     }
 };
 

@@ -8,7 +8,14 @@
 // cross-half shuffle each.
 #include "tw_engine16.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace tw {
+
+#ifdef TW_ABLATE
+__device__ unsigned long long g_stamps16[8];
+#endif
 
 template <int NHT, int NC>
 __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a)
@@ -44,7 +51,15 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
     const uint64_t rec_base = e_own * (uint64_t)a.out.t_pad;
 
     eng.begin2();
+#ifdef TW_ABLATE
+    for (int i = 0; i < 8; ++i) eng.st[i] = 0;
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
     while (__syncthreads_or((alive0 || alive1) ? 1 : 0)) {
+#ifdef TW_ABLATE
+        const unsigned long long t_top = __builtin_readcyclecounter();
+        eng.st[7] += t_top - t_prev;
+#endif
         // ---- twist draw for the own tile (policy.rs:67-77), exchanged with the other half --------
         int perm_own = -1;
         if (eng.pol.n_perms > 0) {
@@ -54,11 +69,19 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
         const int perm_oth = __shfl_xor(perm_own, 32, 64);
         const int perm0 = hh ? perm_oth : perm_own, perm1 = hh ? perm_own : perm_oth;
         typename Eng::OneHots oh;
-        eng.onehots(st0.board, perm0, oh.w0);
-        eng.onehots(st1.board, perm1, oh.w1);
+        eng.onehots(st0.board, perm0, oh.a0);
+        eng.onehots(st1.board, perm1, oh.a1);
 
+#ifdef TW_ABLATE
+        asm volatile("" :: "v"(oh.a0[0]), "v"(oh.a1[0]));
+        const unsigned long long t_fw = __builtin_readcyclecounter();
+        eng.st[0] += t_fw - t_top;
+#endif
         f32x16 out0, out1;
         eng.forward(oh, out0, out1);
+#ifdef TW_ABLATE
+        const unsigned long long t_po = __builtin_readcyclecounter();
+#endif
 
         // ---- own tile: head bias, act-perm, mask, reward, Gumbel-max (policy.rs:56-65,169-172) ---
         const float *bh = reinterpret_cast<const float *>(lds16 + Eng::O_BH);
@@ -94,7 +117,14 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
             else puzzle_step(st1, env, act1);
         }
         ++t;
+#ifdef TW_ABLATE
+        t_prev = __builtin_readcyclecounter();
+        eng.st[6] += t_prev - t_po;
+#endif
     }
+#ifdef TW_ABLATE
+    if (eng.lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps16[i], eng.st[i]);
+#endif
     if (v_own) a.out.ep_len[e_own] = len_own;
     eng.end();
 }
@@ -113,8 +143,22 @@ static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint3
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
+#ifdef TW_ABLATE
+    static const unsigned long long zeros[8] = {};
+    if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps16), zeros, sizeof(zeros)));
+#endif
     hipLaunchKernelGGL((rollout_f16_kernel<NHT, NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
+#ifdef TW_ABLATE
+    if (getenv("TW_STAMPS")) {
+        unsigned long long h[8];
+        TW_HIP(hipStreamSynchronize(s));
+        TW_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps16), sizeof(h)));
+        const double nw = (double)nb * 4.0;
+        fprintf(stderr, "[stamps16] per wave (cycles x100MHz ticks): pre %.0f prologue %.0f stage-body %.0f vmcnt %.0f stage-barrier %.0f heads %.0f post %.0f step-barrier %.0f\n",
+                h[0] / nw, h[1] / nw, h[2] / nw, h[3] / nw, h[4] / nw, h[5] / nw, h[6] / nw, h[7] / nw);
+    }
+#endif
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = Eng::THREADS;
     return TW_OK;
