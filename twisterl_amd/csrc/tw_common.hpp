@@ -79,12 +79,13 @@ __host__ __device__ inline float u32_to_unit(uint32_t word)
 // Domain: positive normal floats, +0 -> -inf, +inf -> +inf.
 __host__ __device__ inline float tw_logf(float x)
 {
-    if (x == 0.0f) return -__builtin_inff();
-    if (x > 3.4028234e38f) return __builtin_inff();
+    // branch-free (selects only): the kernels call this eight times per record from a single wave per SIMD
     uint32_t ix = __builtin_bit_cast(uint32_t, x);
     int e = (int)(ix >> 23) - 127;
     float m = __builtin_bit_cast(float, (ix & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }
+    const bool big = m > 1.41421354f;
+    m = big ? m * 0.5f : m;
+    e = big ? e + 1 : e;
     const float f = m - 1.0f;
     const float z = f * f;
     float p = 7.0376836292e-2f;
@@ -102,6 +103,8 @@ __host__ __device__ inline float tw_logf(float x)
     y = __builtin_fmaf(-0.5f, z, y);
     float r = f + y;
     r = __builtin_fmaf(fe, 0.693359375f, r);
+    r = x > 3.4028234e38f ? __builtin_inff() : r;
+    r = x == 0.0f ? -__builtin_inff() : r;
     return r;
 }
 
@@ -204,17 +207,15 @@ __host__ __device__ inline uint32_t nib(uint64_t b, int i) { return (uint32_t)(b
 // saturating_sub(1) always.
 __host__ __device__ inline void puzzle_step(PuzzleLane &s, const PuzzleConsts &c, int action)
 {
-    int nx = s.zx, ny = s.zy; bool ok = false;
-    if (action == 0)      { ok = s.zx > 0;            nx = s.zx - 1; }
-    else if (action == 1) { ok = s.zy > 0;            ny = s.zy - 1; }
-    else if (action == 2) { ok = s.zx < c.width - 1;  nx = s.zx + 1; }
-    else if (action == 3) { ok = s.zy < c.height - 1; ny = s.zy + 1; }
-    if (ok) {
-        const int zi = s.zy * c.width + s.zx, ti = ny * c.width + nx;
-        const uint64_t tile = (s.board >> (4 * ti)) & 15ull;
-        s.board = (s.board & ~(15ull << (4 * ti))) | (tile << (4 * zi));   // cell zi held 0
-        s.zx = nx; s.zy = ny;
-    }
+    // branch-free: an illegal (or unknown) action moves the blank onto itself, which leaves the board as it is
+    const int dx = (action == 2 ? 1 : 0) - (action == 0 ? 1 : 0), dy = (action == 3 ? 1 : 0) - (action == 1 ? 1 : 0);
+    int nx = s.zx + dx, ny = s.zy + dy;
+    const bool ok = (unsigned)nx < (unsigned)c.width && (unsigned)ny < (unsigned)c.height;
+    nx = ok ? nx : s.zx; ny = ok ? ny : s.zy;
+    const int zi = s.zy * c.width + s.zx, ti = ny * c.width + nx;
+    const uint64_t tile = (s.board >> (4 * ti)) & 15ull;                   // cell zi holds 0
+    s.board = (s.board & ~(15ull << (4 * ti))) | (tile << (4 * zi));
+    s.zx = nx; s.zy = ny;
     s.depth = s.depth > 0 ? s.depth - 1 : 0;
 }
 
@@ -300,6 +301,28 @@ __device__ inline void store_rec(PaddedRec *dst, const uint32_t (&obs4)[4], cons
                       __builtin_bit_cast(uint32_t, lg[2]), __builtin_bit_cast(uint32_t, lg[3]));
     d[2] = make_uint4(__builtin_bit_cast(uint32_t, value), __builtin_bit_cast(uint32_t, reward),
                       (uint32_t)(action & 0xff) | ((uint32_t)(perm & 0xff) << 8), 0u);
+}
+
+// four nibbles (16 bits) -> four bytes
+__host__ __device__ inline uint32_t spread_nibbles4(uint32_t t16)
+{
+    const uint32_t x = (t16 | (t16 << 8)) & 0x00FF00FFu;
+    return (x | (x << 4)) & 0x0F0F0F0Fu;
+}
+// obs ids of a board as 16 bytes: byte i = i*n_cells + tile(i) for i < n_cells, else 0 (puzzle.rs:183-185).
+// base[q] holds the four constants i*n_cells of word q (obs_base_words()).
+__host__ __device__ inline void obs_bytes(uint64_t board, const uint32_t (&base)[4], uint32_t (&pk)[4])
+{
+    const uint32_t lo = (uint32_t)board, hi = (uint32_t)(board >> 32);
+    pk[0] = spread_nibbles4(lo & 0xFFFFu) + base[0]; pk[1] = spread_nibbles4(lo >> 16) + base[1];
+    pk[2] = spread_nibbles4(hi & 0xFFFFu) + base[2]; pk[3] = spread_nibbles4(hi >> 16) + base[3];
+}
+__host__ __device__ inline void obs_base_words(int n_cells, uint32_t (&base)[4])
+{
+    for (int q = 0; q < 4; ++q) {
+        base[q] = 0u;
+        for (int b = 0; b < 4; ++b) { const int i = 4 * q + b; if (i < n_cells) base[q] |= (uint32_t)(i * n_cells) << (8 * b); }
+    }
 }
 
 // compact output

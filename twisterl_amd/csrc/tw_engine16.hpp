@@ -45,7 +45,7 @@ constexpr int E16_MAX_KT = 32;     // embedding size <= 1024
 template <int NHT, int NC>
 __host__ __device__ constexpr size_t engine16_lds_bytes()
 {
-    return 160 + (size_t)(E16_MAXP + 1) * (16 + 256) + 32 + 64 + (size_t)NHT * 128 + (size_t)E16_MAX_KT * 128 +
+    return 160 + (size_t)(E16_MAXP + 1) * (16 + 256) + 32 + (size_t)2 * (E16_MAXP + 1) * 256 + 64 + (size_t)NHT * 128 + (size_t)E16_MAX_KT * 128 +
            (size_t)NHT * 2048 + (size_t)NC * 1024 + (size_t)3 * ((NC + 2 * NHT + 3) / 4) * 4096;
 }
 
@@ -57,7 +57,7 @@ struct Engine16 {
     static constexpr int SBYTES = NOPS * NW * 1024;          // stage image / ring slot, padded to whole rounds of NW pieces
     // LDS map (small tables first: their offsets fit the 16-bit ds offset field)
     static constexpr uint32_t O_OH = 0, O_SRC = 160, O_VMAP = O_SRC + (E16_MAXP + 1) * 16, O_ACT = O_VMAP + (E16_MAXP + 1) * 256,
-                              O_BH = O_ACT + 32, O_B1 = O_BH + 64, O_EBIAS = O_B1 + NHT * 128, O_HEAD = O_EBIAS + E16_MAX_KT * 128,
+                              O_OHB = O_ACT + 32, O_BH = O_OHB + 2 * (E16_MAXP + 1) * 256, O_B1 = O_BH + 64, O_EBIAS = O_B1 + NHT * 128, O_HEAD = O_EBIAS + E16_MAX_KT * 128,
                               O_T0 = O_HEAD + NHT * 2048, O_RING = O_T0 + NC * 1024;
     static_assert(O_RING + 3 * SBYTES == engine16_lds_bytes<NHT, NC>(), "LDS map");
 
@@ -118,6 +118,12 @@ struct Engine16 {
         const int np1 = pol.n_perms + 1;
         for (int i = tid; i < np1 * 16; i += THREADS) lds[O_SRC + i] = pol.srcmap16[i];
         for (int i = tid; i < np1 * 256; i += THREADS) lds[O_VMAP + i] = pol.vmap16[i];
+        // one-hot fragment address of (lane half, twist, chunk, tile value): 16 * min(value' ^ 8h, 8), value' = twisted value
+        for (int i = tid; i < 2 * np1 * 256; i += THREADS) {
+            const int h2 = i / (np1 * 256), r = i - h2 * (np1 * 256);
+            const uint32_t pos = (uint32_t)pol.vmap16[r] ^ ((uint32_t)h2 << 3);
+            lds[O_OHB + h2 * ((E16_MAXP + 1) * 256) + r] = (uint8_t)((pos < 8u ? pos : 8u) * 16u);
+        }
         if (tid < 4) lds[O_ACT + tid] = (uint8_t)tid;
         for (int i = tid; i < pol.n_perms * 4; i += THREADS) lds[O_ACT + 4 + i] = pol.act_perms[i];
         for (int i = tid; i < n_kt * 32; i += THREADS) reinterpret_cast<float *>(lds + O_EBIAS)[i] = pol.ebias16[i];
@@ -130,27 +136,32 @@ struct Engine16 {
     __device__ __forceinline__ void end() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
     // LDS addresses of the one-hot B fragments of one episode under twist perm (-1 = none): 2*NC registers per
-    // lane, computed once per timestep, so that a fragment read in the MFMA loop is ONE instruction
+    // lane, computed once per timestep, so that a fragment read in the MFMA loop is ONE instruction.  Per chunk:
+    // source cell (one 16-byte row read per twist), its tile, then one byte lookup that yields the address.
     __device__ __forceinline__ void onehots(uint64_t board, int perm, uint32_t (&w)[NC]) const
     {
+        static_assert(O_OH == 0, "the byte table holds LDS addresses");
         const int pi = perm + 1;
+        typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+        const u32v4 sr = *(const __attribute__((address_space(3))) u32v4 *)(L + O_SRC + pi * 16);
+        const uint32_t srw[4] = {sr[0], sr[1], sr[2], sr[3]};
+        const uint32_t tb = O_OHB + (uint32_t)(hh * (E16_MAXP + 1) + pi) * 256u;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const uint32_t src = L[O_SRC + pi * 16 + c];
+            const uint32_t src = (srw[c >> 2] >> (8 * (c & 3))) & 0xffu;
             const uint32_t v   = nib(board, (int)src);
-            const uint32_t v2  = L[O_VMAP + (pi * 16 + c) * 16 + v];
-            const uint32_t pos = v2 ^ ((uint32_t)hh << 3);
-            w[c] = O_OH + (pos < 8u ? pos : 8u) * 16u;
+            w[c] = L[tb + c * 16 + v];
         }
     }
 
     __device__ __forceinline__ void act_perm(int perm, float (&lg)[4]) const
     {
-        if (perm < 0) return;
+        typedef __attribute__((address_space(3))) const uint32_t lu1;
+        const uint32_t ap = *(const lu1 *)(L + O_ACT + (perm + 1) * 4);      // perm -1: identity row
         const float l0 = lg[0], l1 = lg[1], l2 = lg[2], l3 = lg[3];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int src = L[O_ACT + (perm + 1) * 4 + i];
+            const uint32_t src = (ap >> (8 * i)) & 0xffu;
             lg[i] = src == 0 ? l0 : (src == 1 ? l1 : (src == 2 ? l2 : l3));
         }
     }

@@ -50,6 +50,12 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
     uint32_t len_own = 0;
     const uint64_t rec_base = e_own * (uint64_t)a.out.t_pad;
 
+    uint32_t obs_base[4];
+    obs_base_words(env.n_cells, obs_base);
+    float bh[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) bh[i] = a.pol.bh16[i];          // uniform: scalar loads, live in SGPRs
+
     eng.begin2();
 #ifdef TW_ABLATE
     for (int i = 0; i < 8; ++i) eng.st[i] = 0;
@@ -84,12 +90,14 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
 #endif
 
         // ---- own tile: head bias, act-perm, mask, reward, Gumbel-max (policy.rs:56-65,169-172) ---
-        const float *bh = reinterpret_cast<const float *>(lds16 + Eng::O_BH);
+        // (everything below is select-based: one wave per SIMD has nothing to hide a branch behind)
         float lg[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) lg[i] = (hh ? out1[i] : out0[i]) + bh[i];
         const float value = (hh ? out1[4] : out0[4]) + bh[4];
-        const PuzzleLane &mine = hh ? st1 : st0;
+        PuzzleLane mine;
+        mine.board = hh ? st1.board : st0.board; mine.zx = hh ? st1.zx : st0.zx; mine.zy = hh ? st1.zy : st0.zy;
+        mine.depth = hh ? st1.depth : st0.depth;
         eng.act_perm(perm_own, lg);
         const uint32_t mb = puzzle_maskbits(mine, env);
 #pragma unroll
@@ -99,22 +107,23 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
         const int act_own = gumbel_argmax4(lg, gw);
         const bool alive_own = hh ? alive1 : alive0;
         if (alive_own) {
-            uint32_t pk[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                if (i < env.n_cells) pk[i >> 2] |= (uint32_t)(i * env.n_cells + (int)nib(mine.board, i)) << (8 * (i & 3));
+            uint32_t pk[4];
+            obs_bytes(mine.board, obs_base, pk);
             store_rec(a.out.rec + rec_base + (uint64_t)t, pk, lg, value, rew, act_own, perm_own);
         }
         const int act_oth = __shfl_xor(act_own, 32, 64);
         const int act0 = hh ? act_oth : act_own, act1 = hh ? act_own : act_oth;
         // ---- is_final / step for both tiles (ppo.rs:78-79) ----------------------------------------
-        if (alive0) {
-            if (puzzle_final(st0, env)) { alive0 = false; if (!hh) len_own = (uint32_t)t + 1u; }
-            else puzzle_step(st0, env, act0);
-        }
-        if (alive1) {
-            if (puzzle_final(st1, env)) { alive1 = false; if (hh) len_own = (uint32_t)t + 1u; }
-            else puzzle_step(st1, env, act1);
+        {
+            const bool fin0 = puzzle_final(st0, env), fin1 = puzzle_final(st1, env);
+            PuzzleLane n0 = st0, n1 = st1;
+            puzzle_step(n0, env, act0); puzzle_step(n1, env, act1);
+            const bool go0 = alive0 && !fin0, go1 = alive1 && !fin1;
+            st0.board = go0 ? n0.board : st0.board; st0.zx = go0 ? n0.zx : st0.zx; st0.zy = go0 ? n0.zy : st0.zy; st0.depth = go0 ? n0.depth : st0.depth;
+            st1.board = go1 ? n1.board : st1.board; st1.zx = go1 ? n1.zx : st1.zx; st1.zy = go1 ? n1.zy : st1.zy; st1.depth = go1 ? n1.depth : st1.depth;
+            const bool died_own = hh ? (alive1 && fin1) : (alive0 && fin0);
+            len_own = died_own ? (uint32_t)t + 1u : len_own;
+            alive0 = go0; alive1 = go1;
         }
         ++t;
 #ifdef TW_ABLATE
