@@ -74,6 +74,11 @@ struct Engine16 {
 #define TW_STAMP(var)
 #define TW_ACC(i, a, b)
 #endif
+#if defined(TW_ABLATE) && defined(TW_EXP)
+#define TW_EXP_IS(n) (TW_EXP == (n))     // numbered timing experiments of the diagnostic build (wrong results)
+#else
+#define TW_EXP_IS(n) false
+#endif
     uint8_t *lg_;                  // LDS base, generic
     uint32_t lds_u32, voff;        // LDS base as an M0 value; per-lane global byte offset of this wave's DMA piece
     lds_cu8 *L;                    // LDS base, address space 3
@@ -245,6 +250,7 @@ struct Engine16 {
         TW_STAMP(t_in);
         using S = Sched<E_P, M_P>;
         using SN = Sched<true, true>;
+        static_assert(!(FIRST && M_P) || ((S::code(0) & 1) && (S::code(1) & 1)), "FIRST: b1 is fetched two positions ahead");
         constexpr int NP = S::NP, LE = S::last_e();
         constexpr int MAFTER = NP - 1 - LE;                                     // common-layer pairs behind the last embedding pair
         constexpr int UPP = !M_P ? 16 : (MAFTER > 1 ? (16 + MAFTER - 2) / (MAFTER - 1) : 16);
@@ -258,6 +264,7 @@ struct Engine16 {
 #pragma unroll
         for (int g = 0; g < 16; ++g) zero16[g] = 0.0f;
         f32x16 e0, e1;
+        f32x16 cbv[2];                                                           // FIRST: b1 of hidden tile ht (parity ht&1) as the C operand
         auto unit = [&](int u) {      // u in [0,16): tile u>>3, fragment (u>>2)&1, register u&3
             if ((u >> 3) == 0) cvt_unit<false>(e0, zero16, (u >> 2) & 1, u & 3, emb_lim, Bn0[(u >> 2) & 1]);
             else               cvt_unit<false>(e1, zero16, (u >> 2) & 1, u & 3, emb_lim, Bn1[(u >> 2) & 1]);
@@ -283,6 +290,10 @@ struct Engine16 {
                 else A[pn] = ld8(nbase + (NC + ix) * 1024);
             }
             if (NEXT != 0 && p == NP - 1) pp.eb = ld16(O_EBIAS + (uint32_t)(ke_next * 2 + hh) * 64u);
+            if (FIRST && p + 2 < NP) {                                          // b1 of the hidden tile whose first pair is two positions ahead
+                const int c2 = S::code(p + 2);
+                if (!(c2 & 1) && ((c2 >> 1) & 1) == 0) cbv[((c2 >> 1) >> 1) & 1] = ld16(O_B1 + (uint32_t)(((c2 >> 1) >> 1) * 2 + hh) * 64u);
+            }
             __builtin_amdgcn_sched_barrier(0);
             const int cd = S::code(p), ix = cd >> 1;
             const bool is_e = cd & 1;
@@ -290,7 +301,7 @@ struct Engine16 {
             if (is_e) mfma_v(e0, A[p], X0[p], ix == 0, eb);
             else {
                 const int ht = ix >> 1, m = ix & 1;
-                acc0[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], Bc0[m], (FIRST && m == 0) ? zero16 : acc0[ht], 0, 0, 0);
+                acc0[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], Bc0[m], (FIRST && m == 0) ? cbv[ht & 1] : acc0[ht], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- side work A: DMA
@@ -306,7 +317,7 @@ struct Engine16 {
             if (is_e) mfma_v(e1, A[p], X1[p], ix == 0, eb);
             else {
                 const int ht = ix >> 1, m = ix & 1;
-                acc1[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], Bc1[m], (FIRST && m == 0) ? zero16 : acc1[ht], 0, 0, 0);
+                acc1[ht] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[p], Bc1[m], (FIRST && m == 0) ? cbv[ht & 1] : acc1[ht], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- side work B: conversion of the embedding tile computed in this phase
@@ -381,19 +392,19 @@ struct Engine16 {
         if (kt < n_kt) stage(std::false_type{}, kt, Bb0, Bb1, Ba0, Ba1);
         rp = s0;
         TW_STAMP(t_h0);
-        // heads: h1 = relu(acc + b1) in f16 is the B operand, hidden index in accumulator-register order
+        // heads: h1 = relu(acc) in f16 is the B operand (b1 went in as the C operand of the first stage), hidden
+        // index in accumulator-register order
         f32x16 h0, h1;
 #pragma unroll
         for (int g = 0; g < 16; ++g) { h0[g] = 0.0f; h1[g] = 0.0f; }
 #pragma unroll
         for (int ht = 0; ht < NHT; ++ht) {
-            const f32x16 cb = ld16(O_B1 + (uint32_t)(ht * 2 + hh) * 64u);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const h16x8 a = ld8(O_HEAD + (uint32_t)(ht * 2 + m) * 1024u + lo);
                 h16x8 b0, b1;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { cvt_unit<true>(acc0[ht], cb, m, q, common_lim, b0); cvt_unit<true>(acc1[ht], cb, m, q, common_lim, b1); }
+                for (int q = 0; q < 4; ++q) { cvt_unit<false>(acc0[ht], h0, m, q, common_lim, b0); cvt_unit<false>(acc1[ht], h0, m, q, common_lim, b1); }
                 h0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, h0, 0, 0, 0);
                 h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, h1, 0, 0, 0);
             }
