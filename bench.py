@@ -33,13 +33,13 @@ BYTES_PER_RECORD = {16: 58, 9: 51}
 PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0}     # MI355X_MICROARCH.md: f32 MFMA (=vector) / dense f16 MFMA
 
 
-def measured_traffic_per_record():
+def measured_traffic_per_record(kernel="rollout_f32"):
     """HBM bytes per record of the rollout kernel from the committed rocprofv3 PMC passes
     (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
         for k, v in d.items():
-            if "rollout" in k:
+            if kernel in k:
                 return float(v["bytes_per_record"])
     except Exception:
         pass
@@ -182,7 +182,7 @@ def main():
     if rank == 0:
         kern_s = float(np.mean(ms_rollout)) * 1e-3
         rec_per_launch = records / args.steps
-        tpr = measured_traffic_per_record() if (args.puzzle == 15 and args.precision == "fp32") else None
+        tpr = measured_traffic_per_record("rollout_f32" if args.precision == "fp32" else "rollout_f16") if args.puzzle == 15 else None
         achieved = rec_per_launch * FLOP_PER_RECORD[n2] / kern_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
         out = {
