@@ -179,7 +179,7 @@ typedef struct {
 typedef struct {
     uint32_t deterministic;       /* argmax (1) or weighted sample (0) of the action probs          */
     uint32_t num_searches;        /* best-of-N attempts per episode                                  */
-    uint32_t num_mcts_searches;   /* 0: Policy::predict.  > 0 (MCTS-guided) is not built: UNSUPPORTED */
+    uint32_t num_mcts_searches;   /* 0: Policy::predict.  > 0: predict_probs_mcts per move (solve.rs:41-47), run on the MCTS kernel */
     float    C;
     uint32_t max_expand_depth;
     uint64_t seed;                /* the reference accepts and ignores `seed` (evaluate.rs:29)       */

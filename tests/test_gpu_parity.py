@@ -295,8 +295,29 @@ def test_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, hidden, twist
         (os_, or_), oact = oracle.solve(oenv, op, det, ns, seed=5, arith=oracle.ARITH_CHAIN, det_math=True)
         assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact
     assert genv.get_state() == before                        # the env passed in is not mutated (solve.rs:85)
-    with pytest.raises(RuntimeError, match="not built"):
-        tw.collector.evaluate(genv, gp, 4, True, 1, 10, 0, 1.41, 1, 1)
+
+
+@pytest.mark.parametrize("w,diff,emb,hidden,twists,S,med", [(3, 3, 32, 32, False, 12, 1), (3, 4, 64, 64, True, 8, 2), (4, 3, 512, 256, True, 6, 1)])
+def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, hidden, twists, S, med):
+    """num_mcts_searches > 0 (solve.rs:41-47): the action distribution comes from predict_probs_mcts; same numbers and the
+    same action list as the oracle, bit for bit (deterministic exp in the spec)."""
+    n2 = w * w
+    gp, op = _pair(oracle, n2, 6, emb, hidden, twists=twists, scale=3.0)
+    genv, oenv = tw.env.Puzzle(w, w, diff, 2, 256), oracle.Puzzle(w, w, diff, 2, 256)
+    for det, ns in ((True, 1), (False, 3)):
+        g = tw.collector.evaluate(genv, gp, num_episodes=40, deterministic=det, num_searches=ns, num_mcts_searches=S,
+                                  seed=3, C=1.41, max_expand_depth=med, num_cores=32)
+        o = oracle.evaluate(oenv, op, 40, det, ns, num_mcts_searches=S, seed=3, Cc=1.41, max_expand_depth=med,
+                            arith=oracle.ARITH_CHAIN, det_math=True)
+        assert f32_bits(g[0]) == f32_bits(o[0]) and f32_bits(g[1]) == f32_bits(o[1]), (det, ns, g, o)
+    start = oracle.Puzzle(w, w, diff, 2, 256); start.reset(seed=2, episode=1)
+    state = start.get_state()
+    genv.set_state(state); oenv.set_state(state)
+    for det, ns in ((True, 1), (False, 4)):
+        (gs, gr), gact = tw.collector.solve(genv, gp, det, ns, S, 1.41, med, seed=5)
+        (os_, or_), oact = oracle.solve(oenv, op, det, ns, num_mcts_searches=S, Cc=1.41, max_expand_depth=med, seed=5,
+                                        arith=oracle.ARITH_CHAIN, det_math=True)
+        assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact
 
 
 # ------------------------------------------------------------------------------ full-size properties

@@ -778,10 +778,6 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
               uint64_t episode_offset, bool from_state, const tw_puzzle *start, int max_steps, bool want_actions,
               std::vector<float> &best_s, std::vector<float> &best_r, std::vector<uint8_t> &best_actions)
 {
-    if (prm->num_mcts_searches != 0) {
-        set_error("solve/evaluate with num_mcts_searches > 0 (MCTS-guided inference) is not built on the HIP path yet");
-        return TW_ERR_UNSUPPORTED;
-    }
     if (prm->num_searches == 0) { best_s.assign(n_episodes, 0.0f); best_r.assign(n_episodes, -__builtin_inff()); return TW_OK; }
     if (prm->precision != TW_PREC_F32_EXACT) { set_error("solve: precision %u not implemented", prm->precision); return TW_ERR_UNSUPPORTED; }
     SolveArgs sa{};
@@ -809,11 +805,34 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     const size_t o_s = seg(A * 4), o_r = seg(A * 4), o_n = seg(A * 4), o_a = seg(want_actions ? A * (size_t)sa.t_pad : 0);
+    // MCTS-guided inference (solve.rs:41-47): per-attempt node arenas for the search trees
+    const bool mcts = prm->num_mcts_searches != 0;
+    const uint64_t node_cap = 5ull + 4ull * prm->num_mcts_searches * (prm->max_expand_depth ? prm->max_expand_depth : 1u);
+    if (mcts && (node_cap > 0xffffffffull || A * node_cap * mcts_node_bytes() > (200ull << 30))) {
+        set_error("solve: MCTS arenas of %llu attempts x %llu nodes do not fit", (unsigned long long)A, (unsigned long long)node_cap);
+        return TW_ERR_UNSUPPORTED;
+    }
+    const size_t o_cnt = seg(mcts ? 8 : 0), o_arena = seg(mcts ? (size_t)(A * node_cap) * mcts_node_bytes() : 0);
     uint8_t *buf = nullptr;
     TW_HIP(hipMalloc((void **)&buf, cur ? cur : 256));
     sa.success = reinterpret_cast<float *>(buf + o_s); sa.total = reinterpret_cast<float *>(buf + o_r);
     sa.n_steps = reinterpret_cast<uint32_t *>(buf + o_n); sa.actions = want_actions ? buf + o_a : nullptr;
-    int rc = launch_solve_f32(sa, s);
+    int rc;
+    if (mcts) {
+        MctsArgs ma{};
+        ma.env = envc; ma.pol = sa.pol; ma.num_episodes = A; ma.episode_offset = episode_offset; ma.seed = prm->seed;
+        ma.num_searches = prm->num_mcts_searches; ma.max_expand_depth = prm->max_expand_depth; ma.C = prm->C;
+        ma.arena = reinterpret_cast<MctsNode *>(buf + o_arena); ma.node_cap = (uint32_t)node_cap;
+        ma.eval_count = reinterpret_cast<unsigned long long *>(buf + o_cnt);
+        ma.solve.on = 1; ma.solve.deterministic = sa.deterministic; ma.solve.num_searches = sa.num_searches;
+        ma.solve.from_state = sa.from_state; ma.solve.start_board = sa.start_board; ma.solve.start_zx = sa.start_zx;
+        ma.solve.start_zy = sa.start_zy; ma.solve.start_depth = sa.start_depth;
+        ma.solve.success = sa.success; ma.solve.total = sa.total; ma.solve.n_steps = sa.n_steps; ma.solve.actions = sa.actions;
+        ma.solve.act_pad = sa.t_pad;
+        hipError_t me = hipMemsetAsync(buf + o_cnt, 0, 8, s);
+        if (me != hipSuccess) { (void)hipFree(buf); return hip_fail(me, "hipMemsetAsync(eval counter)", __FILE__, __LINE__); }
+        rc = launch_mcts_f32(ma, s, nullptr, nullptr);
+    } else rc = launch_solve_f32(sa, s);
     std::vector<float> hs(A), hr(A); std::vector<uint32_t> hn(A);
     hipError_t e = hipSuccess;
     if (rc == TW_OK) {

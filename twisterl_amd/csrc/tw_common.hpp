@@ -367,6 +367,15 @@ struct SolveArgs {
 int launch_solve_f32(const SolveArgs &a, hipStream_t s);
 
 struct MctsNode;   // tw_mcts.hip
+// MCTS-guided inference (solve.rs:41-47): the MCTS kernel runs single_solve instead of AZ self-play when on != 0
+struct MctsSolve {
+    uint32_t on, deterministic, num_searches /* attempts per episode */, from_state;
+    uint64_t start_board; int32_t start_zx, start_zy, start_depth;
+    float   *success, *total;      // [attempts]
+    uint32_t *n_steps;             // [attempts]
+    uint8_t *actions;              // [attempts][act_pad] or null
+    int32_t  act_pad;
+};
 struct MctsArgs {
     PuzzleConsts env;
     PolicyDev    pol;
@@ -377,6 +386,7 @@ struct MctsArgs {
     MctsNode    *arena;        // [num_episodes][node_cap]
     uint32_t     node_cap;
     unsigned long long *eval_count;   // number of policy evaluations (leaf + root), for the stats
+    MctsSolve    solve;        // on == 0: AlphaZero self-play (records into `out`)
 };
 size_t mcts_node_bytes();
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);

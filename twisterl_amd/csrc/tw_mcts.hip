@@ -61,7 +61,10 @@ __global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
     const int j = eng.j, h = eng.h;
     const uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);
     const bool     valid    = e_local < a.num_episodes;
-    const uint64_t e_global = a.episode_offset + e_local;
+    const MctsSolve sv      = a.solve;
+    // solve mode: lane pair = ATTEMPT (episode, search); its draws are keyed like single_solve's (tw_solve.hip)
+    const uint64_t sv_ep    = sv.on ? a.episode_offset + e_local / sv.num_searches : 0;
+    const uint64_t e_global = sv.on ? sv_ep * (uint64_t)sv.num_searches + e_local % sv.num_searches : a.episode_offset + e_local;
     const bool     owner    = valid && h == 0;            // the lane that walks / mutates the tree
     MctsNode *nodes = a.arena + (valid ? e_local : 0) * (uint64_t)a.node_cap;
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
@@ -69,10 +72,16 @@ __global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
 
     PuzzleLane st;                                        // the episode's env (az.rs:56-57)
     st.board = env.ident; st.zx = 0; st.zy = 0; st.depth = 0;
-    if (valid) puzzle_reset(st, env, a.seed, e_global);
+    if (valid) {
+        if (!sv.on) puzzle_reset(st, env, a.seed, e_global);
+        else if (sv.from_state) { st.board = sv.start_board; st.zx = sv.start_zx; st.zy = sv.start_zy; st.depth = sv.start_depth; }
+        else puzzle_reset(st, env, a.seed, sv_ep);
+    }
+    float total = 0.0f;                                   // solve mode: summed rewards (solve.rs:25-34)
 
     // per-episode search state (meaningful on the owner lane; phase/leaf are mirrored to the partner)
     int      phase = valid ? PH_ROOT : PH_DONE;
+    if (sv.on && valid && puzzle_final(st, env)) phase = PH_DONE;      // `while !env.is_final()` (solve.rs:30)
     uint32_t it = 0, expanded = 0, node = 0, n_nodes = 0;
     int      t = 0;
     uint32_t len = 0;
@@ -184,6 +193,25 @@ __global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
 #pragma unroll
                             for (int i = 0; i < 4; ++i) mp[i] = 1.0f / 4.0f;
                         }
+                        if (sv.on) {
+                            // solve.rs:31-58: total += reward; action = argmax | sample of the MCTS probs; step
+                            total = total + puzzle_reward(st, env);
+                            int action = 0;
+                            if (sv.deterministic) {
+                                float bv = mp[0];
+#pragma unroll
+                                for (int i = 1; i < 4; ++i) if (mp[i] > bv) { bv = mp[i]; action = i; }
+                            } else {
+                                const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_SOLVE);
+                                action = sample_weighted(mp, 4, u32_to_unit(w.x));
+                            }
+                            if (sv.actions) sv.actions[e_local * (uint64_t)sv.act_pad + (uint64_t)t] = (uint8_t)action;
+                            puzzle_step(st, env, action);
+                            ++t;
+                            if (puzzle_final(st, env)) { phase = PH_DONE; break; }
+                            phase = PH_ROOT; leaf = st;
+                            break;
+                        }
                         // az.rs:72-81: action = sample(mcts_probs); val = env.reward(); store record
                         const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
                         const int action = sample_weighted(mp, 4, u32_to_unit(w.x));
@@ -240,7 +268,12 @@ __global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
         leaf.depth = __shfl(leaf.depth, j, 64);
     }
     if (owner) {
-        a.out.ep_len[e_local] = len;
+        if (sv.on) {
+            total = total + puzzle_reward(st, env);                       // solve.rs:65-66
+            sv.success[e_local] = puzzle_solved(st, env) ? 1.0f : 0.0f;   // solve.rs:68
+            sv.total[e_local]   = total;
+            sv.n_steps[e_local] = (uint32_t)t;
+        } else a.out.ep_len[e_local] = len;
         atomicAdd(a.eval_count, evals);
     }
     eng.end();
@@ -282,7 +315,8 @@ int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t
     const uint64_t need = 5ull + 4ull * a.num_searches * (a.max_expand_depth ? a.max_expand_depth : 1u);
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||
         a.pol.obs_size > 256 || a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 ||
-        a.out.t_pad < a.env.depth0 + 1 || a.node_cap < need || !a.arena || !a.eval_count) {
+        (!a.solve.on && a.out.t_pad < a.env.depth0 + 1) || a.node_cap < need || !a.arena || !a.eval_count ||
+        (a.solve.on && (!a.solve.success || !a.solve.total || !a.solve.n_steps || a.solve.num_searches == 0))) {
         set_error("mcts: unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d node_cap=%u need=%llu)",
                   a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad, a.node_cap,
                   (unsigned long long)need);
