@@ -241,6 +241,21 @@ typedef struct {
 int  tw_collected_stats(const tw_collected *c, tw_collect_stats *out);
 void tw_collected_free(tw_collected *c);
 
+/* ---- trainer hand-off (replaces the list -> numpy -> tensor path of PPO.data_to_torch / AZ.data_to_torch,
+ *      reference src/twisterl/rl/ppo.py:25-61, rl/az.py:28-46).  Every output is a DEVICE pointer supplied by the
+ *      caller (e.g. torch tensors) and may be NULL; rows [row_begin, row_begin+row_count) of the collected data.
+ *  obs_onehot  float [row_count][obs_size]   np_obs[i, obs_i] = 1.0                        (ppo.py:37-39)
+ *  log_probs   float [row_count]             Categorical(logits).log_prob(actions)          (ppo.py:57-59)  PPO only
+ *  actions     int64 [row_count]             (ppo.py:47)                                                    PPO only
+ *  perms       int64 [row_count]             -1 = None (ppo.py:50-52)
+ *  advs        float [row_count]             advantages; normalize_advantage != 0: (a - mean) / (std + 1e-8) with the
+ *                                            mean / unbiased std of ALL records of the collect (ppo.py:55-56)  PPO only */
+int tw_collected_pack_trainer(const tw_collected *c, uint32_t obs_size, int normalize_advantage, uint64_t row_begin,
+                              uint64_t row_count, float *obs_onehot, float *log_probs, int64_t *actions, int64_t *perms,
+                              float *advs);
+/* mean and unbiased standard deviation (torch.std) of the advantages of the whole collect */
+int tw_collected_adv_stats(const tw_collected *c, double *mean, double *std_unbiased);
+
 #ifdef __cplusplus
 }
 #endif

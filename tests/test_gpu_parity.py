@@ -450,3 +450,56 @@ def test_f16_mode_errors_and_full_size_sample(tw, oracle):
     pol = amd_policy(arrs, [bad], [[0, 1, 2, 3]])
     with pytest.raises(RuntimeError, match="f16"):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1, precision="fp16").collect(tw.env.Puzzle(3, 3, 2, 2, 256), pol)
+
+
+# ------------------------------------------------------------------------------ trainer hand-off
+def test_trainer_handoff_matches_reference_formulas(tw, oracle):
+    """twisterl_amd.trainer.ppo_data_to_torch / az_data_to_torch against a CPU restatement of the reference's
+    PPO.data_to_torch / AZ.data_to_torch (src/twisterl/rl/ppo.py:25-61, rl/az.py:28-46) on the same collected data."""
+    import torch
+    from twisterl_amd import trainer
+    gp, _ = _pair(oracle, 9, 2, 64, 32, twists=True)
+    env = tw.env.Puzzle(3, 3, 6, 2, 256)
+    data = tw.collector.PPOCollector(**{"num_episodes": 200, "gamma": 0.99, "lambda": 0.95, "num_cores": 1}, seed=4).collect(env, gp)
+    a = data.to_numpy()
+    n = len(data)
+    # reference formulas on the CPU (ppo.py:37-59)
+    np_obs = np.zeros((n, 81), dtype=float)
+    for i, o in enumerate(a["obs"].astype(int)):
+        np_obs[i, o] = 1.0
+    t_logits = torch.tensor(a["logits"], dtype=torch.float)
+    t_acts = torch.tensor(a["actions"].astype(np.int64), dtype=torch.long)
+    t_advs = torch.tensor(a["advs"], dtype=torch.float)
+    want_logp = torch.distributions.Categorical(logits=t_logits).log_prob(t_acts).numpy()
+    want_norm = ((t_advs - t_advs.mean()) / (t_advs.std() + 1e-8)).numpy()
+    for norm in (False, True):
+        pt_obs, pt_logp, pt_acts, pt_advs, pt_rets, pt_perm = trainer.ppo_data_to_torch(data, 81, normalize_advantage=norm)
+        assert pt_obs.is_cuda and pt_obs.dtype == torch.float32 and pt_acts.dtype == torch.int64 and pt_perm.dtype == torch.int64
+        assert np.array_equal(pt_obs.cpu().numpy(), np_obs.astype(np.float32))
+        assert np.array_equal(pt_acts.cpu().numpy(), a["actions"].astype(np.int64))
+        assert np.array_equal(pt_perm.cpu().numpy(), a["perms"].astype(np.int64))
+        assert np.array_equal(f32_bits(pt_rets.cpu().numpy()), f32_bits(a["rets"]))
+        np.testing.assert_allclose(pt_logp.cpu().numpy(), want_logp, atol=2e-6, rtol=1e-6)
+        if norm:
+            np.testing.assert_allclose(pt_advs.cpu().numpy(), want_norm, atol=1e-5, rtol=1e-5)
+        else:
+            assert np.array_equal(f32_bits(pt_advs.cpu().numpy()), f32_bits(a["advs"]))
+    # mini-batch of rows: same values, normalisation statistics still those of the whole collect
+    lo, hi = 37, 37 + 300
+    mb = trainer.ppo_data_to_torch(data, 81, normalize_advantage=True, rows=(lo, hi))
+    assert np.array_equal(mb[0].cpu().numpy(), np_obs[lo:hi].astype(np.float32))
+    np.testing.assert_allclose(mb[3].cpu().numpy(), want_norm[lo:hi], atol=1e-5, rtol=1e-5)
+    m, sd = trainer.adv_stats(data)
+    assert abs(m - float(a["advs"].astype(np.float64).mean())) < 1e-9 and abs(sd - float(a["advs"].astype(np.float64).std(ddof=1))) < 1e-9
+    # AlphaZero data (az.py:28-46)
+    az = tw.collector.AZCollector(32, 6, 1.41, 1, 1, seed=2).collect(env, gp)
+    b = az.to_numpy()
+    o2, p2, v2 = trainer.az_data_to_torch(az, 81)
+    want = np.zeros((len(az), 81), np.float32)
+    for i, o in enumerate(b["obs"].astype(int)):
+        want[i, o] = 1.0
+    assert np.array_equal(o2.cpu().numpy(), want) and v2.shape == (len(az), 1)
+    assert np.array_equal(f32_bits(p2.cpu().numpy()), f32_bits(b["logits"]))
+    assert np.array_equal(f32_bits(v2.cpu().numpy()[:, 0]), f32_bits(b["remaining_values"]))
+    with pytest.raises(RuntimeError):
+        trainer.ppo_data_to_torch(az, 81)

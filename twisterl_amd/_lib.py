@@ -125,6 +125,8 @@ SYMBOLS = {
     "tw_collected_copy_to_host": (C.c_int, [_VP, C.c_int, _VP, C.c_size_t]),
     "tw_collected_stats": (C.c_int, [_VP, C.POINTER(CollectStats)]),
     "tw_collected_free": (None, [_VP]),
+    "tw_collected_pack_trainer": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, _VP, _VP, _VP, _VP, _VP]),
+    "tw_collected_adv_stats": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -138,6 +140,13 @@ def lib():
     """Load (building first if needed) libtwisterl_hip.so and declare every prototype."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own HIP runtime under the same soname as /opt/rocm's.  Whichever is loaded first
+        # serves the whole process, and torch fails to initialise ("No HIP GPUs are available") when it finds the
+        # other one already loaded: load torch's first, this library then binds to it as well.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = _build.LIB_PATH
         if not os.path.exists(path) or os.environ.get("TWISTERL_AMD_REBUILD"):
             path = _build.build_library()

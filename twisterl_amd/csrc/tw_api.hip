@@ -533,6 +533,62 @@ extern "C" int tw_collected_stats(const tw_collected *c, tw_collect_stats *out)
     *out = c->stats; return TW_OK;
 }
 
+// ---- trainer hand-off (tw_trainer.hip) ---------------------------------------------------------
+extern "C" int tw_collected_adv_stats(const tw_collected *c, double *mean, double *std_unbiased)
+{
+    if (!c || !mean || !std_unbiased) { set_error("tw_collected_adv_stats: null argument"); return TW_ERR_INVALID; }
+    if (!c->is_ppo || !c->field_ptr[TW_F_ADVS]) { set_error("tw_collected_adv_stats: no advantages in this result (AlphaZero data?)"); return TW_ERR_INVALID; }
+    hipStream_t s = current_stream();
+    double *acc = nullptr;
+    TW_HIP(hipMalloc((void **)&acc, sizeof(double)));
+    const float *adv = reinterpret_cast<const float *>(c->field_ptr[TW_F_ADVS]);
+    const uint64_t n = c->n_records;
+    double sum = 0.0, ss = 0.0;
+    int rc = launch_sum(adv, n, 0.0, 0, acc, s);
+    hipError_t e = hipSuccess;
+    if (rc == TW_OK) { e = hipMemcpyAsync(&sum, acc, 8, hipMemcpyDeviceToHost, s); if (e == hipSuccess) e = hipStreamSynchronize(s); }
+    const double m = n ? sum / (double)n : 0.0;
+    if (rc == TW_OK && e == hipSuccess) rc = launch_sum(adv, n, m, 1, acc, s);
+    if (rc == TW_OK && e == hipSuccess) { e = hipMemcpyAsync(&ss, acc, 8, hipMemcpyDeviceToHost, s); if (e == hipSuccess) e = hipStreamSynchronize(s); }
+    (void)hipFree(acc);
+    if (rc != TW_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "advantage statistics", __FILE__, __LINE__);
+    *mean = m;
+    *std_unbiased = n > 1 ? __builtin_sqrt(ss / (double)(n - 1)) : __builtin_nan("");     // torch.std of one element is nan
+    return TW_OK;
+}
+
+extern "C" int tw_collected_pack_trainer(const tw_collected *c, uint32_t obs_size, int normalize_advantage, uint64_t row_begin,
+                                         uint64_t row_count, float *obs_onehot, float *log_probs, int64_t *actions, int64_t *perms,
+                                         float *advs)
+{
+    if (!c) { set_error("tw_collected_pack_trainer: null result"); return TW_ERR_INVALID; }
+    if (row_begin > c->n_records || row_count > c->n_records - row_begin) {
+        set_error("tw_collected_pack_trainer: rows [%llu, +%llu) outside the %llu records", (unsigned long long)row_begin,
+                  (unsigned long long)row_count, (unsigned long long)c->n_records);
+        return TW_ERR_INVALID;
+    }
+    if (obs_onehot && (obs_size == 0 || obs_size > 256 || obs_size < c->n_cells)) { set_error("tw_collected_pack_trainer: obs_size %u", obs_size); return TW_ERR_INVALID; }
+    if ((log_probs || actions || advs) && !c->is_ppo) { set_error("tw_collected_pack_trainer: log_probs / actions / advs exist for PPO data only"); return TW_ERR_INVALID; }
+    hipStream_t s = current_stream();
+    int rc = TW_OK;
+    if (obs_onehot)
+        rc = launch_onehot(reinterpret_cast<const uint8_t *>(c->field_ptr[TW_F_OBS]), row_begin, row_count, (int)c->n_cells, (int)obs_size, obs_onehot, s);
+    if (rc) return rc;
+    float mean = 0.0f, denom = 1.0f;
+    if (advs && normalize_advantage) {
+        double m, sd;
+        rc = tw_collected_adv_stats(c, &m, &sd); if (rc) return rc;
+        mean = (float)m; denom = (float)sd + 1e-8f;                                  // ppo.py:56, f32 like torch
+    }
+    if (log_probs || actions || perms || advs)
+        rc = launch_ppo_pack(reinterpret_cast<const float *>(c->field_ptr[TW_F_LOGITS]), reinterpret_cast<const uint8_t *>(c->field_ptr[TW_F_ACTIONS]),
+                             reinterpret_cast<const int8_t *>(c->field_ptr[TW_F_PERMS]), reinterpret_cast<const float *>(c->field_ptr[TW_F_ADVS]),
+                             row_begin, row_count, (int)c->n_actions, mean, denom, normalize_advantage ? 1 : 0,
+                             c->is_ppo ? log_probs : nullptr, c->is_ppo ? actions : nullptr, perms, c->is_ppo ? advs : nullptr, s);
+    return rc;
+}
+
 extern "C" void tw_collected_free(tw_collected *c)
 {
     if (!c) return;

@@ -392,6 +392,11 @@ size_t mcts_node_bytes();
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_finalize_az(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,
                        uint8_t *obs_out, float *probs_out, int8_t *perms_out, float *remaining_out, hipStream_t s);
+int launch_onehot(const uint8_t *obs, uint64_t row0, uint64_t rows, int n_cells, int obs_size, float *out, hipStream_t s);
+int launch_ppo_pack(const float *logits, const uint8_t *actions, const int8_t *perms, const float *advs, uint64_t row0, uint64_t rows,
+                    int n_actions, float mean, float denom, int normalize, float *logp_out, int64_t *acts_out, int64_t *perms_out,
+                    float *advs_out, hipStream_t s);
+int launch_sum(const float *x, uint64_t n, double shift, int squared, double *out_dev, hipStream_t s);
 int launch_policy_eval(const PolicyDev &pol, int mode, const int32_t *obs_d, uint32_t n, uint32_t n_obs,
                        const uint8_t *masks_d, const int32_t *perms_d, float *out_actions_d, float *out_values_d,
                        hipStream_t s);
