@@ -134,6 +134,14 @@ typedef struct tw_policy tw_policy;
  * obs_size <= 256.  Anything else: NULL + TW_ERR_UNSUPPORTED. */
 tw_policy *tw_policy_create(const tw_policy_desc *desc);
 void       tw_policy_destroy(tw_policy *p);
+/* Device-to-device policy sync (replaces the per-iteration policy.to_rust() round trip through host lists,
+ * reference src/twisterl/nn/policy.py:191-199, rl/algorithm.py:90-93): rebuilds every weight image of `p` from
+ * the trainer's parameters where they live.  All pointers are DEVICE pointers in torch layout
+ * (nn.Linear.weight = [out][in]): embeddings.weight [emb][obs_size], embeddings.bias [emb], common.0.weight
+ * [hidden][emb], common.0.bias [hidden], action.0.weight [n_actions][hidden], action.0.bias, value.0.weight
+ * [1][hidden], value.0.bias [1].  Shapes, ReLU flags and twists stay those given to tw_policy_create. */
+int tw_policy_update_device(tw_policy *p, const float *emb_w, const float *emb_b, const float *w1, const float *b1,
+                            const float *wa, const float *ba, const float *wv, const float *bv);
 uint32_t   tw_policy_num_actions(const tw_policy *p);
 uint32_t   tw_policy_num_perms(const tw_policy *p);
 

@@ -503,3 +503,40 @@ def test_trainer_handoff_matches_reference_formulas(tw, oracle):
     assert np.array_equal(f32_bits(v2.cpu().numpy()[:, 0]), f32_bits(b["remaining_values"]))
     with pytest.raises(RuntimeError):
         trainer.ppo_data_to_torch(az, 81)
+
+
+# ------------------------------------------------------------------------------ policy sync
+@pytest.mark.parametrize("n2,emb,hidden,twists", [(9, 64, 32, True), (16, 512, 256, True), (4, 96, 128, False)])
+def test_policy_update_from_torch_equals_rebuilding(tw, oracle, n2, emb, hidden, twists):
+    """Policy.update_from_torch (device-to-device image rebuild) gives the same policy, bit for bit, as building a new
+    Policy from the reference's host export (BasicPolicy.to_rust, nn/policy.py:191-199 + nn/utils.py:17-79): identical
+    collects in both precisions."""
+    import torch
+    w = int(round(n2 ** 0.5))
+    arrs_old = make_policy_arrays(n2, seed=1, emb=emb, hidden=hidden)
+    arrs_new = make_policy_arrays(n2, seed=2, emb=emb, hidden=hidden)
+    op_, ap_ = puzzle_transpose_twist(w) if twists else ((), ())
+    pol = amd_policy(arrs_old, op_, ap_)           # built from weight set 1 ...
+    ref = amd_policy(arrs_new, op_, ap_)           # ... reference: rebuilt from weight set 2 through the host
+    we, be, (w1, b1, _), (wa, ba, _), (wv, bv, _) = arrs_new[0], arrs_new[1], arrs_new[2][0], arrs_new[3][0], arrs_new[4][0]
+    state = {                                      # the trainer's tensors: torch layout [out][in], on the GPU
+        "embeddings.weight": torch.tensor(we.T.copy()).cuda(), "embeddings.bias": torch.tensor(be).cuda(),
+        "common.0.weight": torch.tensor(w1.reshape(emb, hidden).T.copy()).cuda(), "common.0.bias": torch.tensor(b1).cuda(),
+        "action.0.weight": torch.tensor(wa.reshape(hidden, 4).T.copy()).cuda(), "action.0.bias": torch.tensor(ba).cuda(),
+        "value.0.weight": torch.tensor(wv.reshape(hidden, 1).T.copy()).cuda(), "value.0.bias": torch.tensor(bv).cuda(),
+    }
+    env = tw.env.Puzzle(w, w, 5, 2, 256)
+    before = tw.collector.PPOCollector(64, 0.99, 0.95, 1).collect(env, pol, seed=3).to_numpy()
+    pol.update_from_torch(state)
+    for prec in ("fp32", "fp16"):
+        coll = tw.collector.PPOCollector(**{"num_episodes": 200, "gamma": 0.99, "lambda": 0.95, "num_cores": 1}, seed=3, precision=prec)
+        a, b = coll.collect(env, pol, seed=3).to_numpy(), coll.collect(env, ref, seed=3).to_numpy()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (prec, k)
+    after = tw.collector.PPOCollector(64, 0.99, 0.95, 1).collect(env, pol, seed=3).to_numpy()
+    assert not np.array_equal(before["logits"][:8], after["logits"][:8])          # the weights did change
+    la, va = pol.evaluate_batch(0, np.arange(n2)[None, :] * n2 + np.arange(n2)[None, :], np.ones((1, 4), np.uint8))
+    lb, vb = ref.evaluate_batch(0, np.arange(n2)[None, :] * n2 + np.arange(n2)[None, :], np.ones((1, 4), np.uint8))
+    assert np.array_equal(f32_bits(la), f32_bits(lb)) and np.array_equal(f32_bits(va), f32_bits(vb))
+    with pytest.raises(ValueError):
+        pol.update_from_torch({**state, "common.0.bias": torch.zeros(3).cuda()})

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtwisterl_hip.so")
-SOURCES = ["tw_api.hip", "tw_rollout.hip", "tw_rollout16.hip", "tw_finalize.hip", "tw_eval.hip", "tw_mcts.hip", "tw_solve.hip", "tw_trainer.hip"]
+SOURCES = ["tw_api.hip", "tw_rollout.hip", "tw_rollout16.hip", "tw_finalize.hip", "tw_eval.hip", "tw_mcts.hip", "tw_solve.hip", "tw_trainer.hip", "tw_sync.hip"]
 HEADERS = [os.path.join(CSRC, "tw_common.hpp"), os.path.join(CSRC, "tw_engine.hpp"), os.path.join(CSRC, "tw_engine16.hpp"),
            os.path.join(ROOT, "include", "twisterl_hip.h")]
 

@@ -237,6 +237,7 @@ struct tw_policy {
     PolicyDev dev{};
     void *arena = nullptr;
     int device = -1;
+    uint32_t n16 = 0, sp16 = 0;      // f16 image geometry (tw_policy_update_device)
 };
 
 namespace {
@@ -440,7 +441,36 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     pd.b1img16 = reinterpret_cast<const float *>(base + s_b116.off);
     pd.bh16 = reinterpret_cast<const float *>(base + s_bh16.off);
     pd.srcmap16 = base + s_src16.off; pd.vmap16 = base + s_vm16.off;
+    pol->n16 = n16; pol->sp16 = SP16;
     return pol;
+}
+
+extern "C" int tw_policy_update_device(tw_policy *p, const float *emb_w, const float *emb_b, const float *w1, const float *b1,
+                                       const float *wa, const float *ba, const float *wv, const float *bv)
+{
+    if (!p || !emb_w || !emb_b || !w1 || !b1 || !wa || !ba || !wv || !bv) { set_error("tw_policy_update_device: null argument"); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+    const PolicyDev &d = p->dev;
+    SyncArgs a{};
+    a.emb_w = emb_w; a.emb_b = emb_b; a.w1 = w1; a.b1 = b1; a.wa = wa; a.ba = ba; a.wv = wv; a.bv = bv;
+    a.OS = d.obs_size; a.E = d.emb; a.H = d.hidden; a.A = d.n_actions; a.NT = d.hidden / 32; a.NQ = (a.NT + 3) / 4;
+    a.n16 = (int)p->n16; a.nc16 = d.f16_nc; a.SP16 = (int)p->sp16; a.NKT = d.emb / 32;
+    auto w = [](const void *q) { return const_cast<void *>(q); };
+    a.emb_rows = (float *)w(d.emb_rows); a.w1p = (float *)w(d.w1p); a.t_img16 = (float *)w(d.t_img16); a.b1_d = (float *)w(d.b1);
+    a.wh8 = (float *)w(d.wh8); a.bh8 = (float *)w(d.bh8); a.w1_nat = (float *)w(d.w1); a.wa_nat = (float *)w(d.wa);
+    a.ba_nat = (float *)w(d.ba); a.wv_nat = (float *)w(d.wv); a.bv_nat = (float *)w(d.bv);
+    a.stage16 = (uint8_t *)w(d.stage16); a.head16 = (uint8_t *)w(d.head16); a.ebias16 = (float *)w(d.ebias16);
+    a.b1img16 = (float *)w(d.b1img16); a.bh16 = (float *)w(d.bh16);
+    const bool f16 = d.f16_nc != 0;
+    const unsigned long long cnt[16] = {
+        (unsigned long long)(a.OS + 2) * a.E, (unsigned long long)a.E * a.NQ * 128, (unsigned long long)(a.E / 16) * 21 * 256,
+        (unsigned long long)a.H, (unsigned long long)a.H * 8, 8ull, (unsigned long long)a.E * a.H, (unsigned long long)a.H * a.A,
+        (unsigned long long)a.A, (unsigned long long)a.H, 1ull,
+        f16 ? (unsigned long long)a.NKT * a.SP16 * 512 : 0ull, f16 ? (unsigned long long)a.NT * 1024 : 0ull,
+        f16 ? (unsigned long long)a.NKT * 32 : 0ull, f16 ? (unsigned long long)a.NT * 32 : 0ull, f16 ? 8ull : 0ull};
+    unsigned long long run = 0;
+    for (int i = 0; i < 16; ++i) { run += cnt[i]; a.seg_end[i] = run; }
+    return launch_policy_sync(a, current_stream());
 }
 
 extern "C" void tw_policy_destroy(tw_policy *p)

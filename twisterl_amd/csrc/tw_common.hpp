@@ -397,6 +397,22 @@ int launch_ppo_pack(const float *logits, const uint8_t *actions, const int8_t *p
                     int n_actions, float mean, float denom, int normalize, float *logp_out, int64_t *acts_out, int64_t *perms_out,
                     float *advs_out, hipStream_t s);
 int launch_sum(const float *x, uint64_t n, double shift, int squared, double *out_dev, hipStream_t s);
+// device-to-device policy sync (tw_sync.hip)
+struct SyncArgs {
+    // torch-layout sources (device)
+    const float *emb_w, *emb_b;   // [E][OS], [E]
+    const float *w1, *b1;         // [H][E], [H]
+    const float *wa, *ba;         // [A][H], [A]
+    const float *wv, *bv;         // [1][H], [1]
+    int OS, E, H, A, NT, NQ, n16, nc16, SP16, NKT;
+    // destinations (the policy's arena)
+    float *emb_rows, *w1p, *t_img16, *b1_d, *wh8, *bh8, *w1_nat, *wa_nat, *ba_nat, *wv_nat, *bv_nat;
+    uint8_t *stage16, *head16; float *ebias16, *b1img16, *bh16;
+    // element counts per segment (prefix sums in seg_end)
+    unsigned long long seg_end[16];
+};
+
+int launch_policy_sync(const SyncArgs &a, hipStream_t s);
 int launch_policy_eval(const PolicyDev &pol, int mode, const int32_t *obs_d, uint32_t n, uint32_t n_obs,
                        const uint8_t *masks_d, const int32_t *perms_d, float *out_actions_d, float *out_values_d,
                        hipStream_t s);

@@ -177,3 +177,42 @@ class Policy:
     def full_predict(self, obs, masks):
         """average over all twists (policy.rs:42-44 -> nn/policy.rs:102-126)"""
         return self._single(_lib.TW_EVAL_FULL_PREDICT, obs, masks, None)
+
+
+def _sync_from_torch(policy: "Policy", state) -> None:
+    """See Policy.update_from_torch."""
+    import torch
+    if hasattr(state, "state_dict"):
+        state = state.state_dict()
+    keys = ["embeddings.weight", "embeddings.bias", "common.0.weight", "common.0.bias", "action.0.weight", "action.0.bias",
+            "value.0.weight", "value.0.bias"]
+    missing = [k for k in keys if k not in state]
+    if missing:
+        raise KeyError(f"update_from_torch: the state has no {missing} (BasicPolicy layout: embeddings / common.0 / action.0 / value.0)")
+    h = policy._handle()
+    emb, hid = int(policy.embeddings.bias.size), policy.common.layers[0].out_features
+    want = {"embeddings.weight": (emb, int(policy.embeddings.vectors.shape[0])), "embeddings.bias": (emb,), "common.0.weight": (hid, emb),
+            "common.0.bias": (hid,), "action.0.weight": (int(policy.num_actions), hid), "action.0.bias": (int(policy.num_actions),),
+            "value.0.weight": (1, hid), "value.0.bias": (1,)}
+    ts = []
+    for k in keys:
+        t = state[k].detach()
+        if tuple(t.shape) != want[k]:
+            raise ValueError(f"update_from_torch: {k} has shape {tuple(t.shape)}, the policy was built for {want[k]}")
+        ts.append(t.to(device="cuda", dtype=torch.float32).contiguous())
+    torch.cuda.current_stream().synchronize()        # the parameters are final before the library's stream reads them
+    _lib.check(_lib.lib().tw_policy_update_device(h, *[C.c_void_p(t.data_ptr()) for t in ts]))
+    torch.cuda.synchronize()                          # the temporaries in `ts` may be freed after this returns
+
+
+def _update_from_torch(self, state) -> "Policy":
+    """Device-to-device policy sync: refresh every weight image of this policy from a torch
+    module / state_dict in the reference's BasicPolicy layout (embeddings, common.0, action.0, value.0; Linear.weight =
+    [out][in]) without leaving the GPU.  Replaces rebuilding the policy from `.cpu().numpy().tolist()` exports on
+    every training iteration (reference src/twisterl/nn/policy.py:191-199, rl/algorithm.py:90-93).  Shapes, ReLU
+    flags and twists stay those the policy was created with."""
+    _sync_from_torch(self, state)
+    return self
+
+
+Policy.update_from_torch = _update_from_torch
