@@ -342,6 +342,16 @@ struct RolloutArgs {
     uint64_t     num_episodes, episode_offset, seed;
 };
 
+// Waves per workgroup of the f32 engine for a batch of n columns (episodes / attempts): 8 (two per SIMD) is the
+// throughput geometry; with fewer than ~190 workgroups of 256 columns the chip is not filled, so smaller groups
+// (64 or 32 columns) spread the batch over more CUs -- every workgroup streams the whole weight set anyway.
+inline int waves_per_group(uint64_t n)
+{
+    if ((n + 255) / 256 >= 192) return 8;
+    if ((n + 63) / 64 >= 192) return 2;
+    return 1;
+}
+
 // kernel launchers (each returns a TW_* status)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);

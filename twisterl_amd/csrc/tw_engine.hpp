@@ -87,9 +87,11 @@ __host__ __device__ inline size_t engine3_lds_floats(int obs_size)
            (size_t)MAX_LDS_PERMS * ((obs_size + 3) / 4 + 1);
 }
 
-template <int NT, int NC, int DBG = 0>
+// NW = waves per workgroup (8: two per SIMD, the throughput geometry; 2 / 1: small batches, so that a few thousand
+// episodes still spread over many CUs -- each workgroup streams the whole weight set either way).
+template <int NT, int NC, int DBG = 0, int NW_ = 8>
 struct Engine3 {
-    static constexpr int NW = 8, KC = R3_KC, THREADS = 512, EPB = NW * EPW, LSTR = R3_LSTR;
+    static constexpr int NW = NW_, KC = R3_KC, THREADS = 64 * NW_, EPB = NW * EPW, LSTR = R3_LSTR;
     static constexpr int NQ     = Tiles<NT>::NQ;
     static constexpr int WSLOT  = KC * NQ * 128;            // floats per W1 slot
     static constexpr int WPIECE = WSLOT / 256;              // DMA pieces per W1 chunk
@@ -215,8 +217,13 @@ struct Engine3 {
                 }
             }
             {   // DMA ops spread over the group
-                constexpr int SP = M / 4 > 0 ? M / 4 : 1;
-                if (m % SP == SP / 2 && op0 + m / SP < op1) stream_op(s_chunk, s_slot, op0 + m / SP);
+                if constexpr (NW == 8) {
+                    constexpr int SP = M / 4 > 0 ? M / 4 : 1;
+                    if (m % SP == SP / 2 && op0 + m / SP < op1) stream_op(s_chunk, s_slot, op0 + m / SP);
+                } else {   // fewer waves, more pieces per wave: as many ops per MFMA slot as it takes
+                    const int g = op1 - op0;
+                    for (int o = m * g / M; o < (m + 1) * g / M; ++o) stream_op(s_chunk, s_slot, op0 + o);
+                }
             }
             if constexpr (HAVE_NEXT_GATHER) {
 #pragma unroll

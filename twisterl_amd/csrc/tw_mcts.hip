@@ -49,10 +49,10 @@ __device__ inline PuzzleLane lane_of(const MctsNode &n, const PuzzleConsts &c)
     return s;
 }
 
-template <int NT, int NC>
-__global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
+template <int NT, int NC, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(const MctsArgs a)
 {
-    using Eng = Engine3<NT, NC, 0>;
+    using Eng = Engine3<NT, NC, 0, NW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -279,25 +279,34 @@ __global__ void __launch_bounds__(512, 2) mcts_f32_kernel(const MctsArgs a)
     eng.end();
 }
 
-template <int NT, int NC>
-static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+template <int NT, int NC, int NW>
+static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    constexpr int EPB = 8 * EPW;
+    constexpr int EPB = NW * EPW;
     const uint64_t nb = (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((mcts_f32_kernel<NT, NC>), dim3((unsigned)nb), dim3(512), lds_bytes, s, a);
+    hipLaunchKernelGGL((mcts_f32_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
-    if (threads) *threads = 512;
+    if (threads) *threads = 64 * NW;
     return TW_OK;
+}
+
+template <int NT, int NC>
+static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    const int nw = waves_per_group(a.num_episodes);
+    if (nw == 1) return launch_mcts_geom<NT, NC, 1>(a, s, blocks, threads);
+    if (nw == 2) return launch_mcts_geom<NT, NC, 2>(a, s, blocks, threads);
+    return launch_mcts_geom<NT, NC, 8>(a, s, blocks, threads);
 }
 
 template <int NT>

@@ -35,10 +35,10 @@
 
 namespace tw {
 
-template <int NT, int NC, int DBG = 0>
-__global__ void __launch_bounds__(512, 2) rollout_f32_kernel(const RolloutArgs a)
+template <int NT, int NC, int DBG = 0, int NW = 8>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(const RolloutArgs a)
 {
-    using Eng = Engine3<NT, NC, DBG>;
+    using Eng = Engine3<NT, NC, DBG, NW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);                               // first weight chunks stream in while the scramble runs
@@ -102,21 +102,21 @@ __global__ void __launch_bounds__(512, 2) rollout_f32_kernel(const RolloutArgs a
     eng.end();
 }
 
-template <int NT, int NC, int DBG = 0>
+template <int NT, int NC, int DBG = 0, int NW = 8>
 static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    constexpr int EPB = 8 * EPW, THREADS = 512;
+    constexpr int EPB = NW * EPW, THREADS = 64 * NW;
     const uint64_t nb = (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;   // per instantiation: raise the dynamic-LDS limit above the 64 KiB default
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, DBG>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, DBG, NW>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = THREADS;
@@ -138,6 +138,10 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
         }
     }
 #endif
+    // small batches: fewer waves per workgroup, so that the episodes spread over more CUs
+    const int nw = waves_per_group(a.num_episodes);
+    if (nw == 1) return launch_geom<NT, NC, 0, 1>(a, s, blocks, threads);
+    if (nw == 2) return launch_geom<NT, NC, 0, 2>(a, s, blocks, threads);
     return launch_geom<NT, NC>(a, s, blocks, threads);
 }
 

@@ -10,10 +10,10 @@
 
 namespace tw {
 
-template <int NT, int NC>
-__global__ void __launch_bounds__(512, 2) solve_f32_kernel(const SolveArgs a)
+template <int NT, int NC, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) solve_f32_kernel(const SolveArgs a)
 {
-    using Eng = Engine3<NT, NC, 0>;
+    using Eng = Engine3<NT, NC, 0, NW>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -78,23 +78,32 @@ __global__ void __launch_bounds__(512, 2) solve_f32_kernel(const SolveArgs a)
     eng.end();
 }
 
-template <int NT, int NC>
-static int launch_solve_one(const SolveArgs &a, hipStream_t s)
+template <int NT, int NC, int NW>
+static int launch_solve_geom(const SolveArgs &a, hipStream_t s)
 {
-    constexpr int EPB = 8 * EPW;
+    constexpr int EPB = NW * EPW;
     const uint64_t nb = (a.num_attempts + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
     const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("solve: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_f32_kernel<NT, NC>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_f32_kernel<NT, NC, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((solve_f32_kernel<NT, NC>), dim3((unsigned)nb), dim3(512), lds_bytes, s, a);
+    hipLaunchKernelGGL((solve_f32_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     return TW_OK;
+}
+
+template <int NT, int NC>
+static int launch_solve_one(const SolveArgs &a, hipStream_t s)
+{
+    const int nw = waves_per_group(a.num_attempts);
+    if (nw == 1) return launch_solve_geom<NT, NC, 1>(a, s);
+    if (nw == 2) return launch_solve_geom<NT, NC, 2>(a, s);
+    return launch_solve_geom<NT, NC, 8>(a, s);
 }
 
 template <int NT>
