@@ -250,7 +250,7 @@ struct Engine16 {
         TW_STAMP(t_in);
         using S = Sched<E_P, M_P>;
         using SN = Sched<true, true>;
-        static_assert(!(FIRST && M_P) || ((S::code(0) & 1) && (S::code(1) & 1)), "FIRST: b1 is fetched two positions ahead");
+
         constexpr int NP = S::NP, LE = S::last_e();
         constexpr int MAFTER = NP - 1 - LE;                                     // common-layer pairs behind the last embedding pair
         constexpr int UPP = !M_P ? 16 : (MAFTER > 1 ? (16 + MAFTER - 2) / (MAFTER - 1) : 16);
@@ -269,6 +269,13 @@ struct Engine16 {
             if ((u >> 3) == 0) cvt_unit<false>(e0, zero16, (u >> 2) & 1, u & 3, emb_lim, Bn0[(u >> 2) & 1]);
             else               cvt_unit<false>(e1, zero16, (u >> 2) & 1, u & 3, emb_lim, Bn1[(u >> 2) & 1]);
         };
+        if (FIRST) {                                                            // b1 for common-layer pairs at positions 0 / 1 (no lookahead room)
+#pragma unroll
+            for (int p0 = 0; p0 < 2 && p0 < NP; ++p0) {
+                const int c0 = S::code(p0);
+                if (!(c0 & 1) && ((c0 >> 1) & 1) == 0) cbv[((c0 >> 1) >> 1) & 1] = ld16(O_B1 + (uint32_t)(((c0 >> 1) >> 1) * 2 + hh) * 64u);
+            }
+        }
         int op = 0, udone = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -373,23 +380,41 @@ struct Engine16 {
         phase<true, false, false, 1, false>(tile_of(1), O_T0 + lo, 0, slot_base(s0), 0, 0, oh, acc0, acc1, Ba0, Ba1, Ba0, Ba1, pp);
         TW_STAMP(t_p1);
         TW_ACC(1, t_p0, t_p1);
-        // every stage: embedding MFMAs of tile kt+1 interleaved with the common-layer MFMAs of tile kt.  (In the
-        // last stage the embedding part runs on tile 0 again and is discarded: one uniform loop body keeps the
-        // register allocation of the 512-register kernel simple; 3 % of the MFMAs.)  Two stages per loop trip:
-        // the B fragments ping-pong between (Ba) and (Bb) without copies.
+        // every stage but the last: embedding MFMAs of tile kt+1 interleaved with the common-layer MFMAs of tile kt;
+        // two stages per loop trip: the B fragments ping-pong between (Ba) and (Bb) without copies.  The last stage
+        // has only the common-layer part; it fetches its first operands itself (the stage before it prefetched for
+        // the order of a full stage).
         auto stage = [&](auto first, int kt, const h16x8 (&c0)[2], const h16x8 (&c1)[2], h16x8 (&n0)[2], h16x8 (&n1)[2]) {
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
             phase<true, true, decltype(first)::value, 1, true>(tile_of(kt + 2), slot_base(s0), slot_base(s0) + NC * 1024, slot_base(s1),
                                                                stage_of(kt), s2, oh, acc0, acc1, c0, c1, n0, n1, pp);
             s0 = s1;
         };
-        stage(std::true_type{}, 0, Ba0, Ba1, Bb0, Bb1);
-        int kt = 1;
-        for (; kt + 1 < n_kt; kt += 2) {
-            stage(std::false_type{}, kt, Bb0, Bb1, Ba0, Ba1);
-            stage(std::false_type{}, kt + 1, Ba0, Ba1, Bb0, Bb1);
+        auto last = [&](auto first, int kt, const h16x8 (&c0)[2], const h16x8 (&c1)[2]) {
+            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
+            const uint32_t bM = slot_base(s0) + NC * 1024;
+#pragma unroll
+            for (int d = 0; d < D; ++d) pp.a[d] = ld8(bM + d * 1024);
+            h16x8 dummy0[2], dummy1[2];
+            phase<false, true, decltype(first)::value, 0, true>(0, 0, bM, 0, stage_of(kt), s2, oh, acc0, acc1, c0, c1, dummy0, dummy1, pp);
+            s0 = s1;
+        };
+        if (n_kt == 1) last(std::true_type{}, 0, Ba0, Ba1);
+        else {
+            stage(std::true_type{}, 0, Ba0, Ba1, Bb0, Bb1);
+            int kt = 1;
+            for (; kt + 2 < n_kt; kt += 2) {
+                stage(std::false_type{}, kt, Bb0, Bb1, Ba0, Ba1);
+                stage(std::false_type{}, kt + 1, Ba0, Ba1, Bb0, Bb1);
+            }
+            if (kt + 1 < n_kt) {                 // odd number of stages left: one more, then move its fragments (16 registers)
+                stage(std::false_type{}, kt, Bb0, Bb1, Ba0, Ba1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { Bb0[m] = Ba0[m]; Bb1[m] = Ba1[m]; }
+                ++kt;
+            }
+            last(std::false_type{}, kt, Bb0, Bb1);
         }
-        if (kt < n_kt) stage(std::false_type{}, kt, Bb0, Bb1, Ba0, Ba1);
         rp = s0;
         TW_STAMP(t_h0);
         // heads: h1 = relu(acc) in f16 is the B operand (b1 went in as the C operand of the first stage), hidden
