@@ -144,13 +144,18 @@ def main():
     coll = twisterl.collector.PPOCollector(**{"num_episodes": E_total, "gamma": 0.995, "lambda": 0.995, "num_cores": 32},
                                            precision=args.precision)
 
+    gather_chunks = int(os.environ.get("TW_GATHER_CHUNKS", "4" if world > 1 else "1"))
+
     def step(i):
         seed = 1000 + i
         if use_dist:
-            merged, data = collect_sharded(coll, env, policy, seed=seed, dst=0)
-            n = len(data)
+            # N > 1: the shard is collected in chunks so that each chunk's xGMI transfer to rank 0 overlaps with the
+            # collection of the next one (twisterl_amd.dist.PipelinedGather); the gather is inside the timed region
+            merged, data = collect_sharded(coll, env, policy, seed=seed, dst=0, chunks=gather_chunks)
+            datas = data if isinstance(data, list) else [data]
+            n = sum(len(d) for d in datas)
             del merged
-            return n, data.stats
+            return n, {"ms_rollout": sum(d.stats["ms_rollout"] for d in datas)}
         data = coll.collect(env, policy, seed=seed)
         return len(data), data.stats
 

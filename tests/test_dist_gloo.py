@@ -54,6 +54,30 @@ def _worker(rank, world, port, E, q):
             "advs": torch.from_numpy(d.additional_data["advs"]), "rets": torch.from_numpy(d.additional_data["rets"]),
         }
         merged = gather_trajectories(fields, torch.from_numpy(d.ep_len.astype(np.int64)), dst=0)
+        # the pipelined form: the same shard handed over in K chunks of episodes must give the same result
+        from twisterl_amd.dist import PipelinedGather
+        K = 3
+        pg = PipelinedGather(dst=0)
+        for c in range(K):
+            a, b = lo + ((hi - lo) * c) // K, lo + ((hi - lo) * (c + 1)) // K
+            if b <= a:
+                dc_fields = {k: v[:0] for k, v in fields.items()}
+                pg.submit(dc_fields, torch.zeros((0,), dtype=torch.int64))
+                continue
+            dc = O.ppo_collect(env, pol, b - a, 0.995, 0.995, seed=77, episode_offset=a, arith=O.ARITH_CHAIN,
+                               det_log=True, merge_order=False)
+            pg.submit({
+                "obs": torch.from_numpy(dc.obs.astype(np.uint8)), "logits": torch.from_numpy(dc.logits),
+                "perms": torch.from_numpy(dc.perms.astype(np.int8)), "values": torch.from_numpy(dc.values),
+                "rewards": torch.from_numpy(dc.rewards), "actions": torch.from_numpy(dc.actions.astype(np.uint8)),
+                "advs": torch.from_numpy(dc.additional_data["advs"]), "rets": torch.from_numpy(dc.additional_data["rets"]),
+            }, torch.from_numpy(dc.ep_len.astype(np.int64)))
+        piped = pg.finish()
+        if rank == 0:
+            for k in merged:
+                assert torch.equal(merged[k], piped[k]), k
+        else:
+            assert piped is None
         if rank == 0:
             full = O.ppo_collect(env, pol, E, 0.995, 0.995, seed=77, arith=O.ARITH_CHAIN, det_log=True, merge_order=True)
             ok = (np.array_equal(merged["obs"].numpy().astype(np.int64), full.obs)

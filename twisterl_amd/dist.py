@@ -82,6 +82,89 @@ def gather_trajectories(fields: Dict[str, torch.Tensor], ep_len: torch.Tensor, d
     return out
 
 
+class PipelinedGather:
+    """Gather that overlaps with collection: a rank's shard is collected in K chunks of episodes; the trajectories
+    of chunk c travel to `dst` (point-to-point, as in gather_trajectories) while chunk c+1 is being collected, so
+    only the last chunk's transfer and one on-device reorder at `dst` are exposed.  xGMI moves ~3.4 GB per rank and
+    Puzzle-15 step into the root at link rate (~50 ms for 7 senders): a third of the collection time if serialised.
+
+    submit(fields, ep_len): chunk in episode-index order (merge_order=0), asynchronous (keeps the tensors alive);
+    finish(): waits and returns, on `dst`, every field in the reference merge order [E-1, 0, ..., E-2]
+    (rust/src/collector/collector.rs:40-46), bit-identical to gather_trajectories of the un-chunked shard."""
+
+    def __init__(self, dst: int = 0, group=None):
+        self.dst, self.group = dst, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.chunks = []          # per chunk: (counts per rank, tail of the last rank, staging dict | None)
+        self.works, self.keep = [], []
+        self.names = None
+
+    def submit(self, fields: Dict[str, torch.Tensor], ep_len: torch.Tensor) -> None:
+        names = [n for n in FIELD_ORDER if n in fields]
+        self.names = names
+        n_local = int(fields[names[0]].shape[0])
+        last_len = int(ep_len[-1].item()) if ep_len.numel() else 0
+        dev = fields[names[0]].device
+        mine = torch.tensor([n_local, last_len], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allc, mine, group=self.group)
+        counts = [int(c[0].item()) for c in allc]
+        tail = int(allc[self.world - 1][1].item())
+        ops, staging = [], None
+        if self.rank == self.dst:
+            total = sum(counts)
+            staging = {n: torch.empty((total,) + tuple(fields[n].shape[1:]), dtype=fields[n].dtype, device=dev) for n in names}
+            off = 0
+            for r in range(self.world):
+                if counts[r]:
+                    for n in names:
+                        if r == self.rank:
+                            staging[n][off:off + counts[r]].copy_(fields[n])
+                        else:
+                            ops.append(dist.P2POp(dist.irecv, staging[n][off:off + counts[r]], r, self.group))
+                off += counts[r]
+        elif n_local:
+            for n in names:
+                t = fields[n].contiguous()
+                self.keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, self.dst, self.group))
+        self.keep.append(fields)
+        if ops:
+            self.works.extend(dist.batch_isend_irecv(ops))
+        self.chunks.append((counts, tail, staging))
+
+    def finish(self) -> Optional[Dict[str, torch.Tensor]]:
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.rank != self.dst:
+            self.keep = []
+            return None
+        names, world, K = self.names, self.world, len(self.chunks)
+        tail = self.chunks[-1][1] if K else 0                       # records of global episode E-1
+        total = sum(sum(c[0]) for c in self.chunks)
+        first = self.chunks[0][2]
+        out = {n: torch.empty((total,) + tuple(first[n].shape[1:]), dtype=first[n].dtype, device=first[n].device) for n in names}
+        # [tail][rank 0: chunk 0..K-1][rank 1: ...]...[rank G-1: ... without its tail]
+        pos = tail
+        for r in range(world):
+            for c, (counts, _, staging) in enumerate(self.chunks):
+                src = sum(counts[:r])
+                n_rec = counts[r]
+                if r == world - 1 and c == K - 1:
+                    body = n_rec - tail
+                    for n in names:
+                        out[n][0:tail].copy_(staging[n][src + body:src + n_rec])
+                    n_rec = body
+                if n_rec > 0:
+                    for n in names:
+                        out[n][pos:pos + n_rec].copy_(staging[n][src:src + n_rec])
+                pos += n_rec
+        assert pos == total
+        self.keep, self.chunks = [], []
+        return out
+
+
 def broadcast_weights(tensors, src: int = 0, group=None) -> None:
     """Policy sync: one flat broadcast of all weight tensors (Puzzle-15: 264,197 f32 ~ 1.06 MB)."""
     flat = torch.cat([t.reshape(-1) for t in tensors])
@@ -93,23 +176,41 @@ def broadcast_weights(tensors, src: int = 0, group=None) -> None:
         off += n
 
 
-def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None, gather: bool = True):
+def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None, gather: bool = True, chunks: int = 1):
     """Run `collector` (a PPOCollector/AZCollector configured with the GLOBAL num_episodes) on this
     rank's shard and gather to `dst`.  Returns (merged dict of device tensors or None, local
-    CollectedData)."""
+    CollectedData -- a list of them, one per chunk, when chunks > 1).  chunks > 1 collects the shard in that
+    many pieces and overlaps each piece's transfer with the collection of the next (PipelinedGather)."""
     import copy
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     lo, hi = shard_range(collector.num_episodes, rank, world)
-    local = copy.copy(collector)
-    local.num_episodes = hi - lo
-    local.episode_offset = collector.episode_offset + lo
-    local.merge_order = False
-    data = local.collect(env, policy, seed=seed)
-    if not gather:
-        return None, data
-    t = data.to_torch()
-    ep_len = t.pop("ep_len")
-    t.pop("ep_start", None)
-    merged = gather_trajectories(t, ep_len, dst=dst, group=group)
-    return merged, data
+    chunks = max(1, min(int(chunks), hi - lo)) if hi > lo else 1
+
+    def run(a, b):
+        local = copy.copy(collector)
+        local.num_episodes = b - a
+        local.episode_offset = collector.episode_offset + a
+        local.merge_order = False
+        return local.collect(env, policy, seed=seed)
+
+    if chunks == 1:
+        data = run(lo, hi)
+        if not gather:
+            return None, data
+        t = data.to_torch()
+        ep_len = t.pop("ep_len")
+        t.pop("ep_start", None)
+        return gather_trajectories(t, ep_len, dst=dst, group=group), data
+    pg = PipelinedGather(dst=dst, group=group) if gather else None
+    datas = []
+    for c in range(chunks):
+        a, b = lo + ((hi - lo) * c) // chunks, lo + ((hi - lo) * (c + 1)) // chunks
+        d = run(a, b)
+        datas.append(d)
+        if pg is not None:
+            t = d.to_torch()
+            ep_len = t.pop("ep_len")
+            t.pop("ep_start", None)
+            pg.submit(t, ep_len)
+    return (pg.finish() if pg is not None else None), datas
