@@ -450,6 +450,17 @@ def test_f16_mode_errors_and_full_size_sample(tw, oracle):
     assert L.sum() == a["obs"].shape[0] and L.min() >= 1 and L.max() <= 65
     rng = np.random.default_rng(1)
     _check_f16_collect(oracle, a, op, 3, 3, 32, 21, 0, [int(e) for e in rng.choice(65536, size=24, replace=False)])
+    # how far the f16-input mode is from the reference's f32 arithmetic on the same records (documented in DESIGN.md §2)
+    L0 = np.concatenate([[0], np.cumsum(L)])
+    worst32 = 0.0
+    for e in rng.choice(65536, size=8, replace=False):
+        for t in range(int(L[e])):
+            r = int(L0[e]) + t
+            obs = a["obs"][r].astype(np.int64)
+            masks = (a["logits"][r] != np.float32(-1e10)).tolist()
+            lr, vr = op.forward(obs.tolist(), masks, arith=oracle.ARITH_REF)
+            worst32 = max(worst32, float(np.max(np.abs(a["logits"][r] - np.asarray(lr, np.float32)))), abs(float(a["values"][r]) - vr))
+    assert 1e-6 < worst32 < 1e-2, worst32
     # a twist that does not map cells to cells has no f16 image
     arrs = make_policy_arrays(9, seed=0, emb=32, hidden=32)
     bad = list(range(81)); bad[0], bad[9] = bad[9], bad[0]
