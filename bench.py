@@ -221,6 +221,23 @@ def main():
                 "hbm_frac": rec_per_launch * BYTES_PER_RECORD[n2] / kern_s / 8e12,
             },
         }
+        if world == 1 and args.precision == "fp32":
+            # side measurement, not the headline: the same workload in the f16-input MFMA mode (BASELINE.json config 2's
+            # "MLP policy fp16"; env transitions / masks / rewards / sampling bit-exact, logits per the f16 spec)
+            try:
+                c16 = twisterl.collector.PPOCollector(**{"num_episodes": E_total, "gamma": 0.995, "lambda": 0.995, "num_cores": 32},
+                                                      precision="fp16")
+                c16.collect(env, policy, seed=1)
+                torch.cuda.synchronize(); t16 = time.perf_counter()
+                d16 = [c16.collect(env, policy, seed=2 + i) for i in range(2)]
+                n16 = sum(len(d) for d in d16)
+                torch.cuda.synchronize(); dt16 = time.perf_counter() - t16
+                k16 = float(np.mean([d.stats["ms_rollout"] for d in d16])) * 1e-3
+                out["f16_input_mode"] = {"value": n16 / dt16, "unit": "env-steps/s", "ms_per_step": dt16 / 2 * 1e3, "kernel_ms": k16 * 1e3,
+                                         "roofline_frac_of_2500_TFLOPs": n16 / 2 * FLOP_PER_RECORD[n2] / k16 / 1e12 / PEAK_TFLOPS["fp16"]}
+                del d16
+            except Exception as e:   # the headline line must not depend on the side measurement
+                out["f16_input_mode"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds, args.cpu_threads)
         print(json.dumps(out), flush=True)
