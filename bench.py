@@ -208,7 +208,8 @@ def main():
                             f"(<= {2 * args.difficulty + 1} records/episode), twists "
                             f"{'none' if args.no_twists else '{identity, transpose}'}, BasicPolicy {n2 * n2}->512->256->4|1, "
                             f"gamma=lambda=0.995, torch-default-init weights seed 0",
-                "envs_per_gpu": args.envs, "records_per_step": rec_per_launch * world, "parallelism": f"episodes sharded x{world}",
+                "envs_per_gpu": args.envs, "records_per_step": rec_per_launch * world,
+                "mean_records_per_episode": rec_per_launch / args.envs, "parallelism": f"episodes sharded x{world}",
             },
             "roofline": {
                 "bound": "mfma", "kernel": "tw::rollout_f32_kernel" if args.precision == "fp32" else "tw::rollout_f16_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
