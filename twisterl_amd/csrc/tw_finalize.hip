@@ -139,8 +139,9 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
     extern __shared__ __attribute__((aligned(16))) float fin_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t_pad = in.t_pad;
-    float *sr = fin_lds + (size_t)wave * 4 * t_pad;   // rewards | values | advs | rets
+    float *sr = fin_lds + (size_t)wave * 5 * t_pad;   // rewards | values | advs | rets | action/perm word
     float *sv = sr + t_pad, *sa = sv + t_pad, *st = sa + t_pad;
+    uint32_t *sz = reinterpret_cast<uint32_t *>(st + t_pad);
 
     for (uint64_t e = (uint64_t)blockIdx.x * FIN_WAVES + wave; e < E; e += (uint64_t)gridDim.x * FIN_WAVES) {
         const int      n     = (int)in.ep_len[e];
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
         const uint64_t dst   = ep_start[e];
         for (int t = lane; t < n; t += 64) {
             const uint4 w = reinterpret_cast<const uint4 *>(in.rec + src + t)[2];
-            sv[t] = __builtin_bit_cast(float, w.x); sr[t] = __builtin_bit_cast(float, w.y);
+            sv[t] = __builtin_bit_cast(float, w.x); sr[t] = __builtin_bit_cast(float, w.y); sz[t] = w.z;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -173,9 +174,9 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
             out.rewards[dst + t] = sr[t];
             out.advs[dst + t]    = sa[t];
             out.rets[dst + t]    = st[t];
-            const uint4 w = reinterpret_cast<const uint4 *>(in.rec + src + t)[2];
-            out.actions[dst + t] = (uint8_t)(w.z & 0xffu);
-            out.perms[dst + t]   = (int8_t)((w.z >> 8) & 0xffu);
+            const uint32_t wz = sz[t];                 // (the third 16 bytes of the record were read once, above)
+            out.actions[dst + t] = (uint8_t)(wz & 0xffu);
+            out.perms[dst + t]   = (int8_t)((wz >> 8) & 0xffu);
             reinterpret_cast<uint4 *>(out.logits)[dst + t] = reinterpret_cast<const uint4 *>(in.rec + src + t)[1];
         }
         if (n_cells == 16) {
@@ -196,7 +197,7 @@ int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t
                         float lambda, const CompactTraj &out, hipStream_t s)
 {
     if (E == 0) return TW_OK;
-    const size_t lds_bytes = (size_t)FIN_WAVES * 4 * in.t_pad * sizeof(float);
+    const size_t lds_bytes = (size_t)FIN_WAVES * 5 * in.t_pad * sizeof(float);
     if (lds_bytes > 64 * 1024) { set_error("finalize: t_pad %d too large for the LDS tile", in.t_pad); return TW_ERR_UNSUPPORTED; }
     uint64_t blocks = (E + FIN_WAVES - 1) / FIN_WAVES;
     if (blocks > 256ull * 16) blocks = 256ull * 16;   // grid-stride the rest
