@@ -30,7 +30,7 @@ import numpy as np
 
 FLOP_PER_RECORD = {16: 272_896, 9: 269_312}
 BYTES_PER_RECORD = {16: 58, 9: 51}
-PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0}     # MI355X_MICROARCH.md: f32 MFMA (=vector) / dense f16 MFMA
+PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0, "fp16x2": 2500.0}     # MI355X_MICROARCH.md: f32 MFMA (=vector) / dense f16 MFMA
 
 
 def measured_traffic_per_record(kernel="rollout_f32"):
@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--envs", type=int, default=262_144, help="episodes per GPU per step")
     ap.add_argument("--puzzle", type=int, default=15, choices=[8, 15])
     ap.add_argument("--difficulty", type=int, default=128)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "fp16x2"])
     ap.add_argument("--no-twists", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -201,7 +201,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16",
+            "dtype": {"fp32": "f32", "fp16": "f16", "fp16x2": "f16x2 (f32-equivalent: two f16 terms per operand)"}[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": f"Puzzle-{args.puzzle} PPO rollout + GAE + merge: {args.envs} envs/GPU, difficulty {args.difficulty} "

@@ -50,7 +50,8 @@ enum {
 /* arithmetic of the policy forward inside the collectors */
 enum {
     TW_PREC_F32_EXACT = 0,  /* f32 MFMA, k-ordered fma chain: bit-equal to the oracle      */
-    TW_PREC_F16       = 1   /* fp16-input MFMA, f32 accumulate (throughput mode)           */
+    TW_PREC_F16       = 1,  /* fp16-input MFMA, f32 accumulate (throughput mode)           */
+    TW_PREC_F16X2     = 2   /* f32 operands split into two f16 terms each: f32-equivalent  */
 };
 
 int         tw_abi_version(void);

@@ -23,7 +23,10 @@ HEADERS = [os.path.join(CSRC, "tw_common.hpp"), os.path.join(CSRC, "tw_engine.hp
            os.path.join(ROOT, "include", "twisterl_hip.h")]
 
 # -ffp-contract=off: the numeric spec allows only the explicit fma() calls
+# -pragma-unroll-threshold: the pinned MFMA schedules are fully unrolled position loops whose bodies call constexpr
+# schedule functions; the default limit (16K IR instructions before folding) would leave them as real loops
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
+         "-mllvm", "-pragma-unroll-threshold=400000",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -320,6 +320,10 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     const Seg s_st16 = seg(f16_ok ? (size_t)NKT * SP16 * 1024 : 0), s_hd16 = seg(f16_ok ? (size_t)NT * 2048 : 0),
               s_eb16 = seg((size_t)NKT * 32 * 4), s_b116 = seg((size_t)NT * 32 * 4), s_bh16 = seg(8 * 4),
               s_src16 = seg(srcmap.size()), s_vm16 = seg(vmap.size());
+    // split-f16 image (EngineS, tw_engine16x2.hpp)
+    const uint32_t SPS = f16_ok ? ((std::max(nc16 + 2 * NT, 4 * NT) + 3) / 4 * 4) : 0;
+    const bool split_ok = f16_ok && NKT >= 2;
+    const Seg s_stS = seg(split_ok ? (size_t)(2 * NKT + 1) * SPS * 1024 : 0), s_t0S = seg(split_ok ? (size_t)2 * nc16 * 1024 : 0);
     std::vector<uint8_t> img(cur, 0);
     float *emb = reinterpret_cast<float *>(img.data() + s_emb.off);
     memcpy(emb, d->emb_vectors, (size_t)OS * E * 4);
@@ -407,6 +411,47 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
         bh16[4] = v.bias[0];
         memcpy(img.data() + s_src16.off, srcmap.data(), srcmap.size());
         memcpy(img.data() + s_vm16.off, vmap.data(), vmap.size());
+        if (split_ok) {
+            // x = x_hi + x_lo with both terms binary16, operands pre-scaled by 16 (exact): hi = f16(16x), lo = f16(16x - hi)
+            auto put2 = [&](size_t off_hi, size_t off_lo, float x) {
+                const float sx = 16.0f * x;
+                const _Float16 hi = (_Float16)sx, lo = (_Float16)(sx - (float)hi);
+                memcpy(img.data() + off_hi, &hi, 2); memcpy(img.data() + off_lo, &lo, 2);
+            };
+            for (uint32_t kt = 0; kt < NKT; ++kt) {
+                const size_t bhi = s_stS.off + (size_t)(2 * kt) * SPS * 1024, blo = bhi + (size_t)SPS * 1024;
+                const uint32_t kte = (kt + 1) % NKT;
+                for (uint32_t l = 0; l < 64; ++l)
+                    for (uint32_t jx = 0; jx < 8; ++jx) {
+                        const uint32_t hh2 = l >> 5, row = l & 31, o = l * 16 + jx * 2;
+                        for (uint32_t c2 = 0; c2 < nc16; ++c2) {
+                            const uint32_t val = 8 * hh2 + jx;
+                            const float x = (c2 < n16 && val < n16) ? d->emb_vectors[(size_t)(c2 * n16 + val) * E + 32 * kte + row] : 0.0f;
+                            put2(bhi + (size_t)c2 * 1024 + o, blo + (size_t)c2 * 1024 + o, x);
+                            if (kt == NKT - 1)   // tile 0 also goes to the resident copy [hi chunks | lo chunks]
+                                put2(s_t0S.off + (size_t)c2 * 1024 + o, s_t0S.off + (size_t)(nc16 + c2) * 1024 + o, x);
+                        }
+                        for (uint32_t ht = 0; ht < NT; ++ht)
+                            for (uint32_t m = 0; m < 2; ++m) {
+                                const uint32_t k = 32 * kt + rho(8 * m + jx, hh2);
+                                const size_t po = (size_t)(nc16 + ht * 2 + m) * 1024 + o;
+                                put2(bhi + po, blo + po, c.weights[(size_t)k * H + 32 * ht + row]);
+                            }
+                    }
+            }
+            const size_t bh = s_stS.off + (size_t)(2 * NKT) * SPS * 1024;
+            for (uint32_t ht = 0; ht < NT; ++ht)
+                for (uint32_t m = 0; m < 2; ++m)
+                    for (uint32_t l = 0; l < 64; ++l)
+                        for (uint32_t jx = 0; jx < 8; ++jx) {
+                            const uint32_t hh2 = l >> 5, row = l & 31, hid = 32 * ht + rho(8 * m + jx, hh2);
+                            float x = 0.0f;
+                            if (row < 8) { if ((row & 3) < A) x = a.weights[(size_t)hid * A + (row & 3)]; }
+                            else if (row == 8 || row == 12) x = v.weights[hid];
+                            const size_t po = (size_t)(ht * 2 + m) * 1024 + l * 16 + jx * 2;
+                            put2(bh + po, bh + (size_t)2 * NT * 1024 + po, x);
+                        }
+        }
     }
 
     tw_policy *pol = new tw_policy();
@@ -441,6 +486,7 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     pd.b1img16 = reinterpret_cast<const float *>(base + s_b116.off);
     pd.bh16 = reinterpret_cast<const float *>(base + s_bh16.off);
     pd.srcmap16 = base + s_src16.off; pd.vmap16 = base + s_vm16.off;
+    pd.stageS = split_ok ? base + s_stS.off : nullptr; pd.t0S = split_ok ? base + s_t0S.off : nullptr;
     pol->n16 = n16; pol->sp16 = SP16;
     return pol;
 }
@@ -470,6 +516,7 @@ extern "C" int tw_policy_update_device(tw_policy *p, const float *emb_w, const f
         f16 ? (unsigned long long)a.NKT * 32 : 0ull, f16 ? (unsigned long long)a.NT * 32 : 0ull, f16 ? 8ull : 0ull};
     unsigned long long run = 0;
     for (int i = 0; i < 16; ++i) { run += cnt[i]; a.seg_end[i] = run; }
+    p->dev.stageS = nullptr; p->dev.t0S = nullptr;      // the split-f16 image is built on the host only: not valid after a device update
     return launch_policy_sync(a, current_stream());
 }
 
@@ -668,7 +715,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
         set_error("Something went wrong. No data in collected data chunks to merge. ");   // collector.rs:41
         return TW_ERR_EMPTY;
     }
-    if (prm->precision != TW_PREC_F32_EXACT && prm->precision != TW_PREC_F16) { set_error("tw_ppo_collect: unknown precision %u", prm->precision); return TW_ERR_INVALID; }
+    if (prm->precision > TW_PREC_F16X2) { set_error("tw_ppo_collect: unknown precision %u", prm->precision); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
 
     RolloutArgs ra{};
@@ -703,8 +750,9 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
     TW_HIP(hipEventRecord(ev.ev[0], s));
-    rc = prm->precision == TW_PREC_F16 ? launch_rollout_f16(ra, s, &st.rollout_blocks, &st.rollout_threads)
-                                       : launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads);
+    rc = prm->precision == TW_PREC_F16     ? launch_rollout_f16(ra, s, &st.rollout_blocks, &st.rollout_threads)
+         : prm->precision == TW_PREC_F16X2 ? launch_rollout_f16x2(ra, s, &st.rollout_blocks, &st.rollout_threads)
+                                           : launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads);
     if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[1], s));
     rc = launch_scan(ra.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);

@@ -270,6 +270,9 @@ struct PolicyDev {
     const float   *bh16;      // [8]: action bias 0..3, value bias 4
     const uint8_t *srcmap16;  // [(n_perms+1)][16]: source cell of target chunk c under twist p-1 (p = 0: identity)
     const uint8_t *vmap16;    // [(n_perms+1)][16][16]: value of the twisted id inside chunk c, 15-bit clean (< 16)
+    // split-f16 image (TW_PREC_F16X2, EngineS in tw_engine16x2.hpp): operands x16, hi / lo binary16 terms
+    const uint8_t *stageS;    // [2*emb/32 + 1][SP KiB]: stage 2k = [T_hi(k+1) | W1_hi(k)], 2k+1 = lo terms, last = [head_hi | head_lo]
+    const uint8_t *t0S;       // [2*f16_nc KiB]: table tile 0, hi chunks then lo chunks
 };
 
 // padded (episode-major) trajectory workspace written by the rollout / MCTS kernels: ONE 48-byte
@@ -355,6 +358,7 @@ inline int waves_per_group(uint64_t n)
 // kernel launchers (each returns a TW_* status)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+int launch_rollout_f16x2(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, uint64_t *ep_start,
                 uint64_t *total /*device*/, void *scratch, size_t scratch_bytes, hipStream_t s);
 size_t scan_scratch_bytes(uint64_t n_episodes);

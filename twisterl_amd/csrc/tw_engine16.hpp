@@ -55,6 +55,7 @@ struct Engine16 {
     static constexpr int SP     = NC + 2 * NHT;              // 1-KiB pieces per stage
     static constexpr int NOPS   = (SP + NW - 1) / NW;        // DMA ops per wave per stage (one piece each)
     static constexpr int SBYTES = NOPS * NW * 1024;          // stage image / ring slot, padded to whole rounds of NW pieces
+    static constexpr float OUT_SCALE = 1.0f;                 // head accumulator -> logit - bias
     // LDS map (small tables first: their offsets fit the 16-bit ds offset field)
     static constexpr uint32_t O_OH = 0, O_SRC = 160, O_VMAP = O_SRC + (E16_MAXP + 1) * 16, O_ACT = O_VMAP + (E16_MAXP + 1) * 256,
                               O_OHB = O_ACT + 32, O_BH = O_OHB + 2 * (E16_MAXP + 1) * 256, O_B1 = O_BH + 64, O_EBIAS = O_B1 + NHT * 128, O_HEAD = O_EBIAS + E16_MAX_KT * 128,

@@ -6,7 +6,7 @@
 // episodes; each lane carries the state of TWO episodes (column j of tile 0 and of tile 1); lane half h
 // samples, records and draws the twist for tile h and hands action and twist to the other half with one
 // cross-half shuffle each.
-#include "tw_engine16.hpp"
+#include "tw_engine16x2.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -17,10 +17,9 @@ namespace tw {
 __device__ unsigned long long g_stamps16[8];
 #endif
 
-template <int NHT, int NC>
+template <class Eng, int NC>
 __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a)
 {
-    using Eng = Engine16<NHT, NC>;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds16[];
     Eng eng;
     eng.begin1(a.pol, lds16);
@@ -93,8 +92,8 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
         // (everything below is select-based: one wave per SIMD has nothing to hide a branch behind)
         float lg[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lg[i] = (hh ? out1[i] : out0[i]) + bh[i];
-        const float value = (hh ? out1[4] : out0[4]) + bh[4];
+        for (int i = 0; i < 4; ++i) lg[i] = (hh ? out1[i] : out0[i]) * Eng::OUT_SCALE + bh[i];
+        const float value = (hh ? out1[4] : out0[4]) * Eng::OUT_SCALE + bh[4];
         PuzzleLane mine;
         mine.board = hh ? st1.board : st0.board; mine.zx = hh ? st1.zx : st0.zx; mine.zy = hh ? st1.zy : st0.zy;
         mine.depth = hh ? st1.depth : st0.depth;
@@ -138,17 +137,15 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
     eng.end();
 }
 
-template <int NHT, int NC>
-static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+template <class Eng, int NC>
+static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads, size_t lds_bytes)
 {
-    using Eng = Engine16<NHT, NC>;
     const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout16: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = engine16_lds_bytes<NHT, NC>();
     if (lds_bytes > 159 * 1024) { set_error("rollout16: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f16_kernel<NHT, NC>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f16_kernel<Eng, NC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
@@ -156,7 +153,7 @@ static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint3
     static const unsigned long long zeros[8] = {};
     if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps16), zeros, sizeof(zeros)));
 #endif
-    hipLaunchKernelGGL((rollout_f16_kernel<NHT, NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((rollout_f16_kernel<Eng, NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
@@ -173,18 +170,30 @@ static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint3
     return TW_OK;
 }
 
-template <int NHT>
+template <int NHT, bool SPLIT>
 static int launch16_nc(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    switch (a.pol.f16_nc) {
-        case 4:  return launch16<NHT, 4>(a, s, blocks, threads);
-        case 9:  return launch16<NHT, 9>(a, s, blocks, threads);
-        case 16: return launch16<NHT, 16>(a, s, blocks, threads);
-        default: set_error("rollout16: bad chunk count %d", a.pol.f16_nc); return TW_ERR_UNSUPPORTED;
+    if constexpr (SPLIT) {
+        switch (a.pol.f16_nc) {
+            case 4:  return launch16<EngineS<NHT, 4>, 4>(a, s, blocks, threads, engineS_lds_bytes<NHT, 4>());
+            case 9:  return launch16<EngineS<NHT, 9>, 9>(a, s, blocks, threads, engineS_lds_bytes<NHT, 9>());
+            case 16: return launch16<EngineS<NHT, 16>, 16>(a, s, blocks, threads, engineS_lds_bytes<NHT, 16>());
+            default: break;
+        }
+    } else {
+        switch (a.pol.f16_nc) {
+            case 4:  return launch16<Engine16<NHT, 4>, 4>(a, s, blocks, threads, engine16_lds_bytes<NHT, 4>());
+            case 9:  return launch16<Engine16<NHT, 9>, 9>(a, s, blocks, threads, engine16_lds_bytes<NHT, 9>());
+            case 16: return launch16<Engine16<NHT, 16>, 16>(a, s, blocks, threads, engine16_lds_bytes<NHT, 16>());
+            default: break;
+        }
     }
+    set_error("rollout16: bad chunk count %d", a.pol.f16_nc);
+    return TW_ERR_UNSUPPORTED;
 }
 
-int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+template <bool SPLIT>
+static int launch_rollout_16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     if (a.pol.f16_nc == 0) {
         set_error("precision f16: this policy has no f16 image (needs obs ids of the form cell*n+tile with n <= 16, at most %d "
@@ -192,20 +201,24 @@ int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
         return TW_ERR_UNSUPPORTED;
     }
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
-        a.pol.emb % 32 != 0 || a.pol.emb < 32 || a.pol.emb > 32 * E16_MAX_KT || a.env.n_cells > a.pol.f16_nc || a.out.t_pad < a.env.depth0 + 1) {
-        set_error("rollout16: unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d)",
-                  a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad);
+        a.pol.emb % 32 != 0 || a.pol.emb < (SPLIT ? 64 : 32) || a.pol.emb > 32 * E16_MAX_KT || a.env.n_cells > a.pol.f16_nc ||
+        a.out.t_pad < a.env.depth0 + 1 || (SPLIT && (!a.pol.stageS || !a.pol.t0S))) {
+        set_error("rollout16: unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d split=%d)",
+                  a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad, (int)SPLIT);
         return TW_ERR_UNSUPPORTED;
     }
     switch (a.pol.hidden) {
-        case 32:  return launch16_nc<1>(a, s, blocks, threads);
-        case 64:  return launch16_nc<2>(a, s, blocks, threads);
-        case 128: return launch16_nc<4>(a, s, blocks, threads);
-        case 256: return launch16_nc<8>(a, s, blocks, threads);
+        case 32:  return launch16_nc<1, SPLIT>(a, s, blocks, threads);
+        case 64:  return launch16_nc<2, SPLIT>(a, s, blocks, threads);
+        case 128: return launch16_nc<4, SPLIT>(a, s, blocks, threads);
+        case 256: return launch16_nc<8, SPLIT>(a, s, blocks, threads);
         default:
             set_error("rollout16: hidden size %d not in {32,64,128,256}", a.pol.hidden);
             return TW_ERR_UNSUPPORTED;
     }
 }
+
+int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads) { return launch_rollout_16<false>(a, s, blocks, threads); }
+int launch_rollout_f16x2(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads) { return launch_rollout_16<true>(a, s, blocks, threads); }
 
 }  // namespace tw
