@@ -34,7 +34,7 @@ __host__ __device__ constexpr size_t engineS_lds_bytes()
 
 template <int NHT, int NC>
 struct EngineS {
-    static constexpr int NW = 4, THREADS = 256, EPB = 256, D = 3;
+    static constexpr int NW = 4, THREADS = 256, EPB = 256, D = 2;
     static constexpr int NM0    = 2 * NHT;                   // W1 (or head) chunks per image
     static constexpr int SP     = engineS_pieces<NHT, NC>();
     static constexpr int NOPS   = (SP + NW - 1) / NW;
@@ -46,7 +46,7 @@ struct EngineS {
     static_assert(O_RING + 3 * SBYTES == engineS_lds_bytes<NHT, NC>(), "LDS map");
 
     struct Pipe { h16x8 a[D], x0[D], x1[D]; f32x16 eb; };
-    struct OneHots { uint32_t a0[NC], a1[NC]; };
+    struct OneHots { uint32_t a0[(NC + 3) / 4], a1[(NC + 3) / 4]; };   // byte c = LDS address of the one-hot fragment of chunk c (tile 0 / 1)
     struct Frags { h16x8 h0[2], h1[2], l0[2], l1[2]; };      // hi / lo B fragments (k-steps 0,1) of tile 0 / tile 1
 
     PolicyDev pol;
@@ -108,18 +108,27 @@ struct EngineS {
     __device__ __forceinline__ void begin2() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __device__ __forceinline__ void end() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-    __device__ __forceinline__ void onehots(uint64_t board, int perm, uint32_t (&w)[NC]) const
+    // one-hot fragment addresses packed four to a register (this mode is matrix-bound: the byte extract next to each
+    // read is free, 2*NC address registers are not)
+    __device__ __forceinline__ void onehots(uint64_t board, int perm, uint32_t (&w)[(NC + 3) / 4]) const
     {
+        static_assert(O_OH == 0, "the byte table holds LDS addresses");
         const int pi = perm + 1;
         typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
         const u32v4 sr = *(const __attribute__((address_space(3))) u32v4 *)(L + O_SRC + pi * 16);
         const uint32_t srw[4] = {sr[0], sr[1], sr[2], sr[3]};
         const uint32_t tb = O_OHB + (uint32_t)(hh * (E16_MAXP + 1) + pi) * 256u;
 #pragma unroll
+        for (int q = 0; q < (NC + 3) / 4; ++q) w[q] = 0u;
+#pragma unroll
         for (int c = 0; c < NC; ++c) {
             const uint32_t src = (srw[c >> 2] >> (8 * (c & 3))) & 0xffu;
-            w[c] = L[tb + c * 16 + nib(board, (int)src)];
+            w[c >> 2] |= (uint32_t)L[tb + c * 16 + nib(board, (int)src)] << (8 * (c & 3));
         }
+    }
+    __device__ __forceinline__ h16x8 ldoh(const uint32_t (&w)[(NC + 3) / 4], int c) const
+    {
+        return ld8(O_OH + ((w[c >> 2] >> (8 * (c & 3))) & 0xffu));
     }
     __device__ __forceinline__ void act_perm(int perm, float (&lg)[4]) const
     {
@@ -201,9 +210,10 @@ struct EngineS {
     // NEXT: 0 no prefetch for the following stage, 1 it has embedding pairs, 2 it has none.  The following stage of a hi
     // stage is the lo stage of the same tile; of a lo stage (and of the prologue) the next hi stage.
     template <int KIND, bool HAVE_E, bool FIRST, int NEXT, bool STREAM>
-    __device__ __forceinline__ void phase(int ke_next, uint32_t baseE, uint32_t baseM, uint32_t nbase, int sg, int s2, const OneHots &oh,
+    __device__ __forceinline__ void phase(int ke_next, uint32_t baseE, uint32_t baseM, uint32_t nbase, int sg, int s2, const OneHots &oh_in,
                                           f32x16 (&acc0)[NHT], f32x16 (&acc1)[NHT], f32x16 &e0, f32x16 &e1, const Frags &Bc, Frags &Bn, Pipe &pp)
     {
+        TW_STAMP(t_in);
         using SH = Shape<KIND, HAVE_E>;
         using S  = typename SH::S;
         using SN = typename Shape<KIND == 0 ? 1 : 0, NEXT == 1>::S;
@@ -214,6 +224,9 @@ struct EngineS {
         constexpr int SPREAD = NP * 5 / 8 > 0 ? NP * 5 / 8 : 1;                  // all DMA ops within the first 5/8 of the phase
         const uint8_t *g_stage = stage_ptr(sg);
         const uint32_t m0_slot = slot_m0(s2);
+        OneHots oh = oh_in;
+#pragma unroll
+        for (int q = 0; q < (NC + 3) / 4; ++q) asm volatile("" : "+v"(oh.a0[q]), "+v"(oh.a1[q]));
         h16x8 A[NP + D], X0[NP + D], X1[NP + D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { A[d] = pp.a[d]; X0[d] = pp.x0[d]; X1[d] = pp.x1[d]; }
@@ -237,11 +250,11 @@ struct EngineS {
             // ---- operand reads of position p + D
             if constexpr (pn < NP) {
                 constexpr int cd = S::code(pn), ix = cd >> 1;
-                if constexpr (cd & 1) { X0[pn] = ld8(oh.a0[ix % NC]); X1[pn] = ld8(oh.a1[ix % NC]); A[pn] = ld8(baseE + ix * 1024); }
+                if constexpr (cd & 1) { X0[pn] = ldoh(oh.a0, ix % NC); X1[pn] = ldoh(oh.a1, ix % NC); A[pn] = ld8(baseE + ix * 1024); }
                 else A[pn] = ld8(baseM + (KIND == 0 ? ix >> 1 : ix) * 1024);
             } else if constexpr (NEXT != 0) {
                 constexpr int cd = SN::code(pn - NP), ix = cd >> 1;
-                if constexpr (cd & 1) { X0[pn] = ld8(oh.a0[ix]); X1[pn] = ld8(oh.a1[ix]); A[pn] = ld8(nbase + ix * 1024); }
+                if constexpr (cd & 1) { X0[pn] = ldoh(oh.a0, ix); X1[pn] = ldoh(oh.a1, ix); A[pn] = ld8(nbase + ix * 1024); }
                 else A[pn] = ld8(nbase + (NC + (KIND == 0 ? ix : ix >> 1)) * 1024);     // the stage after a hi stage is a lo stage (M index = chunk)
             }
             if constexpr (NEXT != 0 && KIND != 0 && p == NP - 1) pp.eb = ld16(O_EBIAS + (uint32_t)(ke_next * 2 + hh) * 64u);
@@ -281,8 +294,12 @@ struct EngineS {
         if constexpr (STREAM) {
             constexpr int issued = NP > 0 ? dma_upto(NP - 1, SPREAD) : 0;
             sfor<NOPS - issued>([&](auto oc) { stream_op(g_stage, m0_slot, issued + decltype(oc)::value); });
+            TW_STAMP(t_b);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TW_STAMP(t_w);
             __syncthreads();
+            TW_STAMP(t_s);
+            TW_ACC(2, t_in, t_b); TW_ACC(3, t_b, t_w); TW_ACC(4, t_w, t_s);
         }
     }
     // DMA ops issued up to and including position p (op o goes to the first position p with o*SPREAD/NOPS <= p)
@@ -313,12 +330,15 @@ struct EngineS {
         // prologue: embedding tile 0 (hi then lo chunks of the resident copy)
         pp.eb = ld16(O_EBIAS + (uint32_t)hh * 64u);
 #pragma unroll
-        for (int d = 0; d < D; ++d) { pp.x0[d] = ld8(oh.a0[d]); pp.x1[d] = ld8(oh.a1[d]); pp.a[d] = ld8(O_T0 + lo + d * 1024); }
+        for (int d = 0; d < D; ++d) { pp.x0[d] = ldoh(oh.a0, d); pp.x1[d] = ldoh(oh.a1, d); pp.a[d] = ld8(O_T0 + lo + d * 1024); }
         phase<2, true, false, 1, false>(tile_of(1), O_T0 + lo, 0, slot_base(s0), 0, 0, oh, acc0, acc1, e0, e1, Fa, Fa, pp);
-        // one embedding tile = a hi stage and a lo stage; `have_e`: the embedding part computes tile kt+1
-        auto tile = [&](auto first, auto have_e, auto next_e, int kt, const Frags &c, Frags &n) {
+        // one embedding tile = a hi stage and a lo stage; `have_e`: the embedding part computes tile kt+1.  ONE steady
+        // instance (plus the first and the last tile): the whole per-timestep code has to stay inside the 64 KiB
+        // instruction cache -- with parity / look-ahead variants of the tile it did not, and ran 40x slower.  The next
+        // fragments are therefore copied (32 registers per tile) instead of ping-ponged, and every lo stage prefetches
+        // as if the next tile had an embedding part (the last tile fetches its own first operands).
+        auto tile = [&](auto first, auto have_e, int kt, const Frags &c, Frags &n) {
             constexpr bool HE = decltype(have_e)::value;
-            constexpr int  NX = decltype(next_e)::value ? 1 : 2;
             {
                 const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
                 phase<0, HE, decltype(first)::value, HE ? 1 : 2, true>(0, slot_base(s0), slot_base(s0) + NC * 1024, slot_base(s1), wrap(q + 2), s2,
@@ -327,29 +347,27 @@ struct EngineS {
             }
             {
                 const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
-                phase<1, HE, false, HE ? NX : 0, true>(tile_of(kt + 2), slot_base(s0), slot_base(s0) + NC * 1024, slot_base(s1), wrap(q + 2), s2,
-                                                        oh, acc0, acc1, e0, e1, c, n, pp);
+                phase<1, HE, false, HE ? 1 : 0, true>(tile_of(kt + 2), slot_base(s0), slot_base(s0) + NC * 1024, slot_base(s1), wrap(q + 2), s2,
+                                                       oh, acc0, acc1, e0, e1, c, n, pp);
                 s0 = s1; ++q;
             }
         };
-        // tiles 0 .. n_kt-2 have an embedding part (tile kt+1); the fragments ping-pong between Fa and Fb
         using T = std::true_type; using F = std::false_type;
-        if (n_kt == 2) tile(T{}, T{}, F{}, 0, Fa, Fb);
-        else           tile(T{}, T{}, T{}, 0, Fa, Fb);
-        int kt = 1;
-        for (; kt + 2 < n_kt; kt += 2) {
-            tile(F{}, T{}, T{}, kt, Fb, Fa);
-            if (kt + 3 < n_kt) tile(F{}, T{}, T{}, kt + 1, Fa, Fb);
-            else               tile(F{}, T{}, F{}, kt + 1, Fa, Fb);
+        tile(T{}, T{}, 0, Fa, Fb);
+        Fa = Fb;
+        for (int kt = 1; kt + 1 < n_kt; ++kt) {
+            tile(F{}, T{}, kt, Fa, Fb);
+            Fa = Fb;
         }
-        if (kt + 1 < n_kt) {                                        // kt == n_kt - 2 (odd count): its embedding tile is the last one
-            tile(F{}, T{}, F{}, kt, Fb, Fa);
-            Fb = Fa;
-            ++kt;
+        {   // last tile: common layer only (n_kt >= 2 is checked on the host)
+            const uint32_t bM = slot_base(s0) + NC * 1024;
+#pragma unroll
+            for (int d = 0; d < D; ++d) pp.a[d] = ld8(bM + (d >> 1) * 1024);
+            tile(F{}, F{}, n_kt - 1, Fa, Fb);
         }
-        tile(F{}, F{}, F{}, kt, Fb, Fa);                             // last tile: common layer only (n_kt >= 2 is checked on the host)
         // heads stage: [head_hi chunks | head_lo chunks]; per hidden tile: split relu(acc) and three products
         {
+            TW_STAMP(t_h0);
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s0 == 0 ? 2 : s0 - 1;
             const uint32_t bH = slot_base(s0);
             const uint8_t *g_stage = stage_ptr(wrap(q + 2));
@@ -379,8 +397,14 @@ struct EngineS {
                 }
             }
             out0 = h0; out1 = h1;
+#ifdef TW_ABLATE
+            asm volatile("" :: "v"(h0), "v"(h1));
+#endif
+            TW_STAMP(t_hb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            TW_STAMP(t_hs);
+            TW_ACC(5, t_h0, t_hb); TW_ACC(4, t_hb, t_hs);
             s0 = s1;
         }
         rp = s0;

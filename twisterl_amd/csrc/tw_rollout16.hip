@@ -21,6 +21,9 @@ template <class Eng, int NC>
 __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds16[];
+#ifdef TW_ABLATE
+    const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+#endif
     Eng eng;
     eng.begin1(a.pol, lds16);
 
@@ -131,6 +134,7 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
 #endif
     }
 #ifdef TW_ABLATE
+    eng.st[3] = __builtin_readcyclecounter() - t_kernel0;      // (slot 3 reused: whole wave lifetime)
     if (eng.lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps16[i], eng.st[i]);
 #endif
     if (v_own) a.out.ep_len[e_own] = len_own;
