@@ -545,7 +545,7 @@ def test_policy_update_from_torch_equals_rebuilding(tw, oracle, n2, emb, hidden,
     env = tw.env.Puzzle(w, w, 5, 2, 256)
     before = tw.collector.PPOCollector(64, 0.99, 0.95, 1).collect(env, pol, seed=3).to_numpy()
     pol.update_from_torch(state)
-    for prec in ("fp32", "fp16"):
+    for prec in ("fp32", "fp16", "fp16x2"):
         coll = tw.collector.PPOCollector(**{"num_episodes": 200, "gamma": 0.99, "lambda": 0.95, "num_cores": 1}, seed=3, precision=prec)
         a, b = coll.collect(env, pol, seed=3).to_numpy(), coll.collect(env, ref, seed=3).to_numpy()
         for k in a:

@@ -237,7 +237,7 @@ struct tw_policy {
     PolicyDev dev{};
     void *arena = nullptr;
     int device = -1;
-    uint32_t n16 = 0, sp16 = 0;      // f16 image geometry (tw_policy_update_device)
+    uint32_t n16 = 0, sp16 = 0, sps = 0;      // f16 / split-f16 image geometry (tw_policy_update_device)
 };
 
 namespace {
@@ -487,7 +487,7 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
     pd.bh16 = reinterpret_cast<const float *>(base + s_bh16.off);
     pd.srcmap16 = base + s_src16.off; pd.vmap16 = base + s_vm16.off;
     pd.stageS = split_ok ? base + s_stS.off : nullptr; pd.t0S = split_ok ? base + s_t0S.off : nullptr;
-    pol->n16 = n16; pol->sp16 = SP16;
+    pol->n16 = n16; pol->sp16 = SP16; pol->sps = split_ok ? SPS : 0;
     return pol;
 }
 
@@ -507,16 +507,18 @@ extern "C" int tw_policy_update_device(tw_policy *p, const float *emb_w, const f
     a.ba_nat = (float *)w(d.ba); a.wv_nat = (float *)w(d.wv); a.bv_nat = (float *)w(d.bv);
     a.stage16 = (uint8_t *)w(d.stage16); a.head16 = (uint8_t *)w(d.head16); a.ebias16 = (float *)w(d.ebias16);
     a.b1img16 = (float *)w(d.b1img16); a.bh16 = (float *)w(d.bh16);
+    a.stageS = (uint8_t *)w(d.stageS); a.t0S = (uint8_t *)w(d.t0S); a.SPS = (int)p->sps;
     const bool f16 = d.f16_nc != 0;
-    const unsigned long long cnt[16] = {
+    const bool split = f16 && p->sps != 0 && d.stageS && d.t0S;
+    const unsigned long long cnt[18] = {
         (unsigned long long)(a.OS + 2) * a.E, (unsigned long long)a.E * a.NQ * 128, (unsigned long long)(a.E / 16) * 21 * 256,
         (unsigned long long)a.H, (unsigned long long)a.H * 8, 8ull, (unsigned long long)a.E * a.H, (unsigned long long)a.H * a.A,
         (unsigned long long)a.A, (unsigned long long)a.H, 1ull,
         f16 ? (unsigned long long)a.NKT * a.SP16 * 512 : 0ull, f16 ? (unsigned long long)a.NT * 1024 : 0ull,
-        f16 ? (unsigned long long)a.NKT * 32 : 0ull, f16 ? (unsigned long long)a.NT * 32 : 0ull, f16 ? 8ull : 0ull};
+        f16 ? (unsigned long long)a.NKT * 32 : 0ull, f16 ? (unsigned long long)a.NT * 32 : 0ull, f16 ? 8ull : 0ull,
+        split ? (unsigned long long)(2 * a.NKT + 1) * a.SPS * 512 : 0ull, split ? (unsigned long long)2 * a.nc16 * 512 : 0ull};
     unsigned long long run = 0;
-    for (int i = 0; i < 16; ++i) { run += cnt[i]; a.seg_end[i] = run; }
-    p->dev.stageS = nullptr; p->dev.t0S = nullptr;      // the split-f16 image is built on the host only: not valid after a device update
+    for (int i = 0; i < 18; ++i) { run += cnt[i]; a.seg_end[i] = run; }
     return launch_policy_sync(a, current_stream());
 }
 

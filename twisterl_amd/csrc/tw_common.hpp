@@ -422,8 +422,9 @@ struct SyncArgs {
     // destinations (the policy's arena)
     float *emb_rows, *w1p, *t_img16, *b1_d, *wh8, *bh8, *w1_nat, *wa_nat, *ba_nat, *wv_nat, *bv_nat;
     uint8_t *stage16, *head16; float *ebias16, *b1img16, *bh16;
+    uint8_t *stageS, *t0S; int SPS;     // split-f16 images (tw_engine16x2.hpp); SPS = KiB per stage
     // element counts per segment (prefix sums in seg_end)
-    unsigned long long seg_end[16];
+    unsigned long long seg_end[18];
 };
 
 int launch_policy_sync(const SyncArgs &a, hipStream_t s);

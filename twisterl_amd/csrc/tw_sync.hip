@@ -13,7 +13,7 @@ __device__ inline int rho_d(int r, int hh) { return 8 * (r >> 2) + 4 * hh + (r &
 __global__ void __launch_bounds__(256) policy_sync_kernel(const SyncArgs a)
 {
     const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= a.seg_end[15]) return;
+    if (gid >= a.seg_end[17]) return;
     int seg = 0;
     while (gid >= a.seg_end[seg]) ++seg;
     const unsigned long long i = gid - (seg ? a.seg_end[seg - 1] : 0ull);
@@ -77,12 +77,49 @@ __global__ void __launch_bounds__(256) policy_sync_kernel(const SyncArgs a)
     case 13: { const int kt = (int)(i >> 5), hh = (int)((i >> 4) & 1), r = (int)(i & 15); a.ebias16[i] = a.emb_b[32 * kt + rho_d(r, hh)]; } break;
     case 14: { const int ht = (int)(i >> 5), hh = (int)((i >> 4) & 1), r = (int)(i & 15); a.b1img16[i] = a.b1[32 * ht + rho_d(r, hh)]; } break;
     case 15: a.bh16[i] = (int)i < A ? a.ba[i] : (i == 4 ? a.bv[0] : 0.0f); break;
+    case 16: case 17: {   // split-f16 images: x16, hi = f16(16x), lo = f16(16x - hi)
+        float v = 0.0f; bool want_lo;
+        if (seg == 16) {  // stageS [2*NKT+1][SPS KiB]
+            const int per = a.SPS * 512;
+            const int st = (int)(i / per), o = (int)(i % per), piece = o >> 9, l = (o >> 3) & 63, jx = o & 7, hh = l >> 5, row = l & 31;
+            if (st < 2 * a.NKT) {
+                const int kt = st >> 1;
+                want_lo = st & 1;
+                if (piece < a.nc16) {
+                    const int val = 8 * hh + jx, kte = (kt + 1) % a.NKT;
+                    if (piece < a.n16 && val < a.n16) v = T(piece * a.n16 + val, 32 * kte + row);
+                } else if (piece < a.nc16 + 2 * NT) {
+                    const int q = piece - a.nc16, ht = q >> 1, m = q & 1;
+                    v = W1(32 * kt + rho_d(8 * m + jx, hh), 32 * ht + row);
+                }
+            } else {      // heads stage: [hi chunks | lo chunks]
+                want_lo = piece >= 2 * NT;
+                const int g = want_lo ? piece - 2 * NT : piece;
+                if (g < 2 * NT) {
+                    const int ht = g >> 1, m = g & 1, hid = 32 * ht + rho_d(8 * m + jx, hh);
+                    if (row < 8) { if ((row & 3) < A) v = WA(hid, row & 3); }
+                    else if (row == 8 || row == 12) v = WV(hid);
+                }
+            }
+            const float sx = 16.0f * v;
+            const _Float16 hi = (_Float16)sx;
+            reinterpret_cast<_Float16 *>(a.stageS)[i] = want_lo ? (_Float16)(sx - (float)hi) : hi;
+        } else {          // t0S [2*nc16 KiB]: table tile 0, hi chunks then lo chunks
+            const int piece = (int)(i >> 9), l = (int)((i >> 3) & 63), jx = (int)(i & 7), hh = l >> 5, row = l & 31;
+            want_lo = piece >= a.nc16;
+            const int c2 = want_lo ? piece - a.nc16 : piece, val = 8 * hh + jx;
+            if (c2 < a.n16 && val < a.n16) v = T(c2 * a.n16 + val, row);
+            const float sx = 16.0f * v;
+            const _Float16 hi = (_Float16)sx;
+            reinterpret_cast<_Float16 *>(a.t0S)[i] = want_lo ? (_Float16)(sx - (float)hi) : hi;
+        }
+    } break;
     }
 }
 
 int launch_policy_sync(const SyncArgs &a, hipStream_t s)
 {
-    const unsigned long long n = a.seg_end[15];
+    const unsigned long long n = a.seg_end[17];
     hipLaunchKernelGGL(policy_sync_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     TW_HIP(hipGetLastError());
     return TW_OK;
