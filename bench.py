@@ -228,7 +228,7 @@ def main():
             #           records (scripts/acc_modes.py; the exact f32 mode is within 2e-8), tests allow BASELINE.json's 1e-5
             #   fp16:   f16-input forward (BASELINE.json config 2's "MLP policy fp16"), logits within 4e-5
             # env transitions / masks / rewards / sampling are bit-exact in every mode.
-            def side(prec):
+            def side_mode(prec):
                 try:
                     c = twisterl.collector.PPOCollector(**{"num_episodes": E_total, "gamma": 0.995, "lambda": 0.995, "num_cores": 32},
                                                         precision=prec)
@@ -242,8 +242,8 @@ def main():
                             "algorithmic_TFLOPs": n / 2 * FLOP_PER_RECORD[n2] / k / 1e12}
                 except Exception as e:   # the headline line must not depend on a side measurement
                     return {"error": str(e)}
-            out["f16x2_mode_f32_equivalent"] = side("fp16x2")
-            out["f16_input_mode"] = side("fp16")
+            out["f16x2_mode_f32_equivalent"] = side_mode("fp16x2")
+            out["f16_input_mode"] = side_mode("fp16")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds, args.cpu_threads)
         print(json.dumps(out), flush=True)
