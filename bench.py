@@ -170,12 +170,18 @@ def main():
     fence()
     t0 = time.perf_counter()
     records, ms_rollout = 0, []
+    trace = [] if os.environ.get("TW_BENCH_TRACE") else None     # per-step wall times on stderr (diagnostic)
     for i in range(args.steps):
+        ts = time.perf_counter()
         n, st = step(args.warmup + i)
         records += n
         ms_rollout.append(st["ms_rollout"])
+        if trace is not None:
+            trace.append(round((time.perf_counter() - ts) * 1e3, 1))
     fence()
     dt = time.perf_counter() - t0
+    if trace is not None:
+        print(f"[bench trace] rank {rank}: ms per step {trace}", file=sys.stderr)
 
     rec_t = torch.tensor([float(records)], device="cuda")
     dt_t = torch.tensor([dt], device="cuda")

@@ -171,9 +171,9 @@ struct EngineS {
 
     // pair order: two embedding pairs per common-layer pair until the embedding pairs are used up, keeping the last
     // common-layer pairs for the shadow of the conversion; code(i) = 2*index + (1 if embedding pair)
-    template <int NE, int NM> struct Sched {
+    template <int NE, int NM, int KEEP_ = 8> struct Sched {
         static constexpr int NP = NE + NM;
-        static constexpr int KEEP = NM < 8 ? NM : 8;
+        static constexpr int KEEP = NM < KEEP_ ? NM : KEEP_;
         static constexpr int code(int i)
         {
             int e = 0, m = 0;
@@ -197,7 +197,7 @@ struct EngineS {
     template <int KIND, bool HAVE_E> struct Shape {
         static constexpr int NE = KIND == 2 ? 2 * NC : (HAVE_E ? NC : 0);
         static constexpr int NM = KIND == 0 ? 2 * NM0 : (KIND == 1 ? NM0 : 0);
-        using S = Sched<NE, NM>;
+        using S = Sched<NE, NM, KIND == 1 ? 12 : 8>;      // lo stage: more trailing pairs for the split of the finished tile
     };
 
     // compile-time position loop: every index below is a constant expression for the FRONT END (the pinned schedule must
