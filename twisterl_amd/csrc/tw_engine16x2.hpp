@@ -34,7 +34,7 @@ __host__ __device__ constexpr size_t engineS_lds_bytes()
 
 template <int NHT, int NC>
 struct EngineS {
-    static constexpr int NW = 4, THREADS = 256, EPB = 256, D = 2;
+    static constexpr int NW = 4, THREADS = 256, EPB = 256, D = 3;
     static constexpr int NM0    = 2 * NHT;                   // W1 (or head) chunks per image
     static constexpr int SP     = engineS_pieces<NHT, NC>();
     static constexpr int NOPS   = (SP + NW - 1) / NW;
