@@ -89,6 +89,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
     PuzzleLane leaf = st;                                 // state whose evaluation is pending
     unsigned long long evals = 0;
 
+    uint32_t obs_base[4];
+    obs_base_words(env.n_cells, obs_base);
+
     eng.begin2();
 
     while (__syncthreads_or(phase != PH_DONE ? 1 : 0)) {
@@ -216,10 +219,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
                         const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
                         const int action = sample_weighted(mp, 4, u32_to_unit(w.x));
                         const uint64_t rec = rec_base + (uint64_t)t;
-                        uint32_t pk[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                        for (int i = 0; i < NC; ++i)
-                            if (i < env.n_cells) pk[i >> 2] |= (uint32_t)(i * env.n_cells + (int)nib(st.board, i)) << (8 * (i & 3));
+                        uint32_t pk[4];
+                        obs_bytes(st.board, obs_base, pk);
                         store_rec(a.out.rec + rec, pk, mp, 0.0f, puzzle_reward(st, env), 0, -1);
                         if (puzzle_final(st, env)) { phase = PH_DONE; len = (uint32_t)t + 1u; break; }   // az.rs:84
                         puzzle_step(st, env, action);                                                   // az.rs:89

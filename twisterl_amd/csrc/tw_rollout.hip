@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
     uint32_t len = 0;
     const uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
 
+    uint32_t obs_base[4];
+    obs_base_words(env.n_cells, obs_base);
+
     eng.begin2();
     // (the barrier inside __syncthreads_or publishes the first two ring slots and the LDS constants)
 
@@ -88,10 +91,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
         if (alive) {
             if (h == 0) {
                 const uint64_t rec = rec_base + (uint64_t)t;
-                uint32_t pk[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int i = 0; i < NC; ++i)
-                    if (i < env.n_cells) pk[i >> 2] |= (uint32_t)(i * env.n_cells + (int)nib(st.board, i)) << (8 * (i & 3));
+                uint32_t pk[4];
+                obs_bytes(st.board, obs_base, pk);
                 store_rec(a.out.rec + rec, pk, lg, value, rew, action, perm);
             }
             if (puzzle_final(st, env)) { alive = false; len = (uint32_t)t + 1u; }
