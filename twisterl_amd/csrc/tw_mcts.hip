@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
 
             // run the search loop until a leaf needs the network or the move is finished
             bool resume_expand = (phase == PH_LEAF);
+            MctsNode cur; bool have_cur = false;      // record of `node` when it was just read by the descent
+            cur.board = 0; cur.value_sum = 0.0f; cur.visit = 0; cur.prior = 0.0f; cur.parent = NONE; cur.child_base = 0;
+            cur.n_children = 0; cur.action = 0; cur.depth = 0;
             for (;;) {
                 if (!resume_expand) {
                     if (it == S) {
@@ -228,31 +231,35 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
                         phase = PH_ROOT; leaf = st;
                         break;
                     }
-                    // descend to a leaf by UCB (search.rs:133-138, next :77-91, ucb :29-39)
+                    // descend to a leaf by UCB (search.rs:133-138, next :77-91, ucb :29-39).  The chosen child's record is
+                    // kept in registers: one dependent HBM round trip per level (its children) instead of two
                     node = 0;
+                    cur = nodes[0];
                     for (;;) {
-                        const MctsNode n = nodes[node];
-                        if (n.n_children == 0) break;
+                        if (cur.n_children == 0) break;
                         uint32_t best = NONE; float best_ucb = -__builtin_inff();
-                        const float sq = sqrtf((float)n.visit);
-                        for (int c = 0; c < n.n_children; ++c) {
-                            const MctsNode ch = nodes[n.child_base + c];
+                        MctsNode bestn = cur;
+                        const float sq = sqrtf((float)cur.visit);
+                        for (int c = 0; c < cur.n_children; ++c) {
+                            const MctsNode ch = nodes[cur.child_base + c];
                             const float q = ch.visit == 0 ? 0.0f : ch.value_sum / (float)ch.visit;
                             float d = sq / ((float)ch.visit + 1.0f);
                             d = a.C * d;
                             d = d * ch.prior;
                             const float u = q + d;
-                            if (u > best_ucb) { best = n.child_base + c; best_ucb = u; }
+                            if (u > best_ucb) { best = cur.child_base + c; best_ucb = u; bestn = ch; }
                         }
                         if (best == NONE) break;        // all-NaN UCB: the reference panics here
-                        node = best;
+                        node = best; cur = bestn;
                     }
                     value = 0.0f; expanded = 0;
+                    have_cur = true;
                 }
                 resume_expand = false;
                 // leaf phase (search.rs:143-160)
                 if (expanded < MED) {
-                    const MctsNode n = nodes[node];
+                    const MctsNode n = have_cur ? cur : nodes[node];
+                    have_cur = false;
                     const PuzzleLane s = lane_of(n, env);
                     value = puzzle_reward(s, env);                                   // :146
                     if (!puzzle_final(s, env)) { phase = PH_LEAF; leaf = s; break; } // :149-155 needs the network
