@@ -49,8 +49,6 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     flags = list(FLAGS)
     if os.environ.get("TW_ABLATE"):      # timing-only ablation variants of the rollout kernel (profiling aid)
         flags.append("-DTW_ABLATE")
-        if os.environ.get("TW_EXP"):     # numbered timing experiment inside the diagnostic build
-            flags.append("-DTW_EXP=" + str(int(os.environ["TW_EXP"])))
     objs = []
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     procs = []

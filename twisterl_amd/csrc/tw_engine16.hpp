@@ -75,11 +75,6 @@ struct Engine16 {
 #define TW_STAMP(var)
 #define TW_ACC(i, a, b)
 #endif
-#if defined(TW_ABLATE) && defined(TW_EXP)
-#define TW_EXP_IS(n) (TW_EXP == (n))     // numbered timing experiments of the diagnostic build (wrong results)
-#else
-#define TW_EXP_IS(n) false
-#endif
     uint8_t *lg_;                  // LDS base, generic
     uint32_t lds_u32, voff;        // LDS base as an M0 value; per-lane global byte offset of this wave's DMA piece
     lds_cu8 *L;                    // LDS base, address space 3
@@ -285,11 +280,7 @@ struct Engine16 {
             if (pn < NP) {
                 const int cd = S::code(pn), ix = cd >> 1;
                 if (cd & 1) {
-#if defined(TW_EXP) && (TW_EXP == 1 || TW_EXP == 3)      // timing experiment: no one-hot reads
-                    X0[pn] = X0[pn - D]; X1[pn] = X1[pn - D];
-#else
                     X0[pn] = ld8(oh.a0[ix]); X1[pn] = ld8(oh.a1[ix]);
-#endif
                     A[pn] = ld8(baseE + ix * 1024);
                 } else A[pn] = ld8(baseM + ix * 1024);
             } else if (NEXT != 0) {
@@ -315,9 +306,6 @@ struct Engine16 {
             // ---- side work A: DMA
             if (STREAM) {
                 constexpr int SPREAD = NP * 5 / 8 > 0 ? NP * 5 / 8 : 1;          // all ops within the first 5/8 of the phase
-#if defined(TW_EXP) && (TW_EXP == 2 || TW_EXP == 3)      // timing experiment: no weight streaming
-                op = NOPS;
-#endif
                 while (op < NOPS && op * SPREAD / NOPS <= p) { stream_op(g_stage, m0_slot, op); ++op; }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -329,11 +317,7 @@ struct Engine16 {
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- side work B: conversion of the embedding tile computed in this phase
-#if defined(TW_EXP) && TW_EXP == 3      // timing experiment: no conversion in the shadow
-            if (false) {
-#else
             if (E_P && M_P && p > LE + 1) {
-#endif
                 const int lim = (p - LE - 1) * UPP < 16 ? (p - LE - 1) * UPP : 16;
                 for (; udone < lim; ++udone) unit(udone);
             }
