@@ -231,7 +231,7 @@ def main():
         if world == 1 and args.precision == "fp32":
             # side measurements, not the headline: the same workload in the two f16-matrix-core modes.
             #   fp16x2: every f32 operand as two f16 terms -- logits within 5e-8 of the reference f32 arithmetic on sampled
-            #           records (scripts/acc_modes.py; the exact f32 mode is within 2e-8), tests allow BASELINE.json's 1e-5
+            #           records (tests/tools/acc_modes.py; the exact f32 mode is within 2e-8), tests allow BASELINE.json's 1e-5
             #   fp16:   f16-input forward (BASELINE.json config 2's "MLP policy fp16"), logits within 4e-5
             # env transitions / masks / rewards / sampling are bit-exact in every mode.
             def side_mode(prec):
