@@ -611,3 +611,27 @@ def test_f16x2_full_size_sample(tw, oracle):
     if np.array_equal(a["ep_len"], c["ep_len"]):
         assert float(np.mean(a["actions"] == c["actions"])) >= 0.999
         np.testing.assert_allclose(a["rets"], c["rets"], atol=1e-5, rtol=1e-5) if np.array_equal(a["actions"], c["actions"]) else None
+
+
+def test_persistent_lane_mode_bit_exact(tw, oracle):
+    """More episodes than resident lanes (65,536): the f32 kernel runs 256 persistent workgroups whose lanes take the next
+    episode from a queue when theirs is over (ragged lengths: Puzzle-8, one scramble move, depth 24).  Which lane runs an
+    episode must not matter: bit-identical to the oracle, and to the non-persistent launch."""
+    import os
+    gp, op = _pair(oracle, 9, 5, 32, 32, twists=True)
+    E = 70_000
+    genv, oenv = tw.env.Puzzle(3, 3, 1, 24, 256), oracle.Puzzle(3, 3, 1, 24, 256)
+    coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32}, seed=17, merge_order=True)
+    g = coll.collect(genv, gp, seed=17)
+    o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=17, arith=oracle.ARITH_CHAIN, det_log=True, merge_order=True, num_threads=8)
+    _assert_same_collect(g, o, 9)
+    L = g.to_numpy()["ep_len"]
+    assert L.min() < L.max() and L.mean() < 0.8 * L.max()      # the lengths are indeed ragged
+    os.environ["TW_NO_PERSIST"] = "1"
+    try:
+        h = coll.collect(genv, gp, seed=17).to_numpy()
+    finally:
+        del os.environ["TW_NO_PERSIST"]
+    a = g.to_numpy()
+    for k in a:
+        assert np.array_equal(a[k], h[k]), k

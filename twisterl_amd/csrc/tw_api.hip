@@ -739,8 +739,10 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     const uint64_t R = E * (uint64_t)t_pad;
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    // persistent-lane mode of the f32 kernel (more episodes than resident lanes): start boards + episode queue
+    const bool persist = prm->precision == TW_PREC_F32_EXACT && E > rollout_f32_resident_episodes() && !getenv("TW_NO_PERSIST");
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
-                 o_scan = seg(scan_scratch_bytes(E));
+                 o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     void *wsp = nullptr;
     rc = ws_reserve(cur, &wsp); if (rc) return rc;
     uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
@@ -751,6 +753,14 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
 
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
+    if (persist) {
+        ra.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
+        ra.queue = reinterpret_cast<unsigned int *>(ws + o_queue);
+        const unsigned int first = (unsigned int)rollout_f32_resident_episodes();      // episodes handed out at launch
+        TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
+        rc = launch_init_boards(ra.env, ra.seed, ra.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
+        if (rc) return rc;
+    }
     TW_HIP(hipEventRecord(ev.ev[0], s));
     rc = prm->precision == TW_PREC_F16     ? launch_rollout_f16(ra, s, &st.rollout_blocks, &st.rollout_threads)
          : prm->precision == TW_PREC_F16X2 ? launch_rollout_f16x2(ra, s, &st.rollout_blocks, &st.rollout_threads)

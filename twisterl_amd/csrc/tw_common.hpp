@@ -230,6 +230,13 @@ __host__ __device__ inline void puzzle_reset(PuzzleLane &s, const PuzzleConsts &
     s.depth = c.depth0;
 }
 
+// lowest zero nibble of a board = the blank cell (the classic zero-byte trick flags only true zeros below the first borrow)
+__host__ __device__ inline int blank_cell(uint64_t b)
+{
+    const uint64_t m = (b - 0x1111111111111111ull) & ~b & 0x8888888888888888ull;
+    return (int)(__builtin_ctzll(m) >> 2);
+}
+
 __host__ __device__ inline bool  puzzle_solved(const PuzzleLane &s, const PuzzleConsts &c) { return s.board == c.ident; }
 __host__ __device__ inline bool  puzzle_final(const PuzzleLane &s, const PuzzleConsts &c) { return s.depth == 0 || s.board == c.ident; }
 __host__ __device__ inline float puzzle_reward(const PuzzleLane &s, const PuzzleConsts &c)
@@ -343,6 +350,11 @@ struct RolloutArgs {
     PolicyDev    pol;
     PaddedTraj   out;
     uint64_t     num_episodes, episode_offset, seed;
+    // persistent-lane mode (f32 kernel, more episodes than resident lanes): a lane whose episode is over takes the next
+    // one from `queue` -- ragged episode lengths then cost the MEAN length, as with the reference's work stealing
+    // (ppo.rs:110-124), not the maximum of every 256-episode workgroup.  Start boards come from init_boards_kernel.
+    const uint64_t *init_boards;   // [num_episodes] scrambled start boards, or null
+    unsigned int   *queue;         // next unassigned episode, or null
 };
 
 // Waves per workgroup of the f32 engine for a batch of n columns (episodes / attempts): 8 (two per SIMD) is the
@@ -357,6 +369,8 @@ inline int waves_per_group(uint64_t n)
 
 // kernel launchers (each returns a TW_* status)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s);
+uint64_t rollout_f32_resident_episodes();   // episodes the f32 rollout keeps resident at once (persistent mode above that)
 int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_rollout_f16x2(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, uint64_t *ep_start,

@@ -36,12 +36,6 @@ size_t mcts_node_bytes() { return sizeof(MctsNode); }
 constexpr uint32_t NONE = 0xffffffffu;
 enum { PH_ROOT = 0, PH_LEAF = 1, PH_DONE = 2 };
 
-__device__ inline int blank_cell(uint64_t b)
-{   // lowest zero nibble (the classic zero-byte trick flags only true zeros below the first borrow)
-    const uint64_t m = (b - 0x1111111111111111ull) & ~b & 0x8888888888888888ull;
-    return (int)(__builtin_ctzll(m) >> 2);
-}
-
 __device__ inline PuzzleLane lane_of(const MctsNode &n, const PuzzleConsts &c)
 {
     PuzzleLane s; s.board = n.board; const int z = blank_cell(n.board);

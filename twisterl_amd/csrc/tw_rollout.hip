@@ -35,7 +35,25 @@
 
 namespace tw {
 
-template <int NT, int NC, int DBG = 0, int NW = 8>
+// scrambled start boards of episodes [offset, offset+n) (Env::reset, puzzle.rs:119-133) for the persistent-lane mode
+__global__ void __launch_bounds__(256) init_boards_kernel(const PuzzleConsts env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    PuzzleLane st;
+    puzzle_reset(st, env, seed, episode_offset + i);
+    out[i] = st.board;
+}
+
+int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s)
+{
+    if (n == 0) return TW_OK;
+    hipLaunchKernelGGL(init_boards_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env, seed, episode_offset, n, out);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
+template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(const RolloutArgs a)
 {
     using Eng = Engine3<NT, NC, DBG, NW>;
@@ -45,18 +63,27 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
 
     const PuzzleConsts env = a.env;
     const int j = eng.j, h = eng.h;
-    const uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);
-    const bool     valid    = e_local < a.num_episodes;
-    const uint64_t e_global = a.episode_offset + e_local;
+    uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);
+    const bool valid  = e_local < a.num_episodes;
+    uint64_t e_global = a.episode_offset + e_local;
 
     PuzzleLane st;
     st.board = env.ident; st.zx = 0; st.zy = 0; st.depth = 0;
-    if (valid) puzzle_reset(st, env, a.seed, e_global);
+    auto take = [&](uint64_t e) {                         // persistent mode: start board of episode e from the pre-pass
+        st.board = a.init_boards[e];
+        const int z = blank_cell(st.board);
+        st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
+    };
+    if (valid) {
+        if constexpr (PERSIST) take(e_local);
+        else puzzle_reset(st, env, a.seed, e_global);
+    }
 
     bool     alive = valid;
+    bool     more  = PERSIST;                             // the queue may still hold episodes
     int      t = 0;
     uint32_t len = 0;
-    const uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
+    uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
 
     uint32_t obs_base[4];
     obs_base_words(env.n_cells, obs_base);
@@ -95,29 +122,47 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
                 obs_bytes(st.board, obs_base, pk);
                 store_rec(a.out.rec + rec, pk, lg, value, rew, action, perm);
             }
-            if (puzzle_final(st, env)) { alive = false; len = (uint32_t)t + 1u; }
-            else { puzzle_step(st, env, action); ++t; }
+            if (puzzle_final(st, env)) {
+                alive = false; len = (uint32_t)t + 1u;
+                if constexpr (PERSIST) { if (h == 0) a.out.ep_len[e_local] = len; }
+            } else { puzzle_step(st, env, action); ++t; }
+        }
+        if constexpr (PERSIST) {
+            if (!alive && more) {                         // take the next episode off the queue (both lanes of the pair the same one)
+                unsigned got = 0xffffffffu;
+                if (h == 0) got = atomicAdd(a.queue, 1u);
+                got = (unsigned)__shfl((int)got, j, 64);
+                if ((uint64_t)got < a.num_episodes) {
+                    e_local = got; e_global = a.episode_offset + e_local; rec_base = e_local * (uint64_t)a.out.t_pad;
+                    take(e_local);
+                    alive = true; t = 0;
+                } else more = false;
+            }
         }
     }
-    if (valid && h == 0) a.out.ep_len[e_local] = len;
+    if constexpr (!PERSIST) { if (valid && h == 0) a.out.ep_len[e_local] = len; }
     eng.end();
 }
 
-template <int NT, int NC, int DBG = 0, int NW = 8>
+constexpr uint64_t PERSIST_BLOCKS = 256;   // one 8-wave workgroup per CU of an MI355X
+
+uint64_t rollout_f32_resident_episodes() { return PERSIST_BLOCKS * 8 * EPW; }
+
+template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
 static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     constexpr int EPB = NW * EPW, THREADS = 64 * NW;
-    const uint64_t nb = (a.num_episodes + EPB - 1) / EPB;
+    const uint64_t nb = PERSIST ? PERSIST_BLOCKS : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;   // per instantiation: raise the dynamic-LDS limit above the 64 KiB default
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, DBG, NW>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = THREADS;
@@ -140,6 +185,8 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
     }
 #endif
     // small batches: fewer waves per workgroup, so that the episodes spread over more CUs
+    if (a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes())
+        return launch_geom<NT, NC, 0, 8, true>(a, s, blocks, threads);
     const int nw = waves_per_group(a.num_episodes);
     if (nw == 1) return launch_geom<NT, NC, 0, 1>(a, s, blocks, threads);
     if (nw == 2) return launch_geom<NT, NC, 0, 2>(a, s, blocks, threads);
