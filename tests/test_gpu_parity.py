@@ -635,3 +635,18 @@ def test_persistent_lane_mode_bit_exact(tw, oracle):
     a = g.to_numpy()
     for k in a:
         assert np.array_equal(a[k], h[k]), k
+    # the f16-matrix-core kernels have the same mode (their lane halves own one episode each): identical to their
+    # non-persistent launches
+    for prec in ("fp16", "fp16x2"):
+        c16 = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32}, seed=17, precision=prec)
+        p1 = c16.collect(genv, gp, seed=17).to_numpy() if prec == "fp16" else None
+        if prec == "fp16x2":
+            gp2, _ = _pair(oracle, 9, 5, 64, 32, twists=True)          # the split mode needs two embedding tiles
+            p1 = c16.collect(genv, gp2, seed=17).to_numpy()
+        os.environ["TW_NO_PERSIST"] = "1"
+        try:
+            p2 = c16.collect(genv, gp2 if prec == "fp16x2" else gp, seed=17).to_numpy()
+        finally:
+            del os.environ["TW_NO_PERSIST"]
+        for k in p1:
+            assert np.array_equal(p1[k], p2[k]), (prec, k)

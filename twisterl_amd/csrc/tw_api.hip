@@ -739,8 +739,8 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     const uint64_t R = E * (uint64_t)t_pad;
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
-    // persistent-lane mode of the f32 kernel (more episodes than resident lanes): start boards + episode queue
-    const bool persist = prm->precision == TW_PREC_F32_EXACT && E > rollout_f32_resident_episodes() && !getenv("TW_NO_PERSIST");
+    // persistent-lane mode (more episodes than resident lanes): start boards + episode queue
+    const bool persist = E > rollout_f32_resident_episodes() && !getenv("TW_NO_PERSIST");
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
                  o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     void *wsp = nullptr;

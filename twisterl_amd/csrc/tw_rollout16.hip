@@ -17,7 +17,7 @@ namespace tw {
 __device__ unsigned long long g_stamps16[8];
 #endif
 
-template <class Eng, int NC>
+template <class Eng, int NC, bool PERSIST = false>
 __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds16[];
@@ -30,13 +30,22 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
     const PuzzleConsts env = a.env;
     const int j = eng.j, hh = eng.hh;
     // this lane half owns tile hh: episode (wave, hh, j)
-    const uint64_t e_own   = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * 64 + hh * 32 + j);
-    const bool     v_own   = e_own < a.num_episodes;
-    const uint64_t eg_own  = a.episode_offset + e_own;
+    uint64_t   e_own  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * 64 + hh * 32 + j);
+    const bool v_own  = e_own < a.num_episodes;
+    uint64_t   eg_own = a.episode_offset + e_own;
 
+    auto from_board = [&](uint64_t b) {                    // persistent mode: start state from a pre-scrambled board
+        PuzzleLane s; s.board = b;
+        const int z = blank_cell(b);
+        s.zx = z % env.width; s.zy = z / env.width; s.depth = env.depth0;
+        return s;
+    };
     PuzzleLane own;
     own.board = env.ident; own.zx = 0; own.zy = 0; own.depth = 0;
-    if (v_own) puzzle_reset(own, env, a.seed, eg_own);
+    if (v_own) {
+        if constexpr (PERSIST) own = from_board(a.init_boards[e_own]);
+        else puzzle_reset(own, env, a.seed, eg_own);
+    }
     // both halves keep both episodes' state (the one-hot operands of both tiles are built on every lane)
     PuzzleLane st0, st1;
     {
@@ -48,9 +57,10 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
     }
     const bool v_oth = __shfl_xor(v_own ? 1 : 0, 32, 64) != 0;
     bool alive0 = hh ? v_oth : v_own, alive1 = hh ? v_own : v_oth;
-    int      t = 0;
+    int      t = 0;                                        // timestep of the OWN episode (the other half keeps the other tile's)
     uint32_t len_own = 0;
-    const uint64_t rec_base = e_own * (uint64_t)a.out.t_pad;
+    uint64_t rec_base = e_own * (uint64_t)a.out.t_pad;
+    bool     more = PERSIST;                               // the episode queue may still hold work
 
     uint32_t obs_base[4];
     obs_base_words(env.n_cells, obs_base);
@@ -126,8 +136,28 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
             const bool died_own = hh ? (alive1 && fin1) : (alive0 && fin0);
             len_own = died_own ? (uint32_t)t + 1u : len_own;
             alive0 = go0; alive1 = go1;
+            if constexpr (PERSIST) { if (died_own) a.out.ep_len[e_own] = len_own; }
         }
         ++t;
+        if constexpr (PERSIST) {
+            // a half whose own episode is over takes the next one off the queue; the other half of the lane pair
+            // needs that tile's new board too (one-hot operands of both tiles are built on every lane)
+            const bool idle_own = !(hh ? alive1 : alive0);
+            unsigned got = 0xffffffffu;
+            if (idle_own && more) got = atomicAdd(a.queue, 1u);
+            const bool took = (uint64_t)got < a.num_episodes;
+            more = more && !(idle_own && !took);
+            uint64_t nb = 0;
+            if (took) { e_own = got; eg_own = a.episode_offset + e_own; rec_base = e_own * (uint64_t)a.out.t_pad; t = 0; nb = a.init_boards[e_own]; }
+            const bool took_oth = __shfl_xor(took ? 1 : 0, 32, 64) != 0;
+            const uint64_t nb_oth = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(nb >> 32), 32, 64) << 32) |
+                                    (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)nb, 32, 64);
+            const PuzzleLane n_own = from_board(nb), n_oth = from_board(nb_oth);
+            const bool t0 = hh ? took_oth : took, t1 = hh ? took : took_oth;
+            const PuzzleLane &n0 = hh ? n_oth : n_own, &n1 = hh ? n_own : n_oth;
+            if (t0) { st0 = n0; alive0 = true; }
+            if (t1) { st1 = n1; alive1 = true; }
+        }
 #ifdef TW_ABLATE
         t_prev = __builtin_readcyclecounter();
         eng.st[6] += t_prev - t_po;
@@ -137,19 +167,19 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
     eng.st[3] = __builtin_readcyclecounter() - t_kernel0;      // (slot 3 reused: whole wave lifetime)
     if (eng.lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps16[i], eng.st[i]);
 #endif
-    if (v_own) a.out.ep_len[e_own] = len_own;
+    if constexpr (!PERSIST) { if (v_own) a.out.ep_len[e_own] = len_own; }
     eng.end();
 }
 
-template <class Eng, int NC>
-static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads, size_t lds_bytes)
+template <class Eng, int NC, bool PERSIST>
+static int launch16p(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads, size_t lds_bytes)
 {
-    const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
+    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / Eng::EPB : (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout16: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     if (lds_bytes > 159 * 1024) { set_error("rollout16: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f16_kernel<Eng, NC>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f16_kernel<Eng, NC, PERSIST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
@@ -157,7 +187,7 @@ static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint3
     static const unsigned long long zeros[8] = {};
     if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps16), zeros, sizeof(zeros)));
 #endif
-    hipLaunchKernelGGL((rollout_f16_kernel<Eng, NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((rollout_f16_kernel<Eng, NC, PERSIST>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
@@ -172,6 +202,14 @@ static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint3
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = Eng::THREADS;
     return TW_OK;
+}
+
+template <class Eng, int NC>
+static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads, size_t lds_bytes)
+{
+    // more episodes than resident lanes: persistent lanes that take the next episode from a queue (tw_rollout.hip)
+    if (a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes()) return launch16p<Eng, NC, true>(a, s, blocks, threads, lds_bytes);
+    return launch16p<Eng, NC, false>(a, s, blocks, threads, lds_bytes);
 }
 
 template <int NHT, bool SPLIT>
