@@ -650,3 +650,26 @@ def test_persistent_lane_mode_bit_exact(tw, oracle):
             del os.environ["TW_NO_PERSIST"]
         for k in p1:
             assert np.array_equal(p1[k], p2[k]), (prec, k)
+
+
+def test_az_persistent_lane_mode_bit_exact(tw, oracle):
+    """AlphaZero self-play with more episodes than resident lanes: persistent lanes reuse their tree arena for every
+    episode they take; bit-identical to the oracle and to the plain launch."""
+    import os
+    gp, op = _pair(oracle, 9, 7, 32, 32, twists=False, scale=3.0)
+    E = 66_000
+    genv, oenv = tw.env.Puzzle(3, 3, 1, 3, 256), oracle.Puzzle(3, 3, 1, 3, 256)
+    coll = tw.collector.AZCollector(num_episodes=E, num_mcts_searches=3, C=1.41, max_expand_depth=1, num_cores=32, seed=19, merge_order=False)
+    g = coll.collect(genv, gp, seed=19).to_numpy()
+    o = oracle.az_collect(oenv, op, E, 3, 1.41, 1, seed=19, arith=oracle.ARITH_CHAIN, num_threads=8, merge_order=False, det_math=True)
+    assert np.array_equal(g["ep_len"], o.ep_len)
+    assert np.array_equal(g["obs"].astype(np.int64), o.obs)
+    assert np.array_equal(f32_bits(g["logits"]), f32_bits(o.logits))
+    assert np.array_equal(f32_bits(g["remaining_values"]), f32_bits(o.additional_data["remaining_values"]))
+    os.environ["TW_NO_PERSIST"] = "1"
+    try:
+        h = coll.collect(genv, gp, seed=19).to_numpy()
+    finally:
+        del os.environ["TW_NO_PERSIST"]
+    for k in g:
+        assert np.array_equal(g[k], h[k]), k

@@ -849,8 +849,12 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     const uint64_t R = E * (uint64_t)t_pad;
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    // persistent lanes (more episodes than resident lanes): one tree arena per LANE, start boards + episode queue
+    const bool persist = E > rollout_f32_resident_episodes() && !getenv("TW_NO_PERSIST");
+    const uint64_t arenas = persist ? rollout_f32_resident_episodes() : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
-                 o_total = seg(16), o_scan = seg(scan_scratch_bytes(E)), o_arena = seg(E * cap64 * mcts_node_bytes());
+                 o_total = seg(16), o_scan = seg(scan_scratch_bytes(E)), o_arena = seg(arenas * cap64 * mcts_node_bytes()),
+                 o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     size_t free_b = 0, total_b = 0;
     TW_HIP(hipMemGetInfo(&free_b, &total_b));
     if (cur > (size_t)(0.9 * (double)total_b)) {
@@ -870,6 +874,14 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
     TW_HIP(hipMemsetAsync(ws + o_total, 0, 16, s));
+    if (persist) {
+        ma.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
+        ma.queue = reinterpret_cast<unsigned int *>(ws + o_queue);
+        const unsigned int first = (unsigned int)rollout_f32_resident_episodes();
+        TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
+        rc = launch_init_boards(ma.env, ma.seed, ma.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
+        if (rc) return rc;
+    }
     TW_HIP(hipEventRecord(ev.ev[0], s));
     rc = launch_mcts_f32(ma, s, &st.rollout_blocks, &st.rollout_threads); if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[1], s));

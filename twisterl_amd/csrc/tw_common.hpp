@@ -415,6 +415,10 @@ struct MctsArgs {
     uint32_t     node_cap;
     unsigned long long *eval_count;   // number of policy evaluations (leaf + root), for the stats
     MctsSolve    solve;        // on == 0: AlphaZero self-play (records into `out`)
+    // persistent-lane mode (self-play with more episodes than resident lanes, see RolloutArgs): the arena is then
+    // [resident lanes][node_cap], a lane reuses its arena for every episode it takes
+    const uint64_t *init_boards;
+    unsigned int   *queue;
 };
 size_t mcts_node_bytes();
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);

@@ -43,7 +43,7 @@ __device__ inline PuzzleLane lane_of(const MctsNode &n, const PuzzleConsts &c)
     return s;
 }
 
-template <int NT, int NC, int NW>
+template <int NT, int NC, int NW, bool PERSIST = false>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(const MctsArgs a)
 {
     using Eng = Engine3<NT, NC, 0, NW>;
@@ -53,21 +53,28 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
 
     const PuzzleConsts env = a.env;
     const int j = eng.j, h = eng.h;
-    const uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);
+    const uint64_t slot     = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);   // lane pair (arena) index
+    uint64_t       e_local  = slot;                                                                // episode being played
     const bool     valid    = e_local < a.num_episodes;
     const MctsSolve sv      = a.solve;
     // solve mode: lane pair = ATTEMPT (episode, search); its draws are keyed like single_solve's (tw_solve.hip)
     const uint64_t sv_ep    = sv.on ? a.episode_offset + e_local / sv.num_searches : 0;
-    const uint64_t e_global = sv.on ? sv_ep * (uint64_t)sv.num_searches + e_local % sv.num_searches : a.episode_offset + e_local;
+    uint64_t       e_global = sv.on ? sv_ep * (uint64_t)sv.num_searches + e_local % sv.num_searches : a.episode_offset + e_local;
     const bool     owner    = valid && h == 0;            // the lane that walks / mutates the tree
-    MctsNode *nodes = a.arena + (valid ? e_local : 0) * (uint64_t)a.node_cap;
+    MctsNode *nodes = a.arena + (valid ? slot : 0) * (uint64_t)a.node_cap;
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
-    const uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
+    uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
 
     PuzzleLane st;                                        // the episode's env (az.rs:56-57)
     st.board = env.ident; st.zx = 0; st.zy = 0; st.depth = 0;
+    auto take = [&](uint64_t e) {                         // persistent mode: start board of episode e from the pre-pass
+        st.board = a.init_boards[e];
+        const int z = blank_cell(st.board);
+        st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
+    };
     if (valid) {
-        if (!sv.on) puzzle_reset(st, env, a.seed, e_global);
+        if constexpr (PERSIST) take(e_local);
+        else if (!sv.on) puzzle_reset(st, env, a.seed, e_global);
         else if (sv.from_state) { st.board = sv.start_board; st.zx = sv.start_zx; st.zy = sv.start_zy; st.depth = sv.start_depth; }
         else puzzle_reset(st, env, a.seed, sv_ep);
     }
@@ -82,6 +89,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
     float    value = 0.0f;
     PuzzleLane leaf = st;                                 // state whose evaluation is pending
     unsigned long long evals = 0;
+    bool more = PERSIST;                                  // the episode queue may still hold work
 
     uint32_t obs_base[4];
     obs_base_words(env.n_cells, obs_base);
@@ -219,7 +227,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
                         uint32_t pk[4];
                         obs_bytes(st.board, obs_base, pk);
                         store_rec(a.out.rec + rec, pk, mp, 0.0f, puzzle_reward(st, env), 0, -1);
-                        if (puzzle_final(st, env)) { phase = PH_DONE; len = (uint32_t)t + 1u; break; }   // az.rs:84
+                        if (puzzle_final(st, env)) {                                                     // az.rs:84
+                            phase = PH_DONE; len = (uint32_t)t + 1u;
+                            if constexpr (PERSIST) {       // episode over: record its length, take the next one off the queue
+                                a.out.ep_len[e_local] = len;
+                                const unsigned got = more ? atomicAdd(a.queue, 1u) : 0xffffffffu;
+                                if ((uint64_t)got < a.num_episodes) {
+                                    e_local = got; e_global = a.episode_offset + e_local; rec_base = e_local * (uint64_t)a.out.t_pad;
+                                    take(e_local);
+                                    t = 0; phase = PH_ROOT; leaf = st;
+                                } else more = false;
+                            }
+                            break;
+                        }
                         puzzle_step(st, env, action);                                                   // az.rs:89
                         ++t;
                         phase = PH_ROOT; leaf = st;
@@ -275,27 +295,27 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
             sv.success[e_local] = puzzle_solved(st, env) ? 1.0f : 0.0f;   // solve.rs:68
             sv.total[e_local]   = total;
             sv.n_steps[e_local] = (uint32_t)t;
-        } else a.out.ep_len[e_local] = len;
+        } else if constexpr (!PERSIST) a.out.ep_len[e_local] = len;
         atomicAdd(a.eval_count, evals);
     }
     eng.end();
 }
 
-template <int NT, int NC, int NW>
+template <int NT, int NC, int NW, bool PERSIST = false>
 static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     constexpr int EPB = NW * EPW;
-    const uint64_t nb = (a.num_episodes + EPB - 1) / EPB;
+    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / EPB : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC, NW>),
+        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC, NW, PERSIST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((mcts_f32_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, s, a);
+    hipLaunchKernelGGL((mcts_f32_kernel<NT, NC, NW, PERSIST>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = 64 * NW;
@@ -305,6 +325,8 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
 template <int NT, int NC>
 static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
+    if (!a.solve.on && a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes())
+        return launch_mcts_geom<NT, NC, 8, true>(a, s, blocks, threads);
     const int nw = waves_per_group(a.num_episodes);
     if (nw == 1) return launch_mcts_geom<NT, NC, 1>(a, s, blocks, threads);
     if (nw == 2) return launch_mcts_geom<NT, NC, 2>(a, s, blocks, threads);
