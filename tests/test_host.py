@@ -130,3 +130,15 @@ def test_policy_constructor_validation():
     with pytest.raises(ValueError):
         twisterl.nn.Policy(emb, twisterl.nn.Sequential([]), twisterl.nn.Sequential([lin]), twisterl.nn.Sequential([lin]),
                            [[0, 1]], [])
+
+
+def test_precision_kwarg_values():
+    """precision= is a build extension of the collector constructors: the three rollout modes are accepted by name,
+    anything else is a ValueError at construction (no GPU needed)."""
+    from twisterl_amd import twisterl, _lib
+    for name, code in (("fp32", 0), ("fp16", 1), ("fp16x2", 2)):
+        c = twisterl.collector.PPOCollector(**{"num_episodes": 4, "gamma": 0.9, "lambda": 0.9, "num_cores": 1}, precision=name)
+        assert _lib.PRECISIONS[c.precision] == code
+    import pytest
+    with pytest.raises(ValueError):
+        twisterl.collector.PPOCollector(4, 0.9, 0.9, 1, precision="bf16")
