@@ -144,15 +144,26 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
     eng.end();
 }
 
-constexpr uint64_t PERSIST_BLOCKS = 256;   // one 8-wave workgroup per CU of an MI355X
+// persistent mode: one 256-episode workgroup per CU of the current device (256 on an MI355X; every rollout kernel needs
+// most of a CU's LDS, so one workgroup is resident per CU)
+static uint64_t persist_blocks()
+{
+    static int cached_dev = -1; static uint64_t cached = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) { cached = (uint64_t)p.multiProcessorCount; cached_dev = dev; }
+    }
+    return cached;
+}
 
-uint64_t rollout_f32_resident_episodes() { return PERSIST_BLOCKS * 8 * EPW; }
+uint64_t rollout_f32_resident_episodes() { return persist_blocks() * 8 * EPW; }
 
 template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
 static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     constexpr int EPB = NW * EPW, THREADS = 64 * NW;
-    const uint64_t nb = PERSIST ? PERSIST_BLOCKS : (a.num_episodes + EPB - 1) / EPB;
+    const uint64_t nb = PERSIST ? persist_blocks() : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
