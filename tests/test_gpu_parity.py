@@ -673,3 +673,13 @@ def test_az_persistent_lane_mode_bit_exact(tw, oracle):
         del os.environ["TW_NO_PERSIST"]
     for k in g:
         assert np.array_equal(g[k], h[k]), k
+
+
+def test_end_to_end_loop_sketch(tw, oracle):
+    """examples/ppo_loop_sketch.py: collect -> data_to_torch -> torch PPO update -> device policy sync -> evaluate, three
+    iterations with nothing going through host lists; the losses are finite and the synced policy is the trained one."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("ppo_loop_sketch", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "ppo_loop_sketch.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    hist = mod.run(iterations=3, episodes=2048, log=lambda *_: None)
+    assert len(hist) == 3 and all(np.isfinite(h[0]) for h in hist) and all(0.0 <= h[1] <= 1.0 for h in hist)
