@@ -1,0 +1,32 @@
+"""Soak: the same collect repeated must give bit-identical buffers (catches rare LDS-ring / queue races that a single
+parity run can miss).  Hashes every field on the device."""
+import sys
+sys.path.insert(0, ".")
+import torch
+import bench
+from tests.util import puzzle_transpose_twist
+from twisterl_amd import twisterl
+
+def digest(d):
+    t = d.to_torch()
+    out = []
+    for k in sorted(t):
+        x = t[k]
+        v = x.view(torch.uint8).to(torch.int64) if x.dtype in (torch.uint8, torch.int8) else x.contiguous().view(torch.int32).to(torch.int64)
+        w = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64) % 1000003
+        out.append(int((v.reshape(-1) * w).sum().item()))
+    return tuple(out)
+
+op, ap = puzzle_transpose_twist(4)
+pol = bench.build_policy(bench.synthetic_weights(16), op, ap)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+for prec, env, E in (("fp32", twisterl.env.Puzzle(4, 4, 128, 2, 256), 262144), ("fp16x2", twisterl.env.Puzzle(4, 4, 128, 2, 256), 262144),
+                     ("fp16", twisterl.env.Puzzle(4, 4, 128, 2, 256), 262144), ("fp32", twisterl.env.Puzzle(4, 4, 1, 64, 256), 200000),
+                     ("fp16x2", twisterl.env.Puzzle(4, 4, 1, 64, 256), 200000)):
+    coll = twisterl.collector.PPOCollector(E, 0.995, 0.995, 1, precision=prec)
+    ref = None; bad = 0
+    for i in range(n):
+        dg = digest(coll.collect(env, pol, seed=5))
+        if ref is None: ref = dg
+        elif dg != ref: bad += 1
+    print(prec, "E", E, "difficulty", env.difficulty, "repeats", n, "mismatching repeats", bad, flush=True)

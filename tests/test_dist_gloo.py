@@ -98,7 +98,7 @@ def _worker(rank, world, port, E, q):
         raise
 
 
-@pytest.mark.parametrize("world,E", [(2, 37), (3, 10), (2, 2)])
+@pytest.mark.parametrize("world,E", [(2, 37), (3, 10), (2, 2), (4, 23)])
 def test_sharded_gather_matches_unsharded_merge_order(oracle, world, E):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
