@@ -250,7 +250,7 @@ def main():
                     return {"error": str(e)}
             out["f16x2_mode_f32_equivalent"] = side_mode("fp16x2")
             out["f16_input_mode"] = side_mode("fp16")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
