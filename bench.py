@@ -39,7 +39,7 @@ def measured_traffic_per_record(kernel="rollout_f32"):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
         for k, v in d.items():
-            if kernel in k:
+            if k.endswith(kernel) or (kernel == "rollout_f32" and kernel in k):
                 return float(v["bytes_per_record"])
     except Exception:
         pass
@@ -193,7 +193,7 @@ def main():
     if rank == 0:
         kern_s = float(np.mean(ms_rollout)) * 1e-3
         rec_per_launch = records / args.steps
-        tpr = measured_traffic_per_record("rollout_f32" if args.precision == "fp32" else "rollout_f16") if args.puzzle == 15 else None
+        tpr = measured_traffic_per_record({"fp32": "rollout_f32", "fp16": "rollout_f16", "fp16x2": "rollout_f16x2"}[args.precision]) if args.puzzle == 15 else None
         achieved = rec_per_launch * FLOP_PER_RECORD[n2] / kern_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
         out = {
