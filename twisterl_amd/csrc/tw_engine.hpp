@@ -99,6 +99,11 @@ struct Engine3 {
     static constexpr int NPIECE = WPIECE + TPIECE;
     static constexpr int NOPS   = (NPIECE + NW - 1) / NW;   // DMA ops per wave per chunk
     static constexpr int M      = 4 * NT;                   // MFMAs per group of four k-steps
+    static constexpr bool SPLIT = false;
+
+    __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size); }
+    __device__ __forceinline__ bool primary() const { return true; }           // this wave owns its episodes' stores
+    __device__ __forceinline__ int  ep_lane() const { return wave * EPW + j; }  // episode index inside the workgroup
 
     PolicyDev pol;
     int tid, lane, wave, j, h;
@@ -338,5 +343,148 @@ struct Engine3 {
         value = __shfl(hacc[0], j + 32, 64) + lds_bh[4];
     }
 };
+
+// =====================================================================================================
+// Engine3S: the small-batch geometry.  The NS waves of a workgroup (one per SIMD) share ONE group of 32
+// episodes and split the hidden units: wave w owns the row tiles [w*NT/NS, (w+1)*NT/NS) of the common
+// Linear, so the 32-column forward runs on NS matrix cores instead of one.  Every wave computes the
+// (cheap) EmbeddingBag gather of all 32 episodes itself; the k-ordered head chain is handed from wave to
+// wave through LDS (partial accumulators are exact, so the result is still the oracle's single fma chain).
+// Same weight images, ring and LDS map as Engine3 + a 2 KiB exchange area.  All NS waves carry the same
+// episode state; only wave 0 (`primary()`) stores.
+// =====================================================================================================
+constexpr int R3S_XCHG = 256, R3S_USER = 256;      // floats: head hand-off | kernel use (MCTS leaf broadcast)
+
+template <int NT, int NC, int NS>
+struct Engine3S : Engine3<NT, NC, 0, NS> {
+    using B = Engine3<NT, NC, 0, NS>;
+    static constexpr int EPB = EPW, NTL = NT / NS, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, NOPS = B::NOPS;
+    static constexpr bool SPLIT = true;
+    static_assert(NT % NS == 0 && (NTL == 1 || NTL == 2), "Engine3S: one or two row tiles per wave");
+
+    float *lds_x, *lds_user;
+
+    __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
+    __device__ __forceinline__ bool primary() const { return this->wave == 0; }
+    __device__ __forceinline__ int  ep_lane() const { return this->j; }
+
+    __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
+    {
+        B::begin1(p, lds);
+        lds_x = lds + engine3_lds_floats<NT>(p.obs_size);
+        lds_user = lds_x + R3S_XCHG;
+    }
+
+    __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
+    {
+        typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+        const int j = this->j, h = this->h, wave = this->wave;
+        f32x16 acc[NTL];
+#pragma unroll
+        for (int r = 0; r < NTL; ++r)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[r][g] = 0.0f;
+
+        const int t0    = wave * NTL;                                           // first row tile of this wave
+        const int a_off = ((h * NQ + (t0 >> 2)) * 32 + j) * 4 + (t0 & 3);       // float offset of its A operands in a k-step block
+        lds_cfloat *ga[NC + 1];
+        ga[0] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT + this->bias_row * R3_LSTR + h * (KC / 2));
+#pragma unroll
+        for (int q = 0; q < NC; ++q) ga[q + 1] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT) + rowoff[q];
+
+        int s0 = this->rp;
+        for (int c = 0; c < this->n_chunks; ++c) {
+            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+            int sc = c + 2; if (sc >= this->n_chunks) sc -= this->n_chunks;     // chunk streamed now (wraps into the next forward)
+            if (this->n_chunks == 1) sc = 0;
+#pragma unroll
+            for (int op = 0; op < NOPS; ++op) this->stream_op(sc, s2, op);
+            lds_cfloat *wb = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
+#pragma unroll
+            for (int ng = 0; ng < 2; ++ng) {
+                // EmbeddingBag: bias row, then the cells in order (four k-steps per 16-byte word)
+                const f32x4 r0 = *reinterpret_cast<lds_cf4 *>(ga[0] + 4 * ng);
+                f32x2 lo = __builtin_shufflevector(r0, r0, 0, 1), hi = __builtin_shufflevector(r0, r0, 2, 3);
+#pragma unroll
+                for (int q = 1; q <= NC; ++q) {
+                    const f32x4 rq = *reinterpret_cast<lds_cf4 *>(ga[q] + 4 * ng);
+                    lo = pk_add(lo, __builtin_shufflevector(rq, rq, 0, 1));
+                    hi = pk_add(hi, __builtin_shufflevector(rq, rq, 2, 3));
+                }
+                f32x4 bq;
+                bq[0] = lo[0]; bq[1] = lo[1]; bq[2] = hi[0]; bq[3] = hi[1];
+                this->finish_b(bq);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lds_cfloat *ap = wb + (ng * 4 + u) * 2 * NQ * 128;
+                    if constexpr (NTL == 2) {
+                        const f32x2 a2 = *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(ap);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0], bq[u], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1], bq[u], acc[1], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(*ap, bq[u], acc[0], 0, 0, 0);
+                    }
+                }
+            }
+            {
+                const int delta = (s1 - s0) * R3_TSLOT;
+#pragma unroll
+                for (int q = 0; q <= NC; ++q) ga[q] += delta;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c+2 have landed
+            __syncthreads();
+            s0 = s1;
+        }
+        this->rp = s0;
+
+        // heads: the hidden-ordered chain runs through the waves in turn
+        f32x16 hacc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) hacc[g] = 0.0f;
+        lds_cfloat *b1_lane = (lds_cfloat *)(this->lds_b1 + h * (NT * 16)) + 16 * t0;
+        lds_cfloat *wh_lane = (lds_cfloat *)(this->lds_wh + ((j < 8 ? j : 8) * 2 + h) * (NT * 16)) + 16 * t0;
+        f32x4 *xl = reinterpret_cast<f32x4 *>(lds_x) + this->lane;
+        for (int w = 0; w < NS; ++w) {
+            if (wave == w) {
+                if (w > 0) {
+                    const f32x4 p = *xl;
+                    hacc[0] = p[0]; hacc[1] = p[1]; hacc[2] = p[2]; hacc[3] = p[3];
+                }
+#pragma unroll
+                for (int bl = 0; bl < NTL * 4; ++bl) {
+                    const int r = bl >> 2, g0 = (bl & 3) * 4;
+                    const f32x4 hb = *reinterpret_cast<lds_cf4 *>(b1_lane + 4 * bl);
+                    const f32x4 hw = *reinterpret_cast<lds_cf4 *>(wh_lane + 4 * bl);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float hv = relu_lim(acc[r][g0 + g] + hb[g], this->common_lim);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(hw[g], hv, hacc, 0, 0, 0);
+                    }
+                }
+                f32x4 o; o[0] = hacc[0]; o[1] = hacc[1]; o[2] = hacc[2]; o[3] = hacc[3];
+                *xl = o;
+            }
+            __syncthreads();
+        }
+        const f32x4 fl = reinterpret_cast<const f32x4 *>(lds_x)[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[i] = fl[i] + this->lds_bh[i];
+        value = lds_x[(j + 32) * 4] + this->lds_bh[4];
+    }
+};
+
+constexpr int geom_threads(int nw) { return 64 * (nw < 0 ? -nw : nw); }
+// launch geometry code -> engine: NW > 0 = NW independent waves of 32 episodes (Engine3); NW < 0 = -NW waves sharing 32 (Engine3S)
+template <int NT, int NC, int DBG, int NW> struct Geom { using Eng = Engine3<NT, NC, DBG, NW>; static constexpr int WAVES = NW; };
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -4> { using Eng = Engine3S<NT, NC, 4>; static constexpr int WAVES = 4; };
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -2> { using Eng = Engine3S<NT, NC, 2>; static constexpr int WAVES = 2; };
+
+// geometry for n episodes: 8 = the throughput shape; below ~3/4 of a chip of 256-episode workgroups the split shape
+template <int NT> inline int geometry_for(uint64_t n)
+{
+    const int nw = waves_per_group(n);
+    if (nw == 8 || NT < 2) return nw;
+    return NT >= 4 ? -4 : -2;
+}
 
 }  // namespace tw

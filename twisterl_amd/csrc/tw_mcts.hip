@@ -34,6 +34,9 @@ static_assert(sizeof(MctsNode) == 32, "MctsNode must be 32 bytes");
 size_t mcts_node_bytes() { return sizeof(MctsNode); }
 
 constexpr uint32_t NONE = 0xffffffffu;
+#ifdef TW_ABLATE   // diagnostic build: per-wave cycle accounting (forward | tree phase | loop trips | searches consumed | max trips)
+__device__ unsigned long long g_mcts_stamps[8];
+#endif
 enum { PH_ROOT = 0, PH_LEAF = 1, PH_DONE = 2 };
 
 __device__ inline PuzzleLane lane_of(const MctsNode &n, const PuzzleConsts &c)
@@ -44,23 +47,23 @@ __device__ inline PuzzleLane lane_of(const MctsNode &n, const PuzzleConsts &c)
 }
 
 template <int NT, int NC, int NW, bool PERSIST = false>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(const MctsArgs a)
+__global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_kernel(const MctsArgs a)
 {
-    using Eng = Engine3<NT, NC, 0, NW>;
+    using Eng = typename Geom<NT, NC, 0, NW>::Eng;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
 
     const PuzzleConsts env = a.env;
     const int j = eng.j, h = eng.h;
-    const uint64_t slot     = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);   // lane pair (arena) index
+    const uint64_t slot     = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)eng.ep_lane();           // lane pair (arena) index
     uint64_t       e_local  = slot;                                                                // episode being played
     const bool     valid    = e_local < a.num_episodes;
     const MctsSolve sv      = a.solve;
     // solve mode: lane pair = ATTEMPT (episode, search); its draws are keyed like single_solve's (tw_solve.hip)
     const uint64_t sv_ep    = sv.on ? a.episode_offset + e_local / sv.num_searches : 0;
     uint64_t       e_global = sv.on ? sv_ep * (uint64_t)sv.num_searches + e_local % sv.num_searches : a.episode_offset + e_local;
-    const bool     owner    = valid && h == 0;            // the lane that walks / mutates the tree
+    const bool     owner    = valid && h == 0 && eng.primary();   // the lane that walks / mutates the tree
     MctsNode *nodes = a.arena + (valid ? slot : 0) * (uint64_t)a.node_cap;
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
@@ -96,7 +99,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
 
     eng.begin2();
 
+#ifdef TW_ABLATE
+    unsigned long long c_fwd = 0, c_tree = 0, c_trips = 0, c_search = 0, c_inner = 0, c_desc = 0;
+#endif
     while (__syncthreads_or(phase != PH_DONE ? 1 : 0)) {
+#ifdef TW_ABLATE
+        const unsigned long long s0 = __builtin_readcyclecounter();
+#endif
         // ---- (2) Policy::full_predict of the pending leaf (policy.rs:102-126) ------------------
         float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
         const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
@@ -122,6 +131,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
         masked_softmax4(lsum, puzzle_maskbits(leaf, env), probs);
         const float nn_value = vsum;
 
+#ifdef TW_ABLATE
+        const unsigned long long s1 = __builtin_readcyclecounter();
+        c_fwd += s1 - s0; ++c_trips;
+#endif
         // ---- (1) per-episode tree work on the owner lane ---------------------------------------
         if (owner && phase != PH_DONE) {
             ++evals;
@@ -182,6 +195,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
             cur.board = 0; cur.value_sum = 0.0f; cur.visit = 0; cur.prior = 0.0f; cur.parent = NONE; cur.child_base = 0;
             cur.n_children = 0; cur.action = 0; cur.depth = 0;
             for (;;) {
+#ifdef TW_ABLATE
+                ++c_inner;
+#endif
                 if (!resume_expand) {
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) --------------
@@ -265,6 +281,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
                         }
                         if (best == NONE) break;        // all-NaN UCB: the reference panics here
                         node = best; cur = bestn;
+#ifdef TW_ABLATE
+                        ++c_desc;
+#endif
                     }
                     value = 0.0f; expanded = 0;
                     have_cur = true;
@@ -282,12 +301,27 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
                 ++it;
             }
         }
-        // mirror what the partner lane needs for the next collective evaluation
-        phase      = __shfl(phase, j, 64);
-        leaf.board = ((uint64_t)__shfl((uint32_t)(leaf.board >> 32), j, 64) << 32) | (uint64_t)__shfl((uint32_t)leaf.board, j, 64);
-        leaf.zx    = __shfl(leaf.zx, j, 64);
-        leaf.zy    = __shfl(leaf.zy, j, 64);
-        leaf.depth = __shfl(leaf.depth, j, 64);
+#ifdef TW_ABLATE
+        c_tree += __builtin_readcyclecounter() - s1;
+#endif
+        // mirror what the other lanes of the episode need for the next collective evaluation
+        if constexpr (Eng::SPLIT) {        // lanes j / j+32 of every wave of the workgroup: through LDS
+            uint32_t *bc = reinterpret_cast<uint32_t *>(eng.lds_user) + j * 8;
+            if (h == 0 && eng.primary()) {
+                bc[0] = (uint32_t)phase; bc[1] = (uint32_t)leaf.board; bc[2] = (uint32_t)(leaf.board >> 32);
+                bc[3] = (uint32_t)leaf.zx; bc[4] = (uint32_t)leaf.zy; bc[5] = (uint32_t)leaf.depth;
+            }
+            __syncthreads();
+            phase = (int)bc[0];
+            leaf.board = ((uint64_t)bc[2] << 32) | (uint64_t)bc[1];
+            leaf.zx = (int)bc[3]; leaf.zy = (int)bc[4]; leaf.depth = (int)bc[5];
+        } else {
+            phase      = __shfl(phase, j, 64);
+            leaf.board = ((uint64_t)__shfl((uint32_t)(leaf.board >> 32), j, 64) << 32) | (uint64_t)__shfl((uint32_t)leaf.board, j, 64);
+            leaf.zx    = __shfl(leaf.zx, j, 64);
+            leaf.zy    = __shfl(leaf.zy, j, 64);
+            leaf.depth = __shfl(leaf.depth, j, 64);
+        }
     }
     if (owner) {
         if (sv.on) {
@@ -298,16 +332,32 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) mcts_f32_kernel(cons
         } else if constexpr (!PERSIST) a.out.ep_len[e_local] = len;
         atomicAdd(a.eval_count, evals);
     }
+#ifdef TW_ABLATE
+    {   // wave-level: cycles from lane 0; per-lane counters: sum and max over the wave's owners
+        unsigned long long mx = c_inner, sm = owner ? c_inner : 0, ds = owner ? c_desc : 0;
+        for (int o = 32; o; o >>= 1) {
+            const unsigned long long m2 = ((unsigned long long)__shfl_xor((unsigned)(mx >> 32), o, 64) << 32) | __shfl_xor((unsigned)mx, o, 64);
+            mx = m2 > mx ? m2 : mx;
+            sm += ((unsigned long long)__shfl_xor((unsigned)(sm >> 32), o, 64) << 32) | __shfl_xor((unsigned)sm, o, 64);
+            ds += ((unsigned long long)__shfl_xor((unsigned)(ds >> 32), o, 64) << 32) | __shfl_xor((unsigned)ds, o, 64);
+        }
+        if (eng.lane == 0) {
+            atomicAdd(&g_mcts_stamps[0], c_fwd); atomicAdd(&g_mcts_stamps[1], c_tree); atomicAdd(&g_mcts_stamps[2], c_trips);
+            atomicAdd(&g_mcts_stamps[3], sm); atomicAdd(&g_mcts_stamps[4], mx); atomicAdd(&g_mcts_stamps[5], ds); atomicAdd(&g_mcts_stamps[6], 1ull);
+        }
+    }
+#endif
     eng.end();
 }
 
 template <int NT, int NC, int NW, bool PERSIST = false>
 static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    constexpr int EPB = NW * EPW;
+    using G = Geom<NT, NC, 0, NW>;
+    constexpr int EPB = G::Eng::EPB;
     const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / EPB : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
@@ -315,10 +365,24 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((mcts_f32_kernel<NT, NC, NW, PERSIST>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, s, a);
+#ifdef TW_ABLATE
+    unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mcts_stamps), zeros, sizeof(zeros)));
+#endif
+    hipLaunchKernelGGL((mcts_f32_kernel<NT, NC, NW, PERSIST>), dim3((unsigned)nb), dim3(64 * G::WAVES), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
+#ifdef TW_ABLATE
+    if (getenv("TW_STAMPS")) {
+        unsigned long long h[8];
+        TW_HIP(hipStreamSynchronize(s));
+        TW_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mcts_stamps), sizeof(h)));
+        const double w = (double)h[6];
+        fprintf(stderr, "mcts stamps: waves %.0f | per wave: fwd %.0f cyc, tree %.0f cyc, trips %.1f | per trip: fwd %.0f, tree %.0f | inner per lane-trip %.2f, max-lane inner per trip %.2f, descents per inner %.2f\n",
+                w, h[0] / w, h[1] / w, h[2] / w, (double)h[0] / h[2], (double)h[1] / h[2], (double)h[3] / (32.0 * h[2]), (double)h[4] / h[2], (double)h[5] / (double)h[3]);
+    }
+#endif
     if (blocks) *blocks = (uint32_t)nb;
-    if (threads) *threads = 64 * NW;
+    if (threads) *threads = 64 * G::WAVES;
     return TW_OK;
 }
 
@@ -327,9 +391,13 @@ static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
 {
     if (!a.solve.on && a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes())
         return launch_mcts_geom<NT, NC, 8, true>(a, s, blocks, threads);
-    const int nw = waves_per_group(a.num_episodes);
-    if (nw == 1) return launch_mcts_geom<NT, NC, 1>(a, s, blocks, threads);
-    if (nw == 2) return launch_mcts_geom<NT, NC, 2>(a, s, blocks, threads);
+    const int nw = geometry_for<NT>(a.num_episodes);
+    if constexpr (NT >= 4) { if (nw == -4) return launch_mcts_geom<NT, NC, -4>(a, s, blocks, threads); }
+    else if constexpr (NT == 2) { if (nw == -2) return launch_mcts_geom<NT, NC, -2>(a, s, blocks, threads); }
+    else {
+        if (nw == 1) return launch_mcts_geom<NT, NC, 1>(a, s, blocks, threads);
+        if (nw == 2) return launch_mcts_geom<NT, NC, 2>(a, s, blocks, threads);
+    }
     return launch_mcts_geom<NT, NC, 8>(a, s, blocks, threads);
 }
 

@@ -54,17 +54,18 @@ int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_
 }
 
 template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(const RolloutArgs a)
+__global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32_kernel(const RolloutArgs a)
 {
-    using Eng = Engine3<NT, NC, DBG, NW>;
+    using Eng = typename Geom<NT, NC, DBG, NW>::Eng;       // NW < 0: -NW waves share 32 episodes (Engine3S); all carry the same state
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);                               // first weight chunks stream in while the scramble runs
 
     const PuzzleConsts env = a.env;
     const int j = eng.j, h = eng.h;
-    uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);
+    uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)eng.ep_lane();
     const bool valid  = e_local < a.num_episodes;
+    const bool writer = h == 0 && eng.primary();          // the lane that stores the episode's records
     uint64_t e_global = a.episode_offset + e_local;
 
     PuzzleLane st;
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
         }
         // ---- push the record (ppo.rs:71-76), then is_final / step (ppo.rs:78-79) --------------
         if (alive) {
-            if (h == 0) {
+            if (writer) {
                 const uint64_t rec = rec_base + (uint64_t)t;
                 uint32_t pk[4];
                 obs_bytes(st.board, obs_base, pk);
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
             }
             if (puzzle_final(st, env)) {
                 alive = false; len = (uint32_t)t + 1u;
-                if constexpr (PERSIST) { if (h == 0) a.out.ep_len[e_local] = len; }
+                if constexpr (PERSIST) { if (writer) a.out.ep_len[e_local] = len; }
             } else { puzzle_step(st, env, action); ++t; }
         }
         if constexpr (PERSIST) {
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) rollout_f32_kernel(c
             }
         }
     }
-    if constexpr (!PERSIST) { if (valid && h == 0) a.out.ep_len[e_local] = len; }
+    if constexpr (!PERSIST) { if (valid && writer) a.out.ep_len[e_local] = len; }
     eng.end();
 }
 
@@ -162,10 +163,11 @@ uint64_t rollout_f32_resident_episodes() { return persist_blocks() * 8 * EPW; }
 template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
 static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    constexpr int EPB = NW * EPW, THREADS = 64 * NW;
+    using G = Geom<NT, NC, DBG, NW>;
+    constexpr int EPB = G::Eng::EPB, THREADS = 64 * G::WAVES;
     const uint64_t nb = PERSIST ? persist_blocks() : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;   // per instantiation: raise the dynamic-LDS limit above the 64 KiB default
     if (lds_bytes > attr_bytes) {
@@ -198,9 +200,13 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
     // small batches: fewer waves per workgroup, so that the episodes spread over more CUs
     if (a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes())
         return launch_geom<NT, NC, 0, 8, true>(a, s, blocks, threads);
-    const int nw = waves_per_group(a.num_episodes);
-    if (nw == 1) return launch_geom<NT, NC, 0, 1>(a, s, blocks, threads);
-    if (nw == 2) return launch_geom<NT, NC, 0, 2>(a, s, blocks, threads);
+    const int nw = geometry_for<NT>(a.num_episodes);
+    if constexpr (NT >= 4) { if (nw == -4) return launch_geom<NT, NC, 0, -4>(a, s, blocks, threads); }
+    else if constexpr (NT == 2) { if (nw == -2) return launch_geom<NT, NC, 0, -2>(a, s, blocks, threads); }
+    else {
+        if (nw == 1) return launch_geom<NT, NC, 0, 1>(a, s, blocks, threads);
+        if (nw == 2) return launch_geom<NT, NC, 0, 2>(a, s, blocks, threads);
+    }
     return launch_geom<NT, NC>(a, s, blocks, threads);
 }
 

@@ -11,17 +11,18 @@
 namespace tw {
 
 template <int NT, int NC, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) solve_f32_kernel(const SolveArgs a)
+__global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) solve_f32_kernel(const SolveArgs a)
 {
-    using Eng = Engine3<NT, NC, 0, NW>;
+    using Eng = typename Geom<NT, NC, 0, NW>::Eng;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
 
     const PuzzleConsts env = a.env;
-    const int j = eng.j, h = eng.h;
-    const uint64_t att   = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)(eng.wave * EPW + j);   // attempt index
+    const int h = eng.h;
+    const uint64_t att   = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)eng.ep_lane();   // attempt index
     const bool     valid = att < a.num_attempts;
+    const bool     writer = h == 0 && eng.primary();
     const uint64_t ep    = a.episode_offset + att / a.num_searches;       // episode: keys the start state
     const uint64_t key   = ep * (uint64_t)a.num_searches + att % a.num_searches;   // keys this attempt's draws
 
@@ -63,13 +64,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) solve_f32_kernel(con
                 const u32x4 w = rng_draw(a.seed, key, (uint32_t)t, STREAM_SOLVE);
                 action = sample_weighted(probs, 4, u32_to_unit(w.x));
             }
-            if (a.actions && h == 0) a.actions[att * (uint64_t)a.t_pad + (uint64_t)t] = (uint8_t)action;
+            if (a.actions && writer) a.actions[att * (uint64_t)a.t_pad + (uint64_t)t] = (uint8_t)action;
             puzzle_step(st, env, action);                             // solve.rs:56
             ++t;
             if (puzzle_final(st, env)) alive = false;
         }
     }
-    if (valid && h == 0) {
+    if (valid && writer) {
         total = total + puzzle_reward(st, env);                       // solve.rs:65-66
         a.success[att] = puzzle_solved(st, env) ? 1.0f : 0.0f;        // solve.rs:68
         a.total[att]   = total;
@@ -81,10 +82,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) solve_f32_kernel(con
 template <int NT, int NC, int NW>
 static int launch_solve_geom(const SolveArgs &a, hipStream_t s)
 {
-    constexpr int EPB = NW * EPW;
+    using G = Geom<NT, NC, 0, NW>;
+    constexpr int EPB = G::Eng::EPB;
     const uint64_t nb = (a.num_attempts + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
-    const size_t lds_bytes = engine3_lds_floats<NT>(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("solve: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
@@ -92,7 +94,7 @@ static int launch_solve_geom(const SolveArgs &a, hipStream_t s)
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_bytes = lds_bytes;
     }
-    hipLaunchKernelGGL((solve_f32_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, s, a);
+    hipLaunchKernelGGL((solve_f32_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(64 * G::WAVES), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     return TW_OK;
 }
@@ -100,9 +102,13 @@ static int launch_solve_geom(const SolveArgs &a, hipStream_t s)
 template <int NT, int NC>
 static int launch_solve_one(const SolveArgs &a, hipStream_t s)
 {
-    const int nw = waves_per_group(a.num_attempts);
-    if (nw == 1) return launch_solve_geom<NT, NC, 1>(a, s);
-    if (nw == 2) return launch_solve_geom<NT, NC, 2>(a, s);
+    const int nw = geometry_for<NT>(a.num_attempts);
+    if constexpr (NT >= 4) { if (nw == -4) return launch_solve_geom<NT, NC, -4>(a, s); }
+    else if constexpr (NT == 2) { if (nw == -2) return launch_solve_geom<NT, NC, -2>(a, s); }
+    else {
+        if (nw == 1) return launch_solve_geom<NT, NC, 1>(a, s);
+        if (nw == 2) return launch_solve_geom<NT, NC, 2>(a, s);
+    }
     return launch_solve_geom<NT, NC, 8>(a, s);
 }
 
