@@ -49,6 +49,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     flags = list(FLAGS)
     if os.environ.get("TW_ABLATE"):      # timing-only ablation variants of the rollout kernel (profiling aid)
         flags.append("-DTW_ABLATE")
+    if os.environ.get("TW_EXTRA_FLAGS"):
+        flags += os.environ["TW_EXTRA_FLAGS"].split()
     objs = []
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     procs = []

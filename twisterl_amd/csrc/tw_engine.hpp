@@ -347,13 +347,15 @@ struct Engine3 {
 // =====================================================================================================
 // Engine3S: the small-batch geometry.  The NS waves of a workgroup (one per SIMD) share ONE group of 32
 // episodes and split the hidden units: wave w owns the row tiles [w*NT/NS, (w+1)*NT/NS) of the common
-// Linear, so the 32-column forward runs on NS matrix cores instead of one.  Every wave computes the
-// (cheap) EmbeddingBag gather of all 32 episodes itself; the k-ordered head chain is handed from wave to
-// wave through LDS (partial accumulators are exact, so the result is still the oracle's single fma chain).
+// Linear, so the 32-column forward runs on NS matrix cores instead of one.  The EmbeddingBag gather is split
+// the other way: wave w sums the rows for 8/NS of the 8 k-steps of the NEXT chunk and publishes them as B
+// operands through a double-buffered LDS exchange (replicating the gather in every wave makes the LDS the
+// bottleneck: measured 7k cycles per chunk).  The k-ordered head chain is handed from wave to wave through
+// LDS (partial accumulators are exact, so the result is still the oracle's single fma chain).
 // Same weight images, ring and LDS map as Engine3 + a 2 KiB exchange area.  All NS waves carry the same
 // episode state; only wave 0 (`primary()`) stores.
 // =====================================================================================================
-constexpr int R3S_XCHG = 256, R3S_USER = 256;      // floats: head hand-off | kernel use (MCTS leaf broadcast)
+constexpr int R3S_XCHG = 256 + 1024, R3S_USER = 256;   // floats: head hand-off + B-operand exchange [2][2][64][4] | kernel use (MCTS leaf broadcast)
 
 template <int NT, int NC, int NS>
 struct Engine3S : Engine3<NT, NC, 0, NS> {
@@ -363,6 +365,32 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
     static_assert(NT % NS == 0 && (NTL == 1 || NTL == 2), "Engine3S: one or two row tiles per wave");
 
     float *lds_x, *lds_user;
+    uint32_t voff;                 // per-lane byte offset inside a DMA piece
+#ifdef TW_ABLATE
+    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk compute | vmcnt wait | barrier wait | heads | -
+#define TW_S3(var) const unsigned long long var = __builtin_readcyclecounter()
+#define TW_A3(i, a, b) stq[i] += (b) - (a)
+#else
+#define TW_S3(var)
+#define TW_A3(i, a, b)
+#endif
+
+    // DMA op with a scalar source (SGPR base + lane*16): no VALU address arithmetic, which a lone wave per SIMD cannot hide
+    // behind its f32 MFMAs.  Piece order as in Engine3::stream_op.
+    __device__ __forceinline__ void stream_op_s(int chunk, int slot, int op)
+    {
+        int piece = this->wave + NS * op;
+        piece = piece < B::NPIECE ? piece : B::NPIECE - 1;
+        const bool is_w = piece < B::WPIECE;
+        const int  tp   = piece - B::WPIECE;
+        const float *src = is_w ? this->pol.w1p + (size_t)chunk * WSLOT + piece * 256
+                                : this->pol.t_img16 + (size_t)chunk * R3_TSLOT + tp * 256;
+        float *dst = is_w ? this->lds_w + slot * WSLOT + piece * 256 : this->lds_t + slot * R3_TSLOT + tp * 256;
+        const unsigned d = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)dst;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                     :: "v"(voff), "s"(__builtin_amdgcn_readfirstlane(d)), "s"(src)
+                     : "memory", "m0");
+    }
 
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
     __device__ __forceinline__ bool primary() const { return this->wave == 0; }
@@ -373,6 +401,7 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
         B::begin1(p, lds);
         lds_x = lds + engine3_lds_floats<NT>(p.obs_size);
         lds_user = lds_x + R3S_XCHG;
+        voff = (uint32_t)this->lane * 16u;
     }
 
     __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
@@ -388,88 +417,166 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
         const int t0    = wave * NTL;                                           // first row tile of this wave
         const int a_off = ((h * NQ + (t0 >> 2)) * 32 + j) * 4 + (t0 & 3);       // float offset of its A operands in a k-step block
         lds_cfloat *ga[NC + 1];
-        ga[0] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT + this->bias_row * R3_LSTR + h * (KC / 2));
+        constexpr int GW = 8 / NS;                                              // k-steps of a chunk this wave gathers
+        ga[0] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT + this->bias_row * R3_LSTR + h * (KC / 2)) + GW * wave;
 #pragma unroll
-        for (int q = 0; q < NC; ++q) ga[q + 1] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT) + rowoff[q];
+        for (int q = 0; q < NC; ++q) ga[q + 1] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT) + rowoff[q] + GW * wave;
+
+        // this wave's share (8/NS k-steps) of the B operands of the chunk the gather pointers point at: all LDS reads are
+        // issued first (gather_issue), the sums and the publication into exchange buffer `buf` follow the chunk's MFMAs
+        float *xb = lds_x + 256;
+        typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
+        f32x2 gr2[NS == 4 ? NC + 1 : 1];
+        f32x4 gr4[NS == 4 ? 1 : NC + 1];
+        auto gather_read = [&](int q) {
+            if constexpr (NS == 4) gr2[q] = *reinterpret_cast<lds_cf2 *>(ga[q]);
+            else gr4[q] = *reinterpret_cast<lds_cf4 *>(ga[q]);
+        };
+        auto gather_issue = [&]() {
+#pragma unroll
+            for (int q = 0; q <= NC; ++q) gather_read(q);
+        };
+        auto gather_finish = [&](int buf) {
+            if constexpr (NS == 4) {
+                f32x2 sm = gr2[0];                                                 // bias row, then the cells in order
+#pragma unroll
+                for (int q = 1; q <= NC; ++q) sm = pk_add(sm, gr2[q]);
+                sm[0] = relu_lim(sm[0], this->emb_lim); sm[1] = relu_lim(sm[1], this->emb_lim);
+                *reinterpret_cast<f32x2 *>(xb + ((buf * 2 + (wave >> 1)) * 64 + this->lane) * 4 + 2 * (wave & 1)) = sm;
+            } else {
+                f32x2 lo = __builtin_shufflevector(gr4[0], gr4[0], 0, 1), hi = __builtin_shufflevector(gr4[0], gr4[0], 2, 3);
+#pragma unroll
+                for (int q = 1; q <= NC; ++q) {
+                    lo = pk_add(lo, __builtin_shufflevector(gr4[q], gr4[q], 0, 1));
+                    hi = pk_add(hi, __builtin_shufflevector(gr4[q], gr4[q], 2, 3));
+                }
+                f32x4 b;
+                b[0] = lo[0]; b[1] = lo[1]; b[2] = hi[0]; b[3] = hi[1];
+                this->finish_b(b);
+                *reinterpret_cast<f32x4 *>(xb + ((buf * 2 + wave) * 64 + this->lane) * 4) = b;
+            }
+        };
+        auto advance = [&](int from, int to) {
+            const int delta = (to - from) * R3_TSLOT;
+#pragma unroll
+            for (int q = 0; q <= NC; ++q) ga[q] += delta;
+        };
 
         int s0 = this->rp;
+        float aw[NTL];
+        {
+            lds_cfloat *ap = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
+            if constexpr (NTL == 2) {
+                const f32x2 a2 = *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(ap);
+                aw[0] = a2[0]; aw[1] = a2[1];
+            } else aw[0] = *ap;
+        }
+        TW_S3(q_in);
+        {
+            const int s1 = s0 == 2 ? 0 : s0 + 1;
+            gather_issue();
+            gather_finish(0);
+            advance(s0, s1);
+            __syncthreads();
+        }
+        TW_S3(q_pro);
+        TW_A3(0, q_in, q_pro);
         for (int c = 0; c < this->n_chunks; ++c) {
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
             int sc = c + 2; if (sc >= this->n_chunks) sc -= this->n_chunks;     // chunk streamed now (wraps into the next forward)
             if (this->n_chunks == 1) sc = 0;
-#pragma unroll
-            for (int op = 0; op < NOPS; ++op) this->stream_op(sc, s2, op);
+            TW_S3(q_c0);
+            f32x4 bg[2];
+            bg[0] = *reinterpret_cast<const f32x4 *>(xb + (((c & 1) * 2 + 0) * 64 + this->lane) * 4);
+            bg[1] = *reinterpret_cast<const f32x4 *>(xb + (((c & 1) * 2 + 1) * 64 + this->lane) * 4);
             lds_cfloat *wb = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
+            lds_cfloat *wn = (lds_cfloat *)(this->lds_w + s1 * WSLOT + a_off);
+            // 8*NTL MFMAs; in the shadow of each: its share of the DMA ops of chunk c+2 (scalar work), of the gather reads of
+            // chunk c+1 (which sits complete in slot s1; after the last chunk that is chunk 0 of the next forward, gathered with
+            // the rows of this one -- never consumed, the next prologue rewrites exchange buffer 0) and the next A operands
+            constexpr int M = 8 * NTL;
 #pragma unroll
-            for (int ng = 0; ng < 2; ++ng) {
-                // EmbeddingBag: bias row, then the cells in order (four k-steps per 16-byte word)
-                const f32x4 r0 = *reinterpret_cast<lds_cf4 *>(ga[0] + 4 * ng);
-                f32x2 lo = __builtin_shufflevector(r0, r0, 0, 1), hi = __builtin_shufflevector(r0, r0, 2, 3);
+            for (int m = 0; m < M; ++m) {
+                const int ks = m / NTL, r = m % NTL;
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[r], bg[ks >> 2][ks & 3], acc[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 1; q <= NC; ++q) {
-                    const f32x4 rq = *reinterpret_cast<lds_cf4 *>(ga[q] + 4 * ng);
-                    lo = pk_add(lo, __builtin_shufflevector(rq, rq, 0, 1));
-                    hi = pk_add(hi, __builtin_shufflevector(rq, rq, 2, 3));
-                }
-                f32x4 bq;
-                bq[0] = lo[0]; bq[1] = lo[1]; bq[2] = hi[0]; bq[3] = hi[1];
-                this->finish_b(bq);
+                for (int op = m * NOPS / M; op < (m + 1) * NOPS / M; ++op) stream_op_s(sc, s2, op);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    lds_cfloat *ap = wb + (ng * 4 + u) * 2 * NQ * 128;
+                for (int q = m * (NC + 1) / M; q < (m + 1) * (NC + 1) / M; ++q) gather_read(q);
+                if (r == NTL - 1) {
+                    lds_cfloat *ap = ks < 7 ? wb + (ks + 1) * 2 * NQ * 128 : wn;
                     if constexpr (NTL == 2) {
                         const f32x2 a2 = *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(ap);
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0], bq[u], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1], bq[u], acc[1], 0, 0, 0);
-                    } else {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(*ap, bq[u], acc[0], 0, 0, 0);
-                    }
+                        aw[0] = a2[0]; aw[1] = a2[1];
+                    } else aw[0] = *ap;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            {
-                const int delta = (s1 - s0) * R3_TSLOT;
-#pragma unroll
-                for (int q = 0; q <= NC; ++q) ga[q] += delta;
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            gather_finish((c + 1) & 1);
+            advance(s1, s2);
+            TW_S3(q_c1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c+2 have landed
+            TW_S3(q_c2);
             __syncthreads();
+            TW_S3(q_c3);
+            TW_A3(1, q_c0, q_c1); TW_A3(2, q_c1, q_c2); TW_A3(3, q_c2, q_c3);
             s0 = s1;
         }
         this->rp = s0;
 
-        // heads: the hidden-ordered chain runs through the waves in turn
-        f32x16 hacc;
+        // heads.  The k-ordered chain over the hidden units is serial, and as a chain of dependent 32x32x2 MFMAs it costs
+        // 64 cycles per two units.  Here instead: every wave writes its ReLU'd hidden units into the ring slot the last chunk
+        // just freed ([unit/4][episode][4], units >= 128 in the W slot), then half-wave hw = 2*wave + h runs the chain of
+        // output hw (4 logits, value) for its 32 episodes as 4-cycle v_fma_f32 steps -- the same fma chain, bit for bit.
+        TW_S3(q_h0);
+        {
+            const int fs = s0 == 0 ? 2 : s0 - 1;                                 // the slot of the chunk consumed last
+            float *hid_lo = this->lds_t + fs * R3_TSLOT, *hid_hi = this->lds_w + fs * WSLOT;
+            lds_cfloat *b1_lane = (lds_cfloat *)(this->lds_b1 + h * (NT * 16)) + 16 * t0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) hacc[g] = 0.0f;
-        lds_cfloat *b1_lane = (lds_cfloat *)(this->lds_b1 + h * (NT * 16)) + 16 * t0;
-        lds_cfloat *wh_lane = (lds_cfloat *)(this->lds_wh + ((j < 8 ? j : 8) * 2 + h) * (NT * 16)) + 16 * t0;
-        f32x4 *xl = reinterpret_cast<f32x4 *>(lds_x) + this->lane;
-        for (int w = 0; w < NS; ++w) {
-            if (wave == w) {
-                if (w > 0) {
-                    const f32x4 p = *xl;
-                    hacc[0] = p[0]; hacc[1] = p[1]; hacc[2] = p[2]; hacc[3] = p[3];
-                }
+            for (int r = 0; r < NTL; ++r) {
+                float *dst = ((t0 + r) < 4 ? hid_lo : hid_hi) + ((t0 + r) & 3) * 8 * 128 + j * 4 + h;
 #pragma unroll
-                for (int bl = 0; bl < NTL * 4; ++bl) {
-                    const int r = bl >> 2, g0 = (bl & 3) * 4;
-                    const f32x4 hb = *reinterpret_cast<lds_cf4 *>(b1_lane + 4 * bl);
-                    const f32x4 hw = *reinterpret_cast<lds_cf4 *>(wh_lane + 4 * bl);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 hb = *reinterpret_cast<lds_cf4 *>(b1_lane + 16 * r + 4 * g4);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float hv = relu_lim(acc[r][g0 + g] + hb[g], this->common_lim);
-                        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(hw[g], hv, hacc, 0, 0, 0);
+                        const int gg = 4 * g4 + g;
+                        dst[(gg >> 1) * 128 + 2 * (gg & 1)] = relu_lim(acc[r][gg] + hb[g], this->common_lim);
                     }
                 }
-                f32x4 o; o[0] = hacc[0]; o[1] = hacc[1]; o[2] = hacc[2]; o[3] = hacc[3];
-                *xl = o;
             }
             __syncthreads();
-        }
-        const f32x4 fl = reinterpret_cast<const f32x4 *>(lds_x)[j];
+            constexpr int NPASS = (5 + 2 * NS - 1) / (2 * NS);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lg[i] = fl[i] + this->lds_bh[i];
-        value = lds_x[(j + 32) * 4] + this->lds_bh[4];
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int o  = 2 * wave + h + 2 * NS * pass;
+                const int oc = o < 4 ? o : 4;
+                lds_cfloat *we = (lds_cfloat *)(this->lds_wh + (oc * 2) * (NT * 16));   // even units of output oc; odd units NT*16 further
+                float a = 0.0f;
+#pragma unroll
+                for (int m = 0; m < NT * 4; ++m) {                               // 8 hidden units per trip
+                    const f32x4 w0 = *reinterpret_cast<lds_cf4 *>(we + 4 * m);
+                    const f32x4 w1 = *reinterpret_cast<lds_cf4 *>(we + NT * 16 + 4 * m);
+                    const float *hp = (m < 16 ? hid_lo + (2 * m) * 128 : hid_hi + (2 * m - 32) * 128) + j * 4;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4 *>(hp);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(hp + 128);
+                    a = __builtin_fmaf(w0[0], x0[0], a); a = __builtin_fmaf(w1[0], x0[1], a);
+                    a = __builtin_fmaf(w0[1], x0[2], a); a = __builtin_fmaf(w1[1], x0[3], a);
+                    a = __builtin_fmaf(w0[2], x1[0], a); a = __builtin_fmaf(w1[2], x1[1], a);
+                    a = __builtin_fmaf(w0[3], x1[2], a); a = __builtin_fmaf(w1[3], x1[3], a);
+                }
+                if (o < 5) lds_x[o * 32 + j] = a + this->lds_bh[o];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[i] = lds_x[i * 32 + j];
+            value = lds_x[4 * 32 + j];
+        }
+        TW_S3(q_h1);
+        TW_A3(4, q_h0, q_h1);
     }
 };
 

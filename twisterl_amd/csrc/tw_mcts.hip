@@ -35,7 +35,7 @@ size_t mcts_node_bytes() { return sizeof(MctsNode); }
 
 constexpr uint32_t NONE = 0xffffffffu;
 #ifdef TW_ABLATE   // diagnostic build: per-wave cycle accounting (forward | tree phase | loop trips | searches consumed | max trips)
-__device__ unsigned long long g_mcts_stamps[8];
+__device__ unsigned long long g_mcts_stamps[16];
 #endif
 enum { PH_ROOT = 0, PH_LEAF = 1, PH_DONE = 2 };
 
@@ -343,6 +343,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
         }
         if (eng.lane == 0) {
             atomicAdd(&g_mcts_stamps[0], c_fwd); atomicAdd(&g_mcts_stamps[1], c_tree); atomicAdd(&g_mcts_stamps[2], c_trips);
+            if constexpr (Eng::SPLIT) { for (int i = 0; i < 5; ++i) atomicAdd(&g_mcts_stamps[8 + i], eng.stq[i]); }
             atomicAdd(&g_mcts_stamps[3], sm); atomicAdd(&g_mcts_stamps[4], mx); atomicAdd(&g_mcts_stamps[5], ds); atomicAdd(&g_mcts_stamps[6], 1ull);
         }
     }
@@ -366,19 +367,21 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
         attr_bytes = lds_bytes;
     }
 #ifdef TW_ABLATE
-    unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long zeros[16] = {0};
     if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mcts_stamps), zeros, sizeof(zeros)));
 #endif
     hipLaunchKernelGGL((mcts_f32_kernel<NT, NC, NW, PERSIST>), dim3((unsigned)nb), dim3(64 * G::WAVES), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
-        unsigned long long h[8];
+        unsigned long long h[16];
         TW_HIP(hipStreamSynchronize(s));
         TW_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mcts_stamps), sizeof(h)));
         const double w = (double)h[6];
         fprintf(stderr, "mcts stamps: waves %.0f | per wave: fwd %.0f cyc, tree %.0f cyc, trips %.1f | per trip: fwd %.0f, tree %.0f | inner per lane-trip %.2f, max-lane inner per trip %.2f, descents per inner %.2f\n",
                 w, h[0] / w, h[1] / w, h[2] / w, (double)h[0] / h[2], (double)h[1] / h[2], (double)h[3] / (32.0 * h[2]), (double)h[4] / h[2], (double)h[5] / (double)h[3]);
+        fprintf(stderr, "  split engine per trip: prologue %.0f, chunk compute %.0f, vmcnt wait %.0f, barrier wait %.0f, heads %.0f\n",
+                (double)h[8] / h[2], (double)h[9] / h[2], (double)h[10] / h[2], (double)h[11] / h[2], (double)h[12] / h[2]);
     }
 #endif
     if (blocks) *blocks = (uint32_t)nb;
