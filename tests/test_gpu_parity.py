@@ -251,6 +251,8 @@ def _assert_same_az(g, o, n_cells):
     (3, 3, 4, 32, 32, 16, 0, 1, False),      # zero searches -> uniform probs (search.rs:184-186)
     (3, 3, 0, 32, 32, 10, 5, 1, False),      # difficulty 0: root is final
     (4, 4, 3, 512, 256, 48, 12, 1, False),   # Puzzle-15 at the benchmark's network size
+    (3, 3, 6, 64, 128, 40, 60, 1, False),    # hidden 128: four waves share 32 episodes, one row tile each
+    (3, 3, 10, 32, 64, 12, 400, 1, False),   # deep trees: search paths longer than the 8 levels kept in LDS
 ])
 def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
     n2 = w * h

@@ -357,12 +357,13 @@ struct RolloutArgs {
     unsigned int   *queue;         // next unassigned episode, or null
 };
 
-// Waves per workgroup of the f32 engine for a batch of n columns (episodes / attempts): 8 (two per SIMD) is the
-// throughput geometry; with fewer than ~190 workgroups of 256 columns the chip is not filled, so smaller groups
-// (64 or 32 columns) spread the batch over more CUs -- every workgroup streams the whole weight set anyway.
+// Waves per workgroup of the f32 engine for a batch of n columns (episodes / attempts): 8 (two per SIMD, 256 columns) is
+// the throughput geometry.  Below ~40k columns the small-batch geometries win (measured crossover of the rollout,
+// scripts/geom_sweep.py): 32 columns per workgroup -- shared by four waves that split the hidden units (Engine3S,
+// tw_engine.hpp: geometry_for()) where the policy has >= 64 hidden units, else 64- or 32-column workgroups of this engine.
 inline int waves_per_group(uint64_t n)
 {
-    if ((n + 255) / 256 >= 192) return 8;
+    if ((n + 255) / 256 >= 156) return 8;
     if ((n + 63) / 64 >= 192) return 2;
     return 1;
 }

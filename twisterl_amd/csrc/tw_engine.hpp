@@ -3,6 +3,7 @@
 // with both weight streams running through a ring of LDS slots.  See tw_rollout.hip for the design notes.
 #pragma once
 #include "tw_common.hpp"
+#include <cstdlib>
 
 namespace tw {
 
@@ -104,6 +105,7 @@ struct Engine3 {
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size); }
     __device__ __forceinline__ bool primary() const { return true; }           // this wave owns its episodes' stores
     __device__ __forceinline__ int  ep_lane() const { return wave * EPW + j; }  // episode index inside the workgroup
+    __device__ __forceinline__ bool owns_lane() const { return true; }          // per-episode serial work (MCTS tree) of lane j runs here
 
     PolicyDev pol;
     int tid, lane, wave, j, h;
@@ -395,6 +397,9 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
     __device__ __forceinline__ bool primary() const { return this->wave == 0; }
     __device__ __forceinline__ int  ep_lane() const { return this->j; }
+    // all NS waves carry every episode's state: serial per-episode work is dealt out 32/NS episodes per wave (less divergence,
+    // NS instruction streams instead of one)
+    __device__ __forceinline__ bool owns_lane() const { return this->wave == this->j / (EPW / NS); }
 
     __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
     {
@@ -589,7 +594,8 @@ template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -2> { using Eng = En
 // geometry for n episodes: 8 = the throughput shape; below ~3/4 of a chip of 256-episode workgroups the split shape
 template <int NT> inline int geometry_for(uint64_t n)
 {
-    const int nw = waves_per_group(n);
+    int nw = waves_per_group(n);
+    if (const char *f = getenv("TW_FORCE_GEOM")) nw = atoi(f) == 8 ? 8 : 1;     // diagnostic: 8 = throughput shape, else small-batch
     if (nw == 8 || NT < 2) return nw;
     return NT >= 4 ? -4 : -2;
 }

@@ -34,6 +34,7 @@ static_assert(sizeof(MctsNode) == 32, "MctsNode must be 32 bytes");
 size_t mcts_node_bytes() { return sizeof(MctsNode); }
 
 constexpr uint32_t NONE = 0xffffffffu;
+constexpr int PATH_DEPTH = 8;     // levels of the search path kept in LDS per episode (deeper paths fall back to parent chasing)
 #ifdef TW_ABLATE   // diagnostic build: per-wave cycle accounting (forward | tree phase | loop trips | searches consumed | max trips)
 __device__ unsigned long long g_mcts_stamps[16];
 #endif
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
     // solve mode: lane pair = ATTEMPT (episode, search); its draws are keyed like single_solve's (tw_solve.hip)
     const uint64_t sv_ep    = sv.on ? a.episode_offset + e_local / sv.num_searches : 0;
     uint64_t       e_global = sv.on ? sv_ep * (uint64_t)sv.num_searches + e_local % sv.num_searches : a.episode_offset + e_local;
-    const bool     owner    = valid && h == 0 && eng.primary();   // the lane that walks / mutates the tree
+    const bool     owner    = valid && h == 0 && eng.owns_lane();   // the lane that walks / mutates the tree
     MctsNode *nodes = a.arena + (valid ? slot : 0) * (uint64_t)a.node_cap;
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
@@ -97,10 +98,34 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
     uint32_t obs_base[4];
     obs_base_words(env.n_cells, obs_base);
 
+    // The search path (root .. current node) with the value_sum / visit_count read on the way down, per owner lane in LDS
+    // ([level][episode], three planes): back-propagation then needs no reads at all -- it stores value_sum + v and visit + 1
+    // for every level at once instead of chasing parent pointers through HBM (one dependent round trip per level).
+    float    *p_vs  = lds + Eng::lds_floats(a.pol.obs_size) + eng.ep_lane();
+    uint32_t *p_idx = reinterpret_cast<uint32_t *>(p_vs + PATH_DEPTH * Eng::EPB);
+    uint32_t *p_vis = p_idx + PATH_DEPTH * Eng::EPB;
+    int      plen = 0;
+    bool     overflow = false;
+    float    root_vs = 0.0f;                              // the root's record lives in registers between searches
+    uint32_t root_visit = 0, root_cb = 0, root_nc = 0;
+    auto st_stats = [&](uint32_t i, float vs, uint32_t vis) {          // value_sum, visit_count: one 8-byte store
+        uint2 w; w.x = __float_as_uint(vs); w.y = vis;
+        *reinterpret_cast<uint2 *>(&nodes[i].value_sum) = w;
+    };
+    auto push = [&](uint32_t idx, float vs, uint32_t vis) {
+        if (plen < PATH_DEPTH) { p_idx[plen * Eng::EPB] = idx; p_vs[plen * Eng::EPB] = vs; p_vis[plen * Eng::EPB] = vis; ++plen; }
+        else overflow = true;
+    };
+
     eng.begin2();
 
 #ifdef TW_ABLATE
-    unsigned long long c_fwd = 0, c_tree = 0, c_trips = 0, c_search = 0, c_inner = 0, c_desc = 0;
+    unsigned long long c_fwd = 0, c_tree = 0, c_trips = 0, c_inner = 0, c_desc = 0, c_pre = 0, c_dsc = 0, c_bp = 0, c_wl = 0;
+#define TW_MS(var) const unsigned long long var = __builtin_readcyclecounter()
+#define TW_MA(acc, a, b) acc += (b) - (a)
+#else
+#define TW_MS(var)
+#define TW_MA(acc, a, b)
 #endif
     while (__syncthreads_or(phase != PH_DONE ? 1 : 0)) {
 #ifdef TW_ABLATE
@@ -139,11 +164,15 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
         if (owner && phase != PH_DONE) {
             ++evals;
             // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step
-            auto expand = [&](uint32_t idx, const PuzzleLane &s) {
+            float pri[4] = {0.0f, 0.0f, 0.0f, 0.0f};        // priors of the children just created, in child order
+            auto expand = [&](uint32_t idx, const PuzzleLane &s) -> uint32_t {
                 uint32_t cnt = 0;
 #pragma unroll
                 for (int act = 0; act < 4; ++act) {
                     if (!(probs[act] > 0.0f)) continue;
+                    // (cnt <= act: a compile-time chain of selects instead of a dynamically indexed register array)
+                    if (cnt == 0) pri[0] = probs[act]; else if (cnt == 1) pri[1] = probs[act];
+                    else if (cnt == 2) pri[2] = probs[act]; else pri[3] = probs[act];
                     PuzzleLane c = s;
                     puzzle_step(c, env, act);
                     MctsNode nn;
@@ -153,42 +182,51 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                     nodes[n_nodes + cnt] = nn;
                     ++cnt;
                 }
-                nodes[idx].child_base = n_nodes;
-                nodes[idx].n_children = (uint8_t)cnt;
+                nodes[idx].child_base = n_nodes; nodes[idx].n_children = (uint8_t)cnt;
                 n_nodes += cnt;
+                return cnt;
             };
-            // backpropagate (search.rs:45-53)
+            // backpropagate (search.rs:45-53): value_sum += v, visit_count += 1 on every node of the path
             auto backprop = [&](uint32_t idx, float val) {
-                while (idx != NONE) {
-                    MctsNode &n = nodes[idx];
-                    n.value_sum = n.value_sum + val;
-                    n.visit += 1;
-                    idx = n.parent;
+                if (!overflow) {
+                    for (int l = 0; l < plen; ++l)
+                        st_stats(p_idx[l * Eng::EPB], p_vs[l * Eng::EPB] + val, p_vis[l * Eng::EPB] + 1u);
+                } else {
+                    while (idx != NONE) {
+                        const MctsNode n = nodes[idx];
+                        st_stats(idx, n.value_sum + val, n.visit + 1u);
+                        idx = n.parent;
+                    }
                 }
+                root_vs = root_vs + val; root_visit += 1u;
             };
 
+            TW_MS(m_pre0);
             if (phase == PH_ROOT) {
                 // root node (search.rs:120-129): visit_count 1, then expand with the root priors
                 MctsNode r;
                 r.board = st.board; r.value_sum = 0.0f; r.visit = 1; r.prior = 0.0f; r.parent = NONE;
                 r.child_base = 0; r.n_children = 0; r.action = 0xff; r.depth = (uint16_t)st.depth;
                 nodes[0] = r; n_nodes = 1;
-                expand(0, st);
+                root_vs = 0.0f; root_visit = 1u; root_cb = 1u;
+                root_nc = expand(0, st);
                 it = 0;
             } else {
-                // the leaf just evaluated (search.rs:154-159): expand, sample a child by the priors
-                expand(node, leaf);
-                const MctsNode nd = nodes[node];
-                if (nd.n_children > 0) {
-                    float pri[4];
-                    for (int c = 0; c < nd.n_children; ++c) pri[c] = nodes[nd.child_base + c].prior;
+                // the leaf just evaluated (search.rs:154-159): expand, sample a child by the priors (the children were
+                // written a moment ago: their priors are still in registers)
+                const uint32_t cb = n_nodes;
+                const uint32_t nch = expand(node, leaf);
+                if (nch > 0) {
                     const u32x4 w = rng_draw(a.seed, e_global, it * MED + expanded, STREAM_MCTS | ((uint32_t)t << 8));
-                    node = nd.child_base + (uint32_t)sample_weighted(pri, nd.n_children, u32_to_unit(w.x));
+                    node = cb + (uint32_t)sample_weighted(pri, (int)nch, u32_to_unit(w.x));
+                    push(node, 0.0f, 0u);
                 }
                 value = nn_value;
                 ++expanded;
             }
 
+            TW_MS(m_pre1);
+            TW_MA(c_pre, m_pre0, m_pre1);
             // run the search loop until a leaf needs the network or the move is finished
             bool resume_expand = (phase == PH_LEAF);
             MctsNode cur; bool have_cur = false;      // record of `node` when it was just read by the descent
@@ -202,9 +240,8 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) --------------
                         float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                        const MctsNode r = nodes[0];
-                        for (int c = 0; c < r.n_children; ++c) {
-                            const MctsNode ch = nodes[r.child_base + c];
+                        for (uint32_t c = 0; c < root_nc; ++c) {
+                            const MctsNode ch = nodes[root_cb + c];
                             mp[ch.action] = (float)ch.visit;
                         }
                         float sum = 0.0f;
@@ -263,8 +300,12 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                     }
                     // descend to a leaf by UCB (search.rs:133-138, next :77-91, ucb :29-39).  The chosen child's record is
                     // kept in registers: one dependent HBM round trip per level (its children) instead of two
+                    TW_MS(m_d0);
                     node = 0;
-                    cur = nodes[0];
+                    cur.board = st.board; cur.value_sum = root_vs; cur.visit = root_visit; cur.prior = 0.0f; cur.parent = NONE;
+                    cur.child_base = root_cb; cur.n_children = (uint8_t)root_nc; cur.action = 0xff; cur.depth = (uint16_t)st.depth;
+                    plen = 0; overflow = false;
+                    push(0u, root_vs, root_visit);
                     for (;;) {
                         if (cur.n_children == 0) break;
                         uint32_t best = NONE; float best_ucb = -__builtin_inff();
@@ -281,12 +322,15 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                         }
                         if (best == NONE) break;        // all-NaN UCB: the reference panics here
                         node = best; cur = bestn;
+                        push(best, bestn.value_sum, bestn.visit);
 #ifdef TW_ABLATE
                         ++c_desc;
 #endif
                     }
                     value = 0.0f; expanded = 0;
                     have_cur = true;
+                    TW_MS(m_d1);
+                    TW_MA(c_dsc, m_d0, m_d1);
                 }
                 resume_expand = false;
                 // leaf phase (search.rs:143-160)
@@ -297,8 +341,14 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                     value = puzzle_reward(s, env);                                   // :146
                     if (!puzzle_final(s, env)) { phase = PH_LEAF; leaf = s; break; } // :149-155 needs the network
                 }
+                TW_MS(m_b0);
                 backprop(node, value);                                               // :163
                 ++it;
+                TW_MS(m_b1);
+                TW_MA(c_bp, m_b0, m_b1);
+#ifdef TW_ABLATE
+                ++c_wl;
+#endif
             }
         }
 #ifdef TW_ABLATE
@@ -307,7 +357,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
         // mirror what the other lanes of the episode need for the next collective evaluation
         if constexpr (Eng::SPLIT) {        // lanes j / j+32 of every wave of the workgroup: through LDS
             uint32_t *bc = reinterpret_cast<uint32_t *>(eng.lds_user) + j * 8;
-            if (h == 0 && eng.primary()) {
+            if (h == 0 && eng.owns_lane()) {
                 bc[0] = (uint32_t)phase; bc[1] = (uint32_t)leaf.board; bc[2] = (uint32_t)(leaf.board >> 32);
                 bc[3] = (uint32_t)leaf.zx; bc[4] = (uint32_t)leaf.zy; bc[5] = (uint32_t)leaf.depth;
             }
@@ -344,6 +394,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
         if (eng.lane == 0) {
             atomicAdd(&g_mcts_stamps[0], c_fwd); atomicAdd(&g_mcts_stamps[1], c_tree); atomicAdd(&g_mcts_stamps[2], c_trips);
             if constexpr (Eng::SPLIT) { for (int i = 0; i < 5; ++i) atomicAdd(&g_mcts_stamps[8 + i], eng.stq[i]); }
+            atomicAdd(&g_mcts_stamps[13], c_pre); atomicAdd(&g_mcts_stamps[14], c_dsc); atomicAdd(&g_mcts_stamps[15], c_bp);
             atomicAdd(&g_mcts_stamps[3], sm); atomicAdd(&g_mcts_stamps[4], mx); atomicAdd(&g_mcts_stamps[5], ds); atomicAdd(&g_mcts_stamps[6], 1ull);
         }
     }
@@ -358,7 +409,7 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
     constexpr int EPB = G::Eng::EPB;
     const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / EPB : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = (G::Eng::lds_floats(a.pol.obs_size) + (size_t)3 * PATH_DEPTH * EPB) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     static size_t attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
@@ -380,6 +431,7 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
         const double w = (double)h[6];
         fprintf(stderr, "mcts stamps: waves %.0f | per wave: fwd %.0f cyc, tree %.0f cyc, trips %.1f | per trip: fwd %.0f, tree %.0f | inner per lane-trip %.2f, max-lane inner per trip %.2f, descents per inner %.2f\n",
                 w, h[0] / w, h[1] / w, h[2] / w, (double)h[0] / h[2], (double)h[1] / h[2], (double)h[3] / (32.0 * h[2]), (double)h[4] / h[2], (double)h[5] / (double)h[3]);
+        fprintf(stderr, "  tree phase per trip: expand+sample %.0f, descents %.0f, backprops %.0f\n", (double)h[13] / h[2], (double)h[14] / h[2], (double)h[15] / h[2]);
         fprintf(stderr, "  split engine per trip: prologue %.0f, chunk compute %.0f, vmcnt wait %.0f, barrier wait %.0f, heads %.0f\n",
                 (double)h[8] / h[2], (double)h[9] / h[2], (double)h[10] / h[2], (double)h[11] / h[2], (double)h[12] / h[2]);
     }
