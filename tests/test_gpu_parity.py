@@ -279,6 +279,31 @@ def test_az_reference_style_consumer(tw, oracle):
     assert all(abs(sum(p) - 1.0) < 1e-5 for p in probs)
 
 
+def test_az_sharding_invariance_and_single_rank_gather(tw, oracle):
+    """Two AZ shards (episode_offset, compact order) concatenate to the unsharded collect; collect_sharded on one rank
+    returns the same tensors (the multi-GPU path of INTEGRATION.md §D for the AlphaZero collector)."""
+    import torch
+    import torch.distributed as dist
+    from twisterl_amd.dist import collect_sharded
+    gp, _ = _pair(oracle, 9, 5, 64, 128)
+    env = tw.env.Puzzle(3, 3, 4, 2, 256)
+    mk = lambda n, off=0: tw.collector.AZCollector(n, 12, 1.41, 1, 1, merge_order=False, episode_offset=off)
+    full = mk(90).collect(env, gp, seed=5).to_numpy()
+    a, b = mk(40).collect(env, gp, seed=5).to_numpy(), mk(50, 40).collect(env, gp, seed=5).to_numpy()
+    keys = [k for k in full if k not in ("ep_start",) and len(full[k])]
+    assert "obs" in keys and "logits" in keys and "ep_len" in keys
+    for k in keys:
+        assert np.array_equal(full[k], np.concatenate([a[k], b[k]])), k
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1)
+    try:
+        merged, _ = collect_sharded(tw.collector.AZCollector(90, 12, 1.41, 1, 1), env, gp, seed=5)
+        ref = tw.collector.AZCollector(90, 12, 1.41, 1, 1).collect(env, gp, seed=5).to_torch()     # reference merge order
+        for k, v in merged.items():
+            assert torch.equal(v.cpu(), ref[k].cpu()), k
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------ evaluate / solve (SURVEY §8f rank 1)
 @pytest.mark.parametrize("w,diff,emb,hidden,twists", [(3, 4, 32, 32, False), (3, 6, 64, 64, True), (4, 5, 512, 256, False)])
 def test_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, hidden, twists):
