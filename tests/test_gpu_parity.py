@@ -304,6 +304,63 @@ def test_az_sharding_invariance_and_single_rank_gather(tw, oracle):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------ Conv1dPolicy
+def _conv_pair(tw, oracle, n, conv_dim, v, hidden, seed):
+    """Conv1dPolicy.to_rust() (src/twisterl/nn/policy.py:258-266, nn/utils.py:68-75): EmbeddingBag(conv_w.squeeze(2).T,
+    zeros, True, obs_shape, conv_dim) with obs_shape = [n_cells, n_cells] (cell, tile)."""
+    rng = np.random.default_rng(seed)
+    n2 = n * n
+    emb = n2 * v
+    arrs = make_policy_arrays(n2, seed=seed, emb=emb, hidden=hidden)
+    conv_w = rng.uniform(-0.3, 0.3, size=(v, n2)).astype(np.float32)           # Conv1d.weight.squeeze(2): [out][in]
+    vec, bias = np.ascontiguousarray(conv_w.T), np.zeros(emb, dtype=np.float32)
+    _, _, common, action, value = arrs
+    seq = lambda ls: tw.nn.Sequential([tw.nn.Linear(w.tolist(), b.tolist(), r) for (w, b, r) in ls])
+    gp = tw.nn.Policy(tw.nn.EmbeddingBag(vec.tolist(), bias.tolist(), True, [n2, n2], conv_dim), seq(common), seq(action), seq(value), [], [])
+    op = oracle.Policy(vec, bias, common, action, value, (), (), obs_shape=[n2, n2], conv_dim=conv_dim)
+    return gp, op, conv_w, arrs
+
+
+@pytest.mark.parametrize("n,conv_dim,v,hidden,E", [(3, 0, 32, 64, 150), (3, 1, 32, 256, 70), (2, 0, 8, 32, 40)])
+def test_conv1d_policy_collect_bit_exact_vs_oracle(tw, oracle, n, conv_dim, v, hidden, E):
+    """The conv1d mode of EmbeddingBag (rust/src/nn/layers.rs:63-77) behind Conv1dPolicy: PPO collect and the plain
+    forward are bit-equal to the oracle's restatement of that mode."""
+    gp, op, _, _ = _conv_pair(tw, oracle, n, conv_dim, v, hidden, 11)
+    genv, oenv = tw.env.Puzzle(n, n, 6, 2, 256), oracle.Puzzle(n, n, 6, 2, 256)
+    g = tw.collector.PPOCollector(E, 0.99, 0.95, 1).collect(genv, gp, seed=21)
+    o = oracle.ppo_collect(oenv, op, E, 0.99, 0.95, seed=21, arith=oracle.ARITH_CHAIN, det_log=True)
+    _assert_same_collect(g, o, n * n)
+    from twisterl_amd import _lib
+    n2 = n * n
+    rng = np.random.default_rng(1)
+    obs = np.arange(n2)[None, :] * n2 + np.stack([rng.permutation(n2) for _ in range(8)])
+    masks = np.ones((8, 4), dtype=np.uint8)
+    la, va = gp.evaluate_batch(_lib.TW_EVAL_FORWARD, obs, masks, np.full(8, -1, dtype=np.int32))
+    for i in range(8):
+        lo, vo = op.forward(obs[i].tolist(), masks[i].tolist(), perm=-1, arith=oracle.ARITH_CHAIN)
+        assert np.array_equal(f32_bits(la[i]), f32_bits(lo)) and f32_bits(va[i]) == f32_bits(vo)
+
+
+def test_conv1d_policy_update_from_torch(tw, oracle):
+    """Policy.update_from_torch for the Conv1dPolicy layout (conv_layer.weight): same result as rebuilding the policy."""
+    import torch
+    n, conv_dim, v, hidden = 3, 1, 32, 64
+    gp_old, _, _, _ = _conv_pair(tw, oracle, n, conv_dim, v, hidden, 3)
+    gp_new, _, conv_w, arrs = _conv_pair(tw, oracle, n, conv_dim, v, hidden, 4)
+    _, _, [(w1, b1, _)], [(wa, ba, _)], [(wv, bv, _)] = arrs
+    emb = n * n * v
+    state = {"conv_layer.weight": torch.tensor(conv_w).unsqueeze(2).cuda(),
+             "common.0.weight": torch.tensor(w1.reshape(emb, hidden).T.copy()).cuda(), "common.0.bias": torch.tensor(b1).cuda(),
+             "action.0.weight": torch.tensor(wa.reshape(hidden, 4).T.copy()).cuda(), "action.0.bias": torch.tensor(ba).cuda(),
+             "value.0.weight": torch.tensor(wv.reshape(hidden, 1).T.copy()).cuda(), "value.0.bias": torch.tensor(bv).cuda()}
+    env = tw.env.Puzzle(n, n, 5, 2, 256)
+    want = tw.collector.PPOCollector(100, 0.99, 0.95, 1).collect(env, gp_new, seed=8).to_numpy()
+    gp_old.update_from_torch(state)
+    got = tw.collector.PPOCollector(100, 0.99, 0.95, 1).collect(env, gp_old, seed=8).to_numpy()
+    for k in ("obs", "logits", "values", "actions", "advs", "rets"):
+        assert np.array_equal(got[k], want[k]), k
+
+
 # ------------------------------------------------------------------------------ evaluate / solve (SURVEY §8f rank 1)
 @pytest.mark.parametrize("w,diff,emb,hidden,twists", [(3, 4, 32, 32, False), (3, 6, 64, 64, True), (4, 5, 512, 256, False)])
 def test_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, hidden, twists):

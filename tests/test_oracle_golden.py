@@ -433,3 +433,36 @@ def test_f16_forward_close_to_f32_forward(oracle):
     l16, v16 = op.forward(obs, [True] * 4, arith=oracle.ARITH_F16)
     assert np.max(np.abs(np.asarray(l32) - np.asarray(l16))) < 5e-3 and abs(v32 - v16) < 5e-3
     assert not np.array_equal(np.asarray(l32, np.float32), np.asarray(l16, np.float32))
+
+
+@pytest.mark.parametrize("conv_dim", [0, 1])
+def test_conv1d_embedding_mode_matches_torch_conv1d(oracle, conv_dim):
+    """The oracle's conv1d EmbeddingBag mode (rust/src/nn/layers.rs:63-77) against what Conv1dPolicy computes in torch
+    (src/twisterl/nn/policy.py:233-247: [Transpose if conv_dim == 1] -> Conv1d(kernel 1, no bias) -> Transpose -> Flatten)
+    on the one-hot observation the ids stand for -- an independent statement of the same layer."""
+    import torch
+    rng = np.random.default_rng(5)
+    R, Cc, v, hidden = 4, 5, 6, 8
+    shape = [R, Cc]
+    n_in, n_slices = shape[conv_dim], shape[1 - conv_dim]
+    conv_w = rng.standard_normal((v, n_in)).astype(np.float32)              # Conv1d.weight.squeeze(2)
+    emb = n_slices * v
+    w1 = rng.standard_normal((hidden, emb)).astype(np.float32) * 0.2; b1 = rng.standard_normal(hidden).astype(np.float32)
+    wa = rng.standard_normal((3, hidden)).astype(np.float32) * 0.3; ba = rng.standard_normal(3).astype(np.float32)
+    wv = rng.standard_normal((1, hidden)).astype(np.float32) * 0.3; bv = rng.standard_normal(1).astype(np.float32)
+    pol = oracle.Policy(np.ascontiguousarray(conv_w.T), np.zeros(emb, dtype=np.float32),
+                        [(np.ascontiguousarray(w1.T).reshape(-1), b1, True)], [(np.ascontiguousarray(wa.T).reshape(-1), ba, False)],
+                        [(np.ascontiguousarray(wv.T).reshape(-1), bv, False)], (), (), obs_shape=shape, conv_dim=conv_dim)
+    for trial in range(6):
+        ids = sorted(rng.choice(R * Cc, size=5, replace=False).tolist())
+        x = torch.zeros(1, R, Cc)
+        for i in ids:
+            x[0, i // Cc, i % Cc] = 1.0
+        y = x.transpose(1, 2) if conv_dim == 1 else x
+        y = torch.nn.functional.conv1d(y, torch.tensor(conv_w).unsqueeze(2)).transpose(1, 2).flatten(1)
+        hdn = torch.relu(torch.relu(y) @ torch.tensor(w1).T + torch.tensor(b1))
+        lg = (hdn @ torch.tensor(wa).T + torch.tensor(ba))[0].numpy()
+        val = float((hdn @ torch.tensor(wv).T + torch.tensor(bv))[0, 0])
+        lo, vo = pol.raw_predict(ids)
+        np.testing.assert_allclose(lo, lg, atol=1e-5, rtol=1e-5)
+        assert abs(vo - val) <= 1e-5

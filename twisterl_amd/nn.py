@@ -42,6 +42,30 @@ class EmbeddingBag:
         self.apply_relu = bool(apply_relu)
         self.obs_shape = [int(s) for s in obs_shape]
         self.conv_dim = int(conv_dim)
+        if len(self.obs_shape) not in (1, 2) or self.conv_dim not in (0, 1):
+            raise ValueError("EmbeddingBag: obs_shape must have one or two entries and conv_dim must be 0 or 1")
+
+    def dense_table(self) -> np.ndarray:
+        """The [obs_size][emb] table the kernels gather from.  1-D mode: the vectors themselves.  Conv1d mode
+        (layers.rs:63-77): id i = (row, col) of obs_shape (swapped for conv_dim 1) adds vectors[row] into the slice
+        [col*v, (col+1)*v) of the output -- the same as adding a row that is vectors[row] in that slice and +0.0
+        elsewhere, and `x + 0.0 == x` bit for bit (the one exception, x = -0.0, needs an exact -0.0 bias)."""
+        if len(self.obs_shape) == 1:
+            return self.vectors
+        rows, cols = self.obs_shape
+        n_vec, v = self.vectors.shape
+        n_slices = self.obs_shape[1 - self.conv_dim]
+        if n_vec < self.obs_shape[self.conv_dim]:
+            raise ValueError("EmbeddingBag: conv1d mode needs one vector per index of obs_shape[conv_dim]")
+        if self.bias.size != n_slices * v:
+            raise ValueError("EmbeddingBag: conv1d bias length must be obs_shape[1 - conv_dim] * vector length")
+        table = np.zeros((rows * cols, n_slices * v), dtype=np.float32)
+        for i in range(rows * cols):
+            r, c = divmod(i, cols)
+            if self.conv_dim == 1:
+                r, c = c, r
+            table[i, c * v:(c + 1) * v] = self.vectors[r]
+        return table
 
 
 class Sequential:
@@ -107,15 +131,13 @@ class Policy:
         architectures the HIP path does not implement."""
         if self._h is None:
             e = self.embeddings
-            if len(e.obs_shape) != 1:
-                raise RuntimeError("policy: the HIP path implements the 1-D EmbeddingBag mode of BasicPolicy "
-                                   "(conv1d mode of Conv1dPolicy is not built)")
-            keep = []
+            table = np.ascontiguousarray(e.dense_table(), dtype=np.float32)    # conv1d mode (Conv1dPolicy): expanded here
+            keep = [table]
             d = _lib.PolicyDesc()
-            d.obs_size, d.emb_size = e.vectors.shape
-            if e.bias.size != e.vectors.shape[1]:
-                raise ValueError("EmbeddingBag: bias length must equal the embedding size in 1-D mode")
-            d.emb_vectors = e.vectors.ctypes.data_as(C.POINTER(C.c_float))
+            d.obs_size, d.emb_size = table.shape
+            if e.bias.size != table.shape[1]:
+                raise ValueError("EmbeddingBag: bias length must equal the embedding size")
+            d.emb_vectors = table.ctypes.data_as(C.POINTER(C.c_float))
             d.emb_bias = e.bias.ctypes.data_as(C.POINTER(C.c_float))
             d.emb_apply_relu = int(e.apply_relu)
             d.n_common, d.common = len(self.common.layers), _linear_descs(self.common, keep)
@@ -184,6 +206,26 @@ def _sync_from_torch(policy: "Policy", state) -> None:
     import torch
     if hasattr(state, "state_dict"):
         state = state.state_dict()
+    e = policy.embeddings
+    if len(e.obs_shape) == 2:
+        # Conv1dPolicy (src/twisterl/nn/policy.py:207-266): conv_layer.weight [v][n_vec][1], no bias.  The dense
+        # [emb][obs_size] Linear weight the kernels' table is made from is assembled on the device (EmbeddingBag.dense_table).
+        if "conv_layer.weight" not in state:
+            raise KeyError("update_from_torch: the state has no conv_layer.weight (Conv1dPolicy layout)")
+        w = state["conv_layer.weight"].detach().to(device="cuda", dtype=torch.float32)
+        n_vec, v = e.vectors.shape
+        if tuple(w.shape) not in ((v, n_vec, 1), (v, n_vec)):
+            raise ValueError(f"update_from_torch: conv_layer.weight has shape {tuple(w.shape)}, the policy was built for {(v, n_vec, 1)}")
+        w = w.reshape(v, n_vec)
+        rows, cols = e.obs_shape
+        i = torch.arange(rows * cols, device="cuda")
+        r, c = (i // cols, i % cols) if e.conv_dim == 0 else (i % cols, i // cols)
+        n_slices = e.obs_shape[1 - e.conv_dim]
+        dense = torch.zeros((n_slices, v, rows * cols), device="cuda", dtype=torch.float32)
+        dense[c, :, i] = w.t()[r]
+        state = dict(state)
+        state["embeddings.weight"] = dense.reshape(n_slices * v, rows * cols)
+        state["embeddings.bias"] = torch.zeros(n_slices * v, device="cuda", dtype=torch.float32)
     keys = ["embeddings.weight", "embeddings.bias", "common.0.weight", "common.0.bias", "action.0.weight", "action.0.bias",
             "value.0.weight", "value.0.bias"]
     missing = [k for k in keys if k not in state]
@@ -191,7 +233,8 @@ def _sync_from_torch(policy: "Policy", state) -> None:
         raise KeyError(f"update_from_torch: the state has no {missing} (BasicPolicy layout: embeddings / common.0 / action.0 / value.0)")
     h = policy._handle()
     emb, hid = int(policy.embeddings.bias.size), policy.common.layers[0].out_features
-    want = {"embeddings.weight": (emb, int(policy.embeddings.vectors.shape[0])), "embeddings.bias": (emb,), "common.0.weight": (hid, emb),
+    obs_size = int(np.prod(policy.embeddings.obs_shape)) if len(policy.embeddings.obs_shape) == 2 else int(policy.embeddings.vectors.shape[0])
+    want = {"embeddings.weight": (emb, obs_size), "embeddings.bias": (emb,), "common.0.weight": (hid, emb),
             "common.0.bias": (hid,), "action.0.weight": (int(policy.num_actions), hid), "action.0.bias": (int(policy.num_actions),),
             "value.0.weight": (1, hid), "value.0.bias": (1,)}
     ts = []
