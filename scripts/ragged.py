@@ -1,5 +1,5 @@
 """Ragged episode lengths (one scramble move, long horizon: most episodes end early): persistent-lane mode vs one
-workgroup per 256 episodes.  Puzzle-15, benchmark-size policy, 262,144 episodes, f32 exact mode."""
+workgroup per 256 episodes.  Puzzle-15, benchmark-size policy, 262,144 episodes (or argv[1]), f32 exact mode."""
 import os, sys, time
 sys.path.insert(0, ".")
 import torch
@@ -9,7 +9,8 @@ from twisterl_amd import twisterl
 op, ap = puzzle_transpose_twist(4)
 pol = bench.build_policy(bench.synthetic_weights(16), op, ap)
 env = twisterl.env.Puzzle(4, 4, 1, 128, 256)
-coll = twisterl.collector.PPOCollector(262144, 0.995, 0.995, 1)
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+coll = twisterl.collector.PPOCollector(E, 0.995, 0.995, 1)
 for mode in ("persistent", "plain"):
     if mode == "plain":
         os.environ["TW_NO_PERSIST"] = "1"
@@ -19,5 +20,5 @@ for mode in ("persistent", "plain"):
     for i in range(3):
         d = coll.collect(env, pol, seed=1 + i); n += len(d); st = d.stats
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(mode, "records/collect", n // 3, "mean len %.1f" % (n / 3 / 262144), "ms/collect %.1f" % (dt / 3 * 1e3), "rollout ms %.1f" % st["ms_rollout"],
+    print(mode, "records/collect", n // 3, "mean len %.1f" % (n / 3 / E), "ms/collect %.1f" % (dt / 3 * 1e3), "rollout ms %.1f" % st["ms_rollout"],
           "records/s %.3g" % (n / dt))

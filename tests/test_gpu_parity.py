@@ -759,6 +759,40 @@ def test_az_persistent_lane_mode_bit_exact(tw, oracle):
         assert np.array_equal(g[k], h[k]), k
 
 
+def test_mid_size_batches_use_the_queue_with_the_small_batch_geometry(tw, oracle):
+    """Between CUs x 32 (8,192) and ~40k episodes (self-play: 49k) the small-batch geometry runs with the episode queue:
+    four waves share 32 episodes and take the next one together.  PPO and self-play: bit-identical to the oracle and to the
+    launch without the queue; the launch geometry is the persistent one (one workgroup per CU)."""
+    import os
+    gp, op = _pair(oracle, 9, 5, 64, 128, twists=True)
+    E = 9_000
+    genv, oenv = tw.env.Puzzle(3, 3, 1, 24, 256), oracle.Puzzle(3, 3, 1, 24, 256)
+    coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32}, seed=23)
+    g = coll.collect(genv, gp, seed=23)
+    o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=23, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8)
+    _assert_same_collect(g, o, 9)
+    assert g.stats["rollout_threads"] == 256 and g.stats["rollout_blocks"] * 32 < E      # fewer lanes than episodes
+    a = g.to_numpy()
+    gp2, op2 = _pair(oracle, 9, 7, 64, 128, twists=False, scale=3.0)
+    aenv, aoenv = tw.env.Puzzle(3, 3, 2, 3, 256), oracle.Puzzle(3, 3, 2, 3, 256)
+    acoll = tw.collector.AZCollector(num_episodes=E, num_mcts_searches=6, C=1.41, max_expand_depth=1, num_cores=32, seed=29, merge_order=False)
+    z = acoll.collect(aenv, gp2, seed=29).to_numpy()
+    zo = oracle.az_collect(aoenv, op2, E, 6, 1.41, 1, seed=29, arith=oracle.ARITH_CHAIN, num_threads=8, merge_order=False, det_math=True)
+    assert np.array_equal(z["ep_len"], zo.ep_len) and np.array_equal(z["obs"].astype(np.int64), zo.obs)
+    assert np.array_equal(f32_bits(z["logits"]), f32_bits(zo.logits))
+    assert np.array_equal(f32_bits(z["remaining_values"]), f32_bits(zo.additional_data["remaining_values"]))
+    os.environ["TW_NO_PERSIST"] = "1"
+    try:
+        h = coll.collect(genv, gp, seed=23).to_numpy()
+        zh = acoll.collect(aenv, gp2, seed=29).to_numpy()
+    finally:
+        del os.environ["TW_NO_PERSIST"]
+    for k in a:
+        assert np.array_equal(a[k], h[k]), k
+    for k in z:
+        assert np.array_equal(z[k], zh[k]), k
+
+
 def test_end_to_end_loop_sketch(tw, oracle):
     """examples/ppo_loop_sketch.py: collect -> data_to_torch -> torch PPO update -> device policy sync -> evaluate, three
     iterations with nothing going through host lists; the losses are finite and the synced policy is the trained one."""

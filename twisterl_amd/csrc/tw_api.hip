@@ -740,7 +740,8 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     // persistent-lane mode (more episodes than resident lanes): start boards + episode queue
-    const bool persist = E > rollout_f32_resident_episodes() && !getenv("TW_NO_PERSIST");
+    const uint64_t resident = prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false) : rollout_f32_resident_episodes();
+    const bool persist = E > resident && !getenv("TW_NO_PERSIST");
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
                  o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     void *wsp = nullptr;
@@ -756,7 +757,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     if (persist) {
         ra.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
         ra.queue = reinterpret_cast<unsigned int *>(ws + o_queue);
-        const unsigned int first = (unsigned int)rollout_f32_resident_episodes();      // episodes handed out at launch
+        const unsigned int first = (unsigned int)resident;      // episodes handed out at launch
         TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
         rc = launch_init_boards(ra.env, ra.seed, ra.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
         if (rc) return rc;
@@ -850,8 +851,9 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     // persistent lanes (more episodes than resident lanes): one tree arena per LANE, start boards + episode queue
-    const bool persist = E > rollout_f32_resident_episodes() && !getenv("TW_NO_PERSIST");
-    const uint64_t arenas = persist ? rollout_f32_resident_episodes() : E;
+    const uint64_t resident = f32_resident_episodes(E, (int)ma.pol.hidden, true);
+    const bool persist = E > resident && !getenv("TW_NO_PERSIST");
+    const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(16), o_scan = seg(scan_scratch_bytes(E)), o_arena = seg(arenas * cap64 * mcts_node_bytes()),
                  o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
@@ -877,7 +879,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     if (persist) {
         ma.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
         ma.queue = reinterpret_cast<unsigned int *>(ws + o_queue);
-        const unsigned int first = (unsigned int)rollout_f32_resident_episodes();
+        const unsigned int first = (unsigned int)resident;
         TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
         rc = launch_init_boards(ma.env, ma.seed, ma.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
         if (rc) return rc;

@@ -372,6 +372,10 @@ inline int waves_per_group(uint64_t n)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s);
 uint64_t rollout_f32_resident_episodes();   // episodes the f32 rollout keeps resident at once (persistent mode above that)
+// Lanes the exact-f32 kernels (rollout, self-play) keep resident for a batch: episodes beyond that wait in the queue of the
+// persistent-lane mode.  CUs x 256 for the 256-episode shape; between CUs x 32 and 3/4 of that the small-batch shape
+// (CUs x 32 lanes, Engine3S) with the queue -- see tw_rollout.hip.
+uint64_t f32_resident_episodes(uint64_t num_episodes, int hidden, bool selfplay);
 int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_rollout_f16x2(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, uint64_t *ep_start,

@@ -407,7 +407,7 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
 {
     using G = Geom<NT, NC, 0, NW>;
     constexpr int EPB = G::Eng::EPB;
-    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / EPB : (a.num_episodes + EPB - 1) / EPB;
+    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / (8 * EPW) : (a.num_episodes + EPB - 1) / EPB;   // persistent: one workgroup per CU
     if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = (G::Eng::lds_floats(a.pol.obs_size) + (size_t)3 * PATH_DEPTH * EPB) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
@@ -444,8 +444,11 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
 template <int NT, int NC>
 static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    if (!a.solve.on && a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes())
+    const uint64_t resident = f32_resident_episodes(a.num_episodes, a.pol.hidden, true);
+    if (!a.solve.on && a.queue && a.init_boards && a.num_episodes > resident) {
+        if constexpr (NT >= 4) { if (resident < rollout_f32_resident_episodes()) return launch_mcts_geom<NT, NC, -4, true>(a, s, blocks, threads); }
         return launch_mcts_geom<NT, NC, 8, true>(a, s, blocks, threads);
+    }
     const int nw = geometry_for<NT>(a.num_episodes);
     if constexpr (NT >= 4) { if (nw == -4) return launch_mcts_geom<NT, NC, -4>(a, s, blocks, threads); }
     else if constexpr (NT == 2) { if (nw == -2) return launch_mcts_geom<NT, NC, -2>(a, s, blocks, threads); }

@@ -129,10 +129,16 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32
             } else { puzzle_step(st, env, action); ++t; }
         }
         if constexpr (PERSIST) {
-            if (!alive && more) {                         // take the next episode off the queue (both lanes of the pair the same one)
-                unsigned got = 0xffffffffu;
-                if (h == 0) got = atomicAdd(a.queue, 1u);
-                got = (unsigned)__shfl((int)got, j, 64);
+            const bool want = !alive && more;             // take the next episode off the queue (every lane of the episode the same one)
+            unsigned got = 0xffffffffu;
+            if (want && writer) got = atomicAdd(a.queue, 1u);
+            if constexpr (Eng::SPLIT) {                   // all waves of the workgroup carry this episode: hand the index round in LDS
+                unsigned *bc = reinterpret_cast<unsigned *>(eng.lds_user);
+                if (writer) bc[j] = got;
+                __syncthreads();
+                got = bc[j];
+            } else got = (unsigned)__shfl((int)got, j, 64);
+            if (want) {
                 if ((uint64_t)got < a.num_episodes) {
                     e_local = got; e_global = a.episode_offset + e_local; rec_base = e_local * (uint64_t)a.out.t_pad;
                     take(e_local);
@@ -159,6 +165,21 @@ static uint64_t persist_blocks()
 }
 
 uint64_t rollout_f32_resident_episodes() { return persist_blocks() * 8 * EPW; }
+
+// Episodes are ragged (a solved puzzle ends its episode), and a lane whose episode is over can only be refilled when there
+// are more episodes than lanes.  Between CUs x 32 episodes and 3/4 of CUs x 256 the small-batch shape with the episode
+// queue (CUs x 32 lanes, every one busy until the queue is empty) beats both running the 32-episode workgroups one after
+// the other and leaving most of the lanes of the 256-episode shape idle behind the longest episodes (self-play, 32,768
+// episodes: 1.8x); from there on the 256-episode shape wins.
+// Upper end of that range: where the 256-episode shape overtakes with episodes of equal length (the rollout crossover of
+// waves_per_group()); self-play episodes are always ragged, there the range extends to 3/4 of CUs x 256.
+uint64_t f32_resident_episodes(uint64_t num_episodes, int hidden, bool selfplay)
+{
+    const uint64_t full = rollout_f32_resident_episodes(), small = full / 8;
+    const bool in_range = selfplay ? num_episodes * 4 <= full * 3 : waves_per_group(num_episodes) != 8;
+    if (hidden >= 128 && num_episodes > small && in_range && !getenv("TW_FORCE_GEOM")) return small;
+    return full;
+}
 
 template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
 static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
@@ -198,8 +219,11 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
     }
 #endif
     // small batches: fewer waves per workgroup, so that the episodes spread over more CUs
-    if (a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes())
+    const uint64_t resident = f32_resident_episodes(a.num_episodes, a.pol.hidden, false);
+    if (a.queue && a.init_boards && a.num_episodes > resident) {
+        if constexpr (NT >= 4) { if (resident < rollout_f32_resident_episodes()) return launch_geom<NT, NC, 0, -4, true>(a, s, blocks, threads); }
         return launch_geom<NT, NC, 0, 8, true>(a, s, blocks, threads);
+    }
     const int nw = geometry_for<NT>(a.num_episodes);
     if constexpr (NT >= 4) { if (nw == -4) return launch_geom<NT, NC, 0, -4>(a, s, blocks, threads); }
     else if constexpr (NT == 2) { if (nw == -2) return launch_geom<NT, NC, 0, -2>(a, s, blocks, threads); }
