@@ -240,9 +240,18 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) --------------
                         float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                        for (uint32_t c = 0; c < root_nc; ++c) {
-                            const MctsNode ch = nodes[root_cb + c];
-                            mp[ch.action] = (float)ch.visit;
+                        if (root_nc > 0) {
+                            MctsNode chs[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) chs[c] = nodes[root_cb + ((uint32_t)c < root_nc ? (uint32_t)c : root_nc - 1u)];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if ((uint32_t)c >= root_nc) continue;
+                                const int act = chs[c].action;     // (a chain of selects instead of a dynamically indexed register array)
+                                const float vis = (float)chs[c].visit;
+                                mp[0] = act == 0 ? vis : mp[0]; mp[1] = act == 1 ? vis : mp[1];
+                                mp[2] = act == 2 ? vis : mp[2]; mp[3] = act == 3 ? vis : mp[3];
+                            }
                         }
                         float sum = 0.0f;
 #pragma unroll
@@ -311,14 +320,21 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                         uint32_t best = NONE; float best_ucb = -__builtin_inff();
                         MctsNode bestn = cur;
                         const float sq = sqrtf((float)cur.visit);
-                        for (int c = 0; c < cur.n_children; ++c) {
-                            const MctsNode ch = nodes[cur.child_base + c];
+                        // all (up to four, contiguous) children are fetched at once: ONE dependent round trip per level, not one
+                        // per child (slots past n_children re-read the last child and are ignored)
+                        const uint32_t nch = cur.n_children, cb = cur.child_base;
+                        MctsNode chs[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) chs[c] = nodes[cb + ((uint32_t)c < nch ? (uint32_t)c : nch - 1u)];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const MctsNode &ch = chs[c];
                             const float q = ch.visit == 0 ? 0.0f : ch.value_sum / (float)ch.visit;
                             float d = sq / ((float)ch.visit + 1.0f);
                             d = a.C * d;
                             d = d * ch.prior;
                             const float u = q + d;
-                            if (u > best_ucb) { best = cur.child_base + c; best_ucb = u; bestn = ch; }
+                            if ((uint32_t)c < nch && u > best_ucb) { best = cb + (uint32_t)c; best_ucb = u; bestn = ch; }
                         }
                         if (best == NONE) break;        // all-NaN UCB: the reference panics here
                         node = best; cur = bestn;
