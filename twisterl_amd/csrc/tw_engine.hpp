@@ -110,12 +110,14 @@ struct Engine3 {
 
     PolicyDev pol;
     int tid, lane, wave, j, h;
+    uint32_t voff;                                          // lane*16: per-lane byte offset inside a DMA piece
     int bias_row, zero_row, n_chunks, rp;                   // rp: ring slot of chunk 0 of the next forward
     float emb_lim, common_lim;                              // 0 (ReLU) or -inf (none): relu_lim()
     float *lds_w, *lds_t, *lds_b1, *lds_wh, *lds_bh;
     const uint8_t *perm_obs, *perm_act;
 
-    // DMA op `op` of this wave for chunk `chunk` (of the flat chunk sequence) into ring slot `slot`
+    // DMA op `op` of this wave for chunk `chunk` (of the flat chunk sequence) into ring slot `slot`.  Scalar source (SGPR base
+    // + lane*16 in a VGPR that never changes) and scalar destination (M0): no vector address arithmetic.
     __device__ __forceinline__ void stream_op(int chunk, int slot, int op)
     {
         if constexpr (DBG & 4) return;
@@ -127,7 +129,10 @@ struct Engine3 {
         const float *src = is_w ? pol.w1p + (size_t)chunk * WSLOT + piece * 256
                                 : pol.t_img16 + (size_t)chunk * R3_TSLOT + tp * 256;
         float *dst = is_w ? lds_w + slot * WSLOT + piece * 256 : lds_t + slot * R3_TSLOT + tp * 256;
-        glds16(src + lane * 4, dst);
+        const unsigned d = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)dst;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                     :: "v"(voff), "s"(__builtin_amdgcn_readfirstlane(d)), "s"(src)
+                     : "memory", "m0");
     }
 
     __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
@@ -137,6 +142,7 @@ struct Engine3 {
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         j = lane & 31; h = lane >> 5;
+        voff = (uint32_t)lane * 16u;
         bias_row = pol.obs_size; zero_row = pol.obs_size + 1;
         n_chunks = pol.emb / KC;
         emb_lim = pol.emb_relu ? 0.0f : -__builtin_inff();
@@ -368,7 +374,6 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
     static_assert(NT % NS == 0 && (NTL == 1 || NTL == 2), "Engine3S: one or two row tiles per wave");
 
     float *lds_x, *lds_user;
-    uint32_t voff;                 // per-lane byte offset inside a DMA piece
 #ifdef TW_ABLATE
     unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk compute | vmcnt wait | barrier wait | heads | -
 #define TW_S3(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -377,23 +382,6 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
 #define TW_S3(var)
 #define TW_A3(i, a, b)
 #endif
-
-    // DMA op with a scalar source (SGPR base + lane*16): no VALU address arithmetic, which a lone wave per SIMD cannot hide
-    // behind its f32 MFMAs.  Piece order as in Engine3::stream_op.
-    __device__ __forceinline__ void stream_op_s(int chunk, int slot, int op)
-    {
-        int piece = this->wave + NS * op;
-        piece = piece < B::NPIECE ? piece : B::NPIECE - 1;
-        const bool is_w = piece < B::WPIECE;
-        const int  tp   = piece - B::WPIECE;
-        const float *src = is_w ? this->pol.w1p + (size_t)chunk * WSLOT + piece * 256
-                                : this->pol.t_img16 + (size_t)chunk * R3_TSLOT + tp * 256;
-        float *dst = is_w ? this->lds_w + slot * WSLOT + piece * 256 : this->lds_t + slot * R3_TSLOT + tp * 256;
-        const unsigned d = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)dst;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                     :: "v"(voff), "s"(__builtin_amdgcn_readfirstlane(d)), "s"(src)
-                     : "memory", "m0");
-    }
 
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
     __device__ __forceinline__ bool primary() const { return this->wave == 0; }
@@ -407,7 +395,6 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
         B::begin1(p, lds);
         lds_x = lds + engine3_lds_floats<NT>(p.obs_size);
         lds_user = lds_x + R3S_XCHG;
-        voff = (uint32_t)this->lane * 16u;
     }
 
     __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
@@ -507,7 +494,7 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[r], bg[ks >> 2][ks & 3], acc[r], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int op = m * NOPS / M; op < (m + 1) * NOPS / M; ++op) stream_op_s(sc, s2, op);
+                for (int op = m * NOPS / M; op < (m + 1) * NOPS / M; ++op) this->stream_op(sc, s2, op);
 #pragma unroll
                 for (int q = m * (NC + 1) / M; q < (m + 1) * (NC + 1) / M; ++q) gather_read(q);
                 if (r == NTL - 1) {
