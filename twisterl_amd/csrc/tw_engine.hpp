@@ -57,6 +57,14 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
     return r;
 }
 
+// the same max, for a result that does not feed an MFMA (no wait states)
+__device__ __forceinline__ float relu_lim_v(float x, float lim)
+{
+    float y;
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "s"(lim), "v"(x));
+    return y;
+}
+
 template <int NT> struct Tiles { static constexpr int NQ = (NT + 3) / 4; };
 
 constexpr int MAX_LDS_PERMS = 4;   // twist tables kept in LDS (more twists fall back to global reads)
@@ -86,7 +94,7 @@ template <int NT>
 __host__ __device__ inline size_t engine3_lds_floats(int obs_size)
 {
     return (size_t)3 * R3_KC * Tiles<NT>::NQ * 128 + (size_t)3 * R3_TSLOT + (size_t)NT * 32 * 10 + 8 +
-           (size_t)MAX_LDS_PERMS * ((obs_size + 3) / 4 + 1);
+           (size_t)MAX_LDS_PERMS * ((obs_size + 3) / 4 + 1) + (size_t)NT * 32 * 5;
 }
 
 // NW = waves per workgroup (8: two per SIMD, the throughput geometry; 2 / 1: small batches, so that a few thousand
@@ -113,7 +121,7 @@ struct Engine3 {
     uint32_t voff;                                          // lane*16: per-lane byte offset inside a DMA piece
     int bias_row, zero_row, n_chunks, rp;                   // rp: ring slot of chunk 0 of the next forward
     float emb_lim, common_lim;                              // 0 (ReLU) or -inf (none): relu_lim()
-    float *lds_w, *lds_t, *lds_b1, *lds_wh, *lds_bh;
+    float *lds_w, *lds_t, *lds_b1, *lds_wh, *lds_bh, *lds_wn;   // lds_wn: head weights in natural order [output 0..4][hidden]
     const uint8_t *perm_obs, *perm_act;
 
     // DMA op `op` of this wave for chunk `chunk` (of the flat chunk sequence) into ring slot `slot`.  Scalar source (SGPR base
@@ -159,6 +167,11 @@ struct Engine3 {
         }
         for (int i = tid; i < NT * 32; i += THREADS) lds_wh[8 * 2 * (NT * 16) + i] = 0.0f;
         if (tid < 8) lds_bh[tid] = pol.bh8[tid];
+        lds_wn = lds_bh + 8 + MAX_LDS_PERMS * ((pol.obs_size + 3) / 4 + 1);
+        for (int i = tid; i < NT * 32 * 5; i += THREADS) {
+            const int c = i / (NT * 32), n = i - c * (NT * 32);
+            lds_wn[i] = pol.wh8[n * 8 + c];
+        }
         perm_obs = pol.obs_perms; perm_act = pol.act_perms;
         if (pol.n_perms > 0 && pol.n_perms <= MAX_LDS_PERMS) {
             uint8_t *po = reinterpret_cast<uint8_t *>(lds_bh + 8);
@@ -323,6 +336,56 @@ struct Engine3 {
 #pragma unroll
             for (int r = 0; r < NT; ++r) value += acc[r][0];
             lg[0] = lg[1] = lg[2] = lg[3] = 0.0f;
+            return;
+        }
+        if constexpr (NT >= 2) {
+            // Heads as v_fma_f32 chains.  As MFMAs the k-ordered chain over the hidden units is 16*NT DEPENDENT 32x32x2 products
+            // of which 5 rows in 32 are used: 6 % of the matrix-pipe time for 1 % of the FLOPs.  Instead: v_permlane32_swap
+            // gives the lower lane half both parities of hidden units [0, H/2) of its episode and the upper half those of
+            // [H/2, H); then, in phase p, the lower half runs units [0, H/2) of output p while the upper half continues
+            // output p-1 over [H/2, H) -- the partial sum crosses the halves between phases.  One fma per hidden unit and
+            // output in hidden order: the same chain as before, bit for bit.
+            constexpr int HH = NT / 2, H = NT * 32;
+            lds_cfloat *b1_lane = (lds_cfloat *)(lds_b1 + h * (NT * 16));
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 hb = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(b1_lane + 16 * r + 4 * g4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[r][4 * g4 + g] = relu_lim_v(acc[r][4 * g4 + g] + hb[g], common_lim);
+                }
+#pragma unroll
+            for (int r = 0; r < HH; ++r)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r][g]), __float_as_uint(acc[r + HH][g]), false, false);
+                    acc[r][g] = __uint_as_float(sw[0]); acc[r + HH][g] = __uint_as_float(sw[1]);
+                }
+            float a = 0.0f, res[5];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                const int o = p - h;
+                lds_cfloat *wp = (lds_cfloat *)lds_wn + (o < 0 ? 0 : (o > 4 ? 4 : o)) * H + h * (H / 2);
+#pragma unroll
+                for (int u4 = 0; u4 < H / 8; ++u4) {
+                    const f32x4 w = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(wp + 4 * u4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int u = 4 * u4 + k;                       // position inside the half: unit = (H/2)*h + u
+                        a = __builtin_fmaf(w[k], acc[(u >> 5) + HH * (u & 1)][(u & 31) >> 1], a);
+                    }
+                }
+                const auto sw = __builtin_amdgcn_permlane32_swap(0u, __float_as_uint(a), false, false);
+                a = __uint_as_float(sw[0]);                             // lower half: 0; upper half: the lower half's partial sum
+                if (p >= 1) res[p - 1] = __uint_as_float(sw[1]);        // upper half: output p-1, complete
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(res[i]), __float_as_uint(res[i]), false, false);
+                const float out = __uint_as_float(sw[1]) + lds_bh[i];   // both halves: the upper half's value
+                if (i < 4) lg[i] = out; else value = out;
+            }
             return;
         }
         f32x16 hacc;
