@@ -19,13 +19,13 @@
 //     the 16 tiles of a cell (conflict-free; equal tiles broadcast).
 //   * an f32 MFMA chain IS a k-ordered fmaf chain, so the result is bit-equal to the oracle's
 //     TWO_ARITH_CHAIN forward; rows of W1 are fed in an order (hid()) that makes the accumulator
-//     registers come out in natural hidden order for the head product, which consumes the
-//     accumulators directly as its B operand (no LDS round trip, no shuffles).
+//     registers come out in natural hidden order for the head product.
 //   * both weight streams are pure LDS-DMA (global_load_lds_dwordx4 via inline asm) into a ring of
 //     three slots, two chunks ahead, spread between the MFMAs; the inner loop is software-pipelined
 //     by hand across chunk boundaries (issue order pinned with sched_barrier, chunk body branch-free),
 //     so nothing but the barrier itself sits between the last MFMA of a chunk and the first of the next.
-//   * heads: [4 logits + value] x hidden on the same MFMA shape (rows 5..31 are zero).
+//   * heads: [4 logits + value] x hidden as v_fma_f32 chains in hidden order over v_permlane32_swap'd accumulators
+//     (tw_engine.hpp; the dependent-MFMA form cost 6 % of the matrix-pipe time for 1 % of the FLOPs).
 //   * the f32-input MFMA executes on the SIMD's f32 FMA lanes, so the gather's VALU adds do NOT overlap
 //     it: the practical ceiling is MFMA cycles + add cycles (~0.85 of the MFMA-only peak).
 #include "tw_engine.hpp"
