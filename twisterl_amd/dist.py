@@ -129,16 +129,15 @@ class PipelinedGather:
                 self.keep.append(t)
                 ops.append(dist.P2POp(dist.isend, t, self.dst, self.group))
         self.keep.append(fields)
-        if ops:
-            self.works.extend(dist.batch_isend_irecv(ops))
+        self.works.append(dist.batch_isend_irecv(ops) if ops else [])      # per chunk: finish() waits chunk by chunk
         self.chunks.append((counts, tail, staging))
 
     def finish(self) -> Optional[Dict[str, torch.Tensor]]:
-        for w in self.works:
-            w.wait()
-        self.works = []
         if self.rank != self.dst:
-            self.keep = []
+            for ws in self.works:
+                for w in ws:
+                    w.wait()
+            self.works, self.keep = [], []
             return None
         names, world, K = self.names, self.world, len(self.chunks)
         tail = self.chunks[-1][1] if K else 0                       # records of global episode E-1
@@ -146,22 +145,29 @@ class PipelinedGather:
         first = self.chunks[0][2]
         out = {n: torch.empty((total,) + tuple(first[n].shape[1:]), dtype=first[n].dtype, device=first[n].device) for n in names}
         # [tail][rank 0: chunk 0..K-1][rank 1: ...]...[rank G-1: ... without its tail]
+        plan = [[] for _ in range(K)]          # per chunk: (src_lo, src_hi, dst_lo)
         pos = tail
         for r in range(world):
-            for c, (counts, _, staging) in enumerate(self.chunks):
+            for c, (counts, _, _) in enumerate(self.chunks):
                 src = sum(counts[:r])
                 n_rec = counts[r]
                 if r == world - 1 and c == K - 1:
                     body = n_rec - tail
-                    for n in names:
-                        out[n][0:tail].copy_(staging[n][src + body:src + n_rec])
+                    plan[c].append((src + body, src + n_rec, 0))
                     n_rec = body
                 if n_rec > 0:
-                    for n in names:
-                        out[n][pos:pos + n_rec].copy_(staging[n][src:src + n_rec])
+                    plan[c].append((src, src + n_rec, pos))
                 pos += n_rec
         assert pos == total
-        self.keep, self.chunks = [], []
+        # chunk by chunk: the reorder of the early chunks runs while the last chunk is still arriving
+        for c, (_, _, staging) in enumerate(self.chunks):
+            for w in self.works[c]:
+                w.wait()
+            for (lo, hi, d) in plan[c]:
+                if hi > lo:
+                    for n in names:
+                        out[n][d:d + hi - lo].copy_(staging[n][lo:hi])
+        self.works, self.keep, self.chunks = [], [], []
         return out
 
 
