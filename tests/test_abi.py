@@ -60,3 +60,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "tw_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_compiled_c_host_builds_and_fails_loudly_without_a_gpu():
+    """examples/collect_from_c.c links against the C ABI with plain gcc; with no GPU it must stop with an error
+    (exit code 2), not fall back to anything."""
+    import subprocess
+    import twisterl_amd
+    from twisterl_amd import build as tb
+    exe = tb.build_c_example()
+    if twisterl_amd.device_count() > 0:
+        return                                  # on the GPU box the parity test runs it for real
+    r = subprocess.run([exe, "4", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode == 2 and "no GPU" in r.stderr and "records" not in r.stdout

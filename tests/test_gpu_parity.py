@@ -793,6 +793,53 @@ def test_mid_size_batches_use_the_queue_with_the_small_batch_geometry(tw, oracle
         assert np.array_equal(z[k], zh[k]), k
 
 
+def test_compiled_host_over_the_c_abi_matches_the_python_mirror(tw, oracle):
+    """examples/collect_from_c.c (gcc, no Python, no torch in the process) builds a policy from an LCG, collects through the
+    C ABI and prints FNV-1a checksums of every field; the same weights through twisterl_amd.nn give the same bytes."""
+    import os, subprocess
+    from twisterl_amd import build as tb
+    exe = tb.build_c_example()
+    E, seed = 500, 7
+    env = dict(os.environ)
+    out = subprocess.run([exe, str(E), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = {}
+    for line in out.stdout.splitlines():
+        parts = line.split()
+        if len(parts) == 3 and parts[0] in ("obs", "logits", "perms", "values", "rewards", "actions", "advs", "rets", "ep_len"):
+            got[parts[0]] = (int(parts[1]), int(parts[2], 16))
+    assert set(got) >= {"obs", "logits", "values", "actions", "advs", "rets", "ep_len"}
+
+    state = 0x9e3779b97f4a7c15
+    def filled(n, bound):                                  # the C program's LCG, bit for bit
+        nonlocal state
+        v = np.empty(n, dtype=np.float32)
+        for i in range(n):
+            state = (state * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
+            r = np.float32(state >> 40)
+            v[i] = (r / np.float32(16777216.0) * np.float32(2.0) - np.float32(1.0)) * np.float32(bound)
+        return v
+    OBS, EMB, HID, ACT = 81, 64, 64, 4
+    emb, emb_b = filled(OBS * EMB, 0.111), filled(EMB, 0.111)
+    w1, b1 = filled(EMB * HID, 0.125), filled(HID, 0.125)
+    wa, ba = filled(HID * ACT, 0.125), filled(ACT, 0.125)
+    wv, bv = filled(HID, 0.125), filled(1, 0.125)
+    pol = tw.nn.Policy(tw.nn.EmbeddingBag(emb.reshape(OBS, EMB).tolist(), emb_b.tolist(), True, [OBS], 0),
+                       tw.nn.Sequential([tw.nn.Linear(w1.tolist(), b1.tolist(), True)]),
+                       tw.nn.Sequential([tw.nn.Linear(wa.tolist(), ba.tolist(), False)]),
+                       tw.nn.Sequential([tw.nn.Linear(wv.tolist(), bv.tolist(), False)]), [], [])
+    a = tw.collector.PPOCollector(E, 0.995, 0.995, 1).collect(tw.env.Puzzle(3, 3, 6, 2, 256), pol, seed=seed).to_numpy()
+
+    def fnv1a(arr):
+        h = 0xcbf29ce484222325
+        for b in np.ascontiguousarray(arr).view(np.uint8).reshape(-1).tolist():
+            h = ((h ^ b) * 0x100000001b3) & (2**64 - 1)
+        return h
+    for k, (nbytes, h) in got.items():
+        assert a[k].nbytes == nbytes, (k, a[k].nbytes, nbytes)
+        assert fnv1a(a[k]) == h, k
+
+
 def test_end_to_end_loop_sketch(tw, oracle):
     """examples/ppo_loop_sketch.py: collect -> data_to_torch -> torch PPO update -> device policy sync -> evaluate, three
     iterations with nothing going through host lists; the losses are finite and the synced policy is the trained one."""

@@ -77,5 +77,19 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_c_example() -> str:
+    """examples/collect_from_c.c: a compiled host over the C ABI alone (gcc, links the library built above)."""
+    src = os.path.join(ROOT, "examples", "collect_from_c.c")
+    exe = os.path.join(ROOT, "examples", "collect_from_c")
+    if _stale(exe, [src, LIB_PATH, os.path.join(ROOT, "include", "twisterl_hip.h")]):
+        cmd = ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-L", LIB_DIR, "-ltwisterl_hip",
+               "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,$ORIGIN/../twisterl_amd/lib", "-lm", "-o", exe]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"gcc failed on collect_from_c.c:\n{r.stdout}")
+    return exe
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_c_example())
