@@ -636,11 +636,184 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
     }
 };
 
-constexpr int geom_threads(int nw) { return 64 * (nw < 0 ? -nw : nw); }
+// =====================================================================================================
+// Engine3T: the tiny-batch geometry.  v_mfma_f32_16x16x4_f32 is a k-ordered fma chain too (scripts/mfma_probe/
+// probe_f32_16x16x4.hip: 0 mismatches in 65,536), so the exact forward also runs with SIXTEEN episodes per workgroup: four
+// waves, one per SIMD, share them and split the hidden units (16-row tiles, NT/2 per wave); per 16-column chunk a wave issues
+// 4 k-groups x NT/2 MFMAs of 32 cycles -- half the matrix time of Engine3S per forward, and twice as many workgroups, so
+// batches of <= CUs x 16 episodes (the reference's 1,024 envs and 4,096 self-play episodes) use every CU.
+// Lane l = (kq = l >> 4, jj = l & 15): A row / B and D column jj, k index kq inside a k-group; D rows 4*kq .. 4*kq+3.
+//   * A operands come from the SAME W1 image as Engine3 (k-step 2g + (kq>>1), parity kq&1, 32-row position 16*half + jj):
+//     one ds_read_b128 = the wave's four row tiles of a k-group;
+//   * the gather is split over the waves: wave w sums the rows for k-group w (one float per lane) and publishes it through
+//     the double-buffered LDS exchange, as in Engine3S;
+//   * heads: v_fma_f32 chains over the hidden units written to the freed ring slot, as in Engine3S.
+// In the kernels `j` is the episode column (0..15) and `h` the k index (0..3): lanes with h == 0 of wave 0 store.
+// =====================================================================================================
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int NT, int NC>
+struct Engine3T : Engine3<NT, NC, 0, 4> {
+    using B = Engine3<NT, NC, 0, 4>;
+    static constexpr int NS = 4, EPB = 16, TPW = NT / 2, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, NOPS = B::NOPS, H = NT * 32;
+    static constexpr bool SPLIT = true;
+    static_assert(NT == 8 || NT == 4, "Engine3T: 128 or 256 hidden units");
+
+    float *lds_x, *lds_user;
+
+    __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
+    __device__ __forceinline__ bool primary() const { return this->wave == 0; }
+    __device__ __forceinline__ int  ep_lane() const { return this->j; }
+    __device__ __forceinline__ bool owns_lane() const { return this->wave == this->j / (EPB / NS); }
+
+    __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
+    {
+        B::begin1(p, lds);
+        this->j = this->lane & 15; this->h = this->lane >> 4;
+        lds_x = lds + engine3_lds_floats<NT>(p.obs_size);
+        lds_user = lds_x + R3S_XCHG;
+    }
+
+    __device__ __forceinline__ void rows_of(uint64_t board, int n_cells, int perm, int (&rowoff)[NC]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int row = this->zero_row;
+            if (i < n_cells) {
+                const int id = i * n_cells + (int)nib(board, i);
+                row = perm >= 0 ? (int)this->perm_obs[perm * this->pol.obs_size + id] : id;
+            }
+            rowoff[i] = row * R3_LSTR;
+        }
+    }
+
+    __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
+    {
+        typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+        typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
+        const int jj = this->j, kq = this->h, wave = this->wave;
+        f32x4v acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+        // this wave's row tiles inside the W1 image: 32-row block 4*q + cc, rows 16*half .. 16*half+15 of it
+        const int half = wave >> 1;
+        const int q    = NT == 8 ? (wave & 1) : 0;
+        const int cc0  = NT == 8 ? 0 : 2 * (wave & 1);
+        const int a_off = (kq * NQ + q) * 128 + (16 * half + jj) * 4 + cc0;      // + g * 4*NQ*128 for k-group g
+        // gather: k-group `wave`, this lane's k = 4*wave + kq of the chunk -> position in the [even k | odd k] row image
+        const int gpos = (kq & 1) * 8 + 2 * wave + (kq >> 1);
+        lds_cfloat *ga[NC + 1];
+        ga[0] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT + this->bias_row * R3_LSTR) + gpos;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ga[c + 1] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT) + rowoff[c] + gpos;
+
+        float *xb = lds_x + 256;                                                  // [2 buffers][64 lanes][4 k-groups]
+        float gr[NC + 1];
+        auto gather_read = [&](int c) { gr[c] = *ga[c]; };
+        auto gather_finish = [&](int buf) {
+            float sm = gr[0];                                                     // bias row, then the cells in order
+#pragma unroll
+            for (int c = 1; c <= NC; ++c) sm = sm + gr[c];
+            xb[(buf * 64 + this->lane) * 4 + wave] = relu_lim_v(sm, this->emb_lim);
+        };
+        auto advance = [&](int from, int to) {
+            const int delta = (to - from) * R3_TSLOT;
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) ga[c] += delta;
+        };
+        auto read_a = [&](lds_cfloat *base, int g, float (&a)[TPW]) {
+            lds_cfloat *ap = base + g * (4 * NQ * 128);
+            if constexpr (TPW == 4) {
+                const f32x4 v = *reinterpret_cast<lds_cf4 *>(ap);
+                a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+            } else {
+                const f32x2 v = *reinterpret_cast<lds_cf2 *>(ap);
+                a[0] = v[0]; a[1] = v[1];
+            }
+        };
+
+        int s0 = this->rp;
+        float aw[TPW];
+        read_a((lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off), 0, aw);
+        {
+            const int s1 = s0 == 2 ? 0 : s0 + 1;
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) gather_read(c);
+            gather_finish(0);
+            advance(s0, s1);
+            __syncthreads();
+        }
+        for (int c = 0; c < this->n_chunks; ++c) {
+            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+            int sc = c + 2; if (sc >= this->n_chunks) sc -= this->n_chunks;       // chunk streamed now (wraps into the next forward)
+            if (this->n_chunks == 1) sc = 0;
+            const f32x4 bq = *reinterpret_cast<const f32x4 *>(xb + ((c & 1) * 64 + this->lane) * 4);
+            lds_cfloat *wb = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
+            lds_cfloat *wn = (lds_cfloat *)(this->lds_w + s1 * WSLOT + a_off);
+            constexpr int M = 4 * TPW;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const int g = m / TPW, t = m % TPW;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t], bq[g], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int op = m * NOPS / M; op < (m + 1) * NOPS / M; ++op) this->stream_op(sc, s2, op);
+#pragma unroll
+                for (int cq = m * (NC + 1) / M; cq < (m + 1) * (NC + 1) / M; ++cq) gather_read(cq);   // chunk c+1, complete in slot s1
+                if (t == TPW - 1) {
+                    if (g < 3) read_a(wb, g + 1, aw); else read_a(wn, 0, aw);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            gather_finish((c + 1) & 1);
+            advance(s1, s2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            s0 = s1;
+        }
+        this->rp = s0;
+
+        // heads: hidden units -> freed table slot as [unit/4][16 episodes][4], then one v_fma_f32 chain per (episode, output)
+        {
+            const int fs = s0 == 0 ? 2 : s0 - 1;
+            float *hid = this->lds_t + fs * R3_TSLOT;
+            // D row 4*kq + r of local tile t is hidden unit 32*(4q + cc0 + t) + 2*(r + 8*half + 4*(kq>>1)) + (kq&1)
+            const int ublk = 8 * half + 4 * (kq >> 1);                            // the lane-dependent part of g'
+            float *dst = hid + (8 * (4 * q + cc0) + 2 * (2 * half + (kq >> 1))) * 64 + jj * 4 + (kq & 1);
+            lds_cfloat *b1p = (lds_cfloat *)(this->lds_b1 + (kq & 1) * (NT * 16)) + 16 * (4 * q + cc0) + ublk;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[t * 8 * 64 + (r >> 1) * 64 + 2 * (r & 1)] = relu_lim_v(acc[t][r] + b1p[16 * t + r], this->common_lim);
+            __syncthreads();
+            const int o  = wave + 4 * kq;                                          // outputs 0..3: lanes kq == 0 of wave o; value: kq == 1 of wave 0
+            const int oc = o < 4 ? o : 4;
+            lds_cfloat *wp = (lds_cfloat *)this->lds_wn + oc * H;
+            float a = 0.0f;
+#pragma unroll
+            for (int m = 0; m < H / 4; ++m) {
+                const f32x4 w = *reinterpret_cast<lds_cf4 *>(wp + 4 * m);
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(hid + m * 64 + jj * 4);
+                a = __builtin_fmaf(w[0], x[0], a); a = __builtin_fmaf(w[1], x[1], a);
+                a = __builtin_fmaf(w[2], x[2], a); a = __builtin_fmaf(w[3], x[3], a);
+            }
+            if (o < 5) lds_x[o * 16 + jj] = a + this->lds_bh[o];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[i] = lds_x[i * 16 + jj];
+            value = lds_x[4 * 16 + jj];
+        }
+    }
+};
+
+constexpr int geom_threads(int nw) { return nw == -16 ? 256 : 64 * (nw < 0 ? -nw : nw); }
 // launch geometry code -> engine: NW > 0 = NW independent waves of 32 episodes (Engine3); NW < 0 = -NW waves sharing 32 (Engine3S)
 template <int NT, int NC, int DBG, int NW> struct Geom { using Eng = Engine3<NT, NC, DBG, NW>; static constexpr int WAVES = NW; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -4> { using Eng = Engine3S<NT, NC, 4>; static constexpr int WAVES = 4; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -2> { using Eng = Engine3S<NT, NC, 2>; static constexpr int WAVES = 2; };
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -16> { using Eng = Engine3T<NT, NC>; static constexpr int WAVES = 4; };   // 16 episodes per workgroup
 
 // geometry for n episodes: 8 = the throughput shape; below ~3/4 of a chip of 256-episode workgroups the split shape
 template <int NT> inline int geometry_for(uint64_t n)
@@ -648,6 +821,8 @@ template <int NT> inline int geometry_for(uint64_t n)
     int nw = waves_per_group(n);
     if (const char *f = getenv("TW_FORCE_GEOM")) nw = atoi(f) == 8 ? 8 : 1;     // diagnostic: 8 = throughput shape, else small-batch
     if (nw == 8 || NT < 2) return nw;
+    // up to one 16-episode workgroup per CU (4,096 episodes on an MI355X): the tiny-batch shape; TW_FORCE_GEOM=32 keeps the 32-episode one
+    if (NT >= 4 && n <= rollout_f32_resident_episodes() / 16 && !(getenv("TW_FORCE_GEOM") && atoi(getenv("TW_FORCE_GEOM")) == 32)) return -16;
     return NT >= 4 ? -4 : -2;
 }
 

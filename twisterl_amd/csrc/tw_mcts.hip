@@ -466,6 +466,7 @@ static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
         return launch_mcts_geom<NT, NC, 8, true>(a, s, blocks, threads);
     }
     const int nw = geometry_for<NT>(a.num_episodes);
+    if constexpr (NT >= 4) { if (nw == -16) return launch_mcts_geom<NT, NC, -16>(a, s, blocks, threads); }
     if constexpr (NT >= 4) { if (nw == -4) return launch_mcts_geom<NT, NC, -4>(a, s, blocks, threads); }
     else if constexpr (NT == 2) { if (nw == -2) return launch_mcts_geom<NT, NC, -2>(a, s, blocks, threads); }
     else {

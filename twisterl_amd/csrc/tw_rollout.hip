@@ -225,6 +225,7 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
         return launch_geom<NT, NC, 0, 8, true>(a, s, blocks, threads);
     }
     const int nw = geometry_for<NT>(a.num_episodes);
+    if constexpr (NT >= 4) { if (nw == -16) return launch_geom<NT, NC, 0, -16>(a, s, blocks, threads); }
     if constexpr (NT >= 4) { if (nw == -4) return launch_geom<NT, NC, 0, -4>(a, s, blocks, threads); }
     else if constexpr (NT == 2) { if (nw == -2) return launch_geom<NT, NC, 0, -2>(a, s, blocks, threads); }
     else {

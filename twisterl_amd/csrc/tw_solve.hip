@@ -103,6 +103,7 @@ template <int NT, int NC>
 static int launch_solve_one(const SolveArgs &a, hipStream_t s)
 {
     const int nw = geometry_for<NT>(a.num_attempts);
+    if constexpr (NT >= 4) { if (nw == -16) return launch_solve_geom<NT, NC, -16>(a, s); }
     if constexpr (NT >= 4) { if (nw == -4) return launch_solve_geom<NT, NC, -4>(a, s); }
     else if constexpr (NT == 2) { if (nw == -2) return launch_solve_geom<NT, NC, -2>(a, s); }
     else {
