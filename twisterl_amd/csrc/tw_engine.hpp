@@ -124,23 +124,29 @@ struct Engine3 {
     float *lds_w, *lds_t, *lds_b1, *lds_wh, *lds_bh, *lds_wn;   // lds_wn: head weights in natural order [output 0..4][hidden]
     const uint8_t *perm_obs, *perm_act;
 
-    // DMA op `op` of this wave for chunk `chunk` (of the flat chunk sequence) into ring slot `slot`.  Scalar source (SGPR base
-    // + lane*16 in a VGPR that never changes) and scalar destination (M0): no vector address arithmetic.
+    // DMA op `op` of this wave for chunk `chunk` (of the flat chunk sequence) into ring slot `slot`: piece wave + NW*op of
+    // [W1 pieces | table pieces].  Scalar source (SGPR base + lane*16 in a VGPR that never changes) and scalar destination (M0).
+    // WPIECE is a multiple of NW, so an op's role (W1 or table) is a compile-time fact once the op loop is unrolled, and
+    // everything wave-dependent is folded into dsrc_* / ddst_* at begin1: an op costs two 64-bit scalar adds, one 32-bit add
+    // and the M0 write (the generic form spent 9 scalar instructions per op, which a lone wave per SIMD cannot hide).
+    static_assert(WPIECE % NW == 0, "W1 pieces per chunk must be a multiple of the wave count");
+    const uint8_t *dsrc_w, *dsrc_t;        // image bases (+ this wave's first W1 piece)
+    uint32_t ddst_w, ddst_t;               // LDS byte addresses of ring slot 0 (+ this wave's first W1 piece)
     __device__ __forceinline__ void stream_op(int chunk, int slot, int op)
     {
         if constexpr (DBG & 4) return;
-        // branch-free: a piece index past the end repeats the last piece (same bytes, same place)
-        int piece = wave + NW * op;
-        piece = piece < NPIECE ? piece : NPIECE - 1;
-        const bool is_w = piece < WPIECE;
-        const int  tp   = piece - WPIECE;
-        const float *src = is_w ? pol.w1p + (size_t)chunk * WSLOT + piece * 256
-                                : pol.t_img16 + (size_t)chunk * R3_TSLOT + tp * 256;
-        float *dst = is_w ? lds_w + slot * WSLOT + piece * 256 : lds_t + slot * R3_TSLOT + tp * 256;
-        const unsigned d = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)dst;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                     :: "v"(voff), "s"(__builtin_amdgcn_readfirstlane(d)), "s"(src)
-                     : "memory", "m0");
+        if (NW * op < WPIECE) {
+            const uint8_t *src = dsrc_w + (size_t)chunk * (WSLOT * 4) + (size_t)op * (NW * 1024);
+            const uint32_t dst = ddst_w + (uint32_t)slot * (WSLOT * 4) + (uint32_t)op * (NW * 1024);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(voff), "s"(dst), "s"(src) : "memory", "m0");
+        } else {
+            const int T0 = NW * op - WPIECE;                                 // table piece of wave 0
+            uint32_t tp = (uint32_t)wave + (uint32_t)T0;
+            if (T0 + NW - 1 >= TPIECE) tp = tp < (uint32_t)TPIECE ? tp : (uint32_t)TPIECE - 1u;   // past the end: repeat the last piece
+            const uint8_t *src = dsrc_t + (size_t)chunk * (R3_TSLOT * 4) + (size_t)tp * 1024;
+            const uint32_t dst = ddst_t + (uint32_t)slot * (R3_TSLOT * 4) + tp * 1024u;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(voff), "s"(dst), "s"(src) : "memory", "m0");
+        }
     }
 
     __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
@@ -160,6 +166,10 @@ struct Engine3 {
         lds_b1 = lds_t + 3 * R3_TSLOT;
         lds_wh = lds_b1 + NT * 32;
         lds_bh = lds_wh + NT * 32 * 9;
+        dsrc_w = reinterpret_cast<const uint8_t *>(pol.w1p) + (size_t)wave * 1024;
+        dsrc_t = reinterpret_cast<const uint8_t *>(pol.t_img16);
+        ddst_w = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds_w) + (uint32_t)wave * 1024u;
+        ddst_t = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds_t);
         for (int i = tid; i < NT * 32; i += THREADS) lds_b1[(i & 1) * (NT * 16) + (i >> 1)] = pol.b1[i];
         for (int i = tid; i < NT * 32 * 8; i += THREADS) {
             const int n = i >> 3, c = i & 7;
@@ -660,6 +670,9 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
     static_assert(NT == 8 || NT == 4, "Engine3T: 128 or 256 hidden units");
 
     float *lds_x, *lds_user;
+#ifdef TW_ABLATE
+    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk compute | vmcnt wait | barrier wait | heads | -
+#endif
 
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
     __device__ __forceinline__ bool primary() const { return this->wave == 0; }
@@ -735,6 +748,7 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
 
         int s0 = this->rp;
         float aw[TPW];
+        TW_S3(q_in);
         read_a((lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off), 0, aw);
         {
             const int s1 = s0 == 2 ? 0 : s0 + 1;
@@ -744,10 +758,13 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             advance(s0, s1);
             __syncthreads();
         }
+        TW_S3(q_pro);
+        TW_A3(0, q_in, q_pro);
         for (int c = 0; c < this->n_chunks; ++c) {
             const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
             int sc = c + 2; if (sc >= this->n_chunks) sc -= this->n_chunks;       // chunk streamed now (wraps into the next forward)
             if (this->n_chunks == 1) sc = 0;
+            TW_S3(q_c0);
             const f32x4 bq = *reinterpret_cast<const f32x4 *>(xb + ((c & 1) * 64 + this->lane) * 4);
             lds_cfloat *wb = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
             lds_cfloat *wn = (lds_cfloat *)(this->lds_w + s1 * WSLOT + a_off);
@@ -768,13 +785,18 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             }
             gather_finish((c + 1) & 1);
             advance(s1, s2);
+            TW_S3(q_c1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TW_S3(q_c2);
             __syncthreads();
+            TW_S3(q_c3);
+            TW_A3(1, q_c0, q_c1); TW_A3(2, q_c1, q_c2); TW_A3(3, q_c2, q_c3);
             s0 = s1;
         }
         this->rp = s0;
 
         // heads: hidden units -> freed table slot as [unit/4][16 episodes][4], then one v_fma_f32 chain per (episode, output)
+        TW_S3(q_h0);
         {
             const int fs = s0 == 0 ? 2 : s0 - 1;
             float *hid = this->lds_t + fs * R3_TSLOT;
@@ -805,6 +827,8 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             for (int i = 0; i < 4; ++i) lg[i] = lds_x[i * 16 + jj];
             value = lds_x[4 * 16 + jj];
         }
+        TW_S3(q_h1);
+        TW_A3(4, q_h0, q_h1);
     }
 };
 
