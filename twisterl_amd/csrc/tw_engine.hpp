@@ -105,7 +105,10 @@ struct Engine3 {
     static constexpr int NQ     = Tiles<NT>::NQ;
     static constexpr int WSLOT  = KC * NQ * 128;            // floats per W1 slot
     static constexpr int WPIECE = WSLOT / 256;              // DMA pieces per W1 chunk
-    static constexpr int TPIECE = R3_TSLOT / 256;           // DMA pieces per table chunk (21)
+    // DMA pieces per table chunk: only the rows a board of <= NC cells can address (NC*NC ids + bias row + zero row) are
+    // streamed -- 21 pieces for Puzzle-15, 7 for Puzzle-8 (the image and the LDS slot keep the full 21 KiB stride)
+    static constexpr int TPIECE = ((NC * NC + 2) * R3_LSTR * 4 + 1023) / 1024;
+    static_assert(TPIECE * 256 <= R3_TSLOT, "table chunk larger than its slot");
     static constexpr int NPIECE = WPIECE + TPIECE;
     static constexpr int NOPS   = (NPIECE + NW - 1) / NW;   // DMA ops per wave per chunk
     static constexpr int M      = 4 * NT;                   // MFMAs per group of four k-steps
