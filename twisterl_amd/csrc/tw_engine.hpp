@@ -14,20 +14,10 @@ typedef __attribute__((address_space(3))) const float lds_cfloat;
 
 constexpr int EPW = 32;            // episodes per wave (MFMA columns)
 
-// One 1-KiB LDS-DMA piece: every lane copies 16 bytes global -> LDS (destination = wave-uniform
-// base in M0 + lane*16).  Issued through inline asm on purpose: the builtin form is FLAT-encoded
-// with an LDS memory operand, which makes hipcc treat it as a pending flat access and degrade
-// EVERY later LDS wait to lgkmcnt(0) until the DMA has been waited for.  The copy is waited for
-// with the explicit vmcnt(0) in front of the chunk barrier.
-__device__ __forceinline__ void glds16(const float *gsrc, float *lds_dst)
-{
-    unsigned keep;
-    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds_dst;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(dst))
-                 : "memory");
-}
+// LDS-DMA (Engine3::stream_op): one 1-KiB piece per instruction, every lane copies 16 bytes global -> LDS (destination =
+// wave-uniform base in M0 + lane*16).  Issued through inline asm on purpose: the builtin form is FLAT-encoded with an LDS
+// memory operand, which makes hipcc treat it as a pending flat access and degrade EVERY later LDS wait to lgkmcnt(0) until
+// the DMA has been waited for.  The copy is waited for with the explicit vmcnt(0) in front of the chunk barrier.
 
 // ReLU as ONE v_max_f32 (hipcc lowers `x > 0 ? x : 0` to a canonicalising v_max plus the v_max).
 // IEEE mode: max(0, NaN) = 0, like the reference's `if x > 0.0 { x } else { 0.0 }` (layers.rs:89-91).

@@ -81,7 +81,7 @@ struct Engine16 {
     h16x2 emb_lim, common_lim;
 
     // One DMA op = this wave's 1-KiB piece (wave + NW*op) of a stage: global (SGPR base + per-lane VGPR offset) -> LDS
-    // (M0 = wave-uniform destination, the hardware adds lane*16).  Inline asm: see glds16() in tw_engine.hpp.
+    // (M0 = wave-uniform destination, the hardware adds lane*16).  Inline asm: see the LDS-DMA note in tw_engine.hpp.
     __device__ __forceinline__ void stream_op(const uint8_t *stage_base, uint32_t slot_m0, int op) const
     {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
