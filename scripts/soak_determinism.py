@@ -30,3 +30,24 @@ for prec, env, E in (("fp32", twisterl.env.Puzzle(4, 4, 128, 2, 256), 262144), (
         if ref is None: ref = dg
         elif dg != ref: bad += 1
     print(prec, "E", E, "difficulty", env.difficulty, "repeats", n, "mismatching repeats", bad, flush=True)
+
+# small and mid-size batches: the 16-episode shape, the 32-episode shape, the same with the episode queue; self-play likewise
+pol0 = bench.build_policy(bench.synthetic_weights(16), [], [])
+for E, rep in ((1024, 4 * n), (4096, 4 * n), (8000, 2 * n), (20000, 2 * n)):
+    for env in (twisterl.env.Puzzle(4, 4, 16, 2, 256), twisterl.env.Puzzle(4, 4, 1, 32, 256)):
+        coll = twisterl.collector.PPOCollector(E, 0.995, 0.995, 1)
+        ref = None; bad = 0
+        for i in range(rep):
+            dg = digest(coll.collect(env, pol, seed=5))
+            if ref is None: ref = dg
+            elif dg != ref: bad += 1
+        print("fp32 small E", E, "difficulty", env.difficulty, "repeats", rep, "mismatching repeats", bad, flush=True)
+for E, S, rep in ((1024, 50, n), (4096, 30, n), (20000, 16, n), (70000, 8, max(2, n // 3))):
+    env = twisterl.env.Puzzle(4, 4, 4, 2, 256)
+    coll = twisterl.collector.AZCollector(E, S, 1.41, 1, 1)
+    ref = None; bad = 0
+    for i in range(rep):
+        dg = digest(coll.collect(env, pol0, seed=7))
+        if ref is None: ref = dg
+        elif dg != ref: bad += 1
+    print("self-play E", E, "searches", S, "repeats", rep, "mismatching repeats", bad, flush=True)
