@@ -840,6 +840,34 @@ def test_compiled_host_over_the_c_abi_matches_the_python_mirror(tw, oracle):
         assert fnv1a(a[k]) == h, k
 
 
+@pytest.mark.parametrize("geom", ["32", "8"])
+def test_every_launch_shape_gives_the_same_bytes(tw, oracle, geom):
+    """The launch shape is chosen from the batch size (16 / 32 episodes per workgroup shared by four waves, or 8 waves x 32);
+    TW_FORCE_GEOM pins it.  A Puzzle-15 collect and a self-play collect must not depend on it, bit for bit -- and the
+    default shape is checked against the oracle by the other tests."""
+    import os
+    gp, _ = _pair(oracle, 16, 1, 512, 256, twists=True)
+    env = tw.env.Puzzle(4, 4, 6, 2, 256)
+    pc = tw.collector.PPOCollector(600, 0.995, 0.995, 1)
+    gz, _ = _pair(oracle, 9, 2, 64, 128, twists=False, scale=3.0)
+    zenv = tw.env.Puzzle(3, 3, 3, 2, 256)
+    zc = tw.collector.AZCollector(300, 12, 1.41, 1, 1)
+    a = pc.collect(env, gp, seed=31)
+    z = zc.collect(zenv, gz, seed=37)
+    os.environ["TW_FORCE_GEOM"] = geom
+    try:
+        b = pc.collect(env, gp, seed=31)
+        y = zc.collect(zenv, gz, seed=37)
+    finally:
+        del os.environ["TW_FORCE_GEOM"]
+    assert (a.stats["rollout_blocks"], a.stats["rollout_threads"]) != (b.stats["rollout_blocks"], b.stats["rollout_threads"])
+    an, bn, zn, yn = a.to_numpy(), b.to_numpy(), z.to_numpy(), y.to_numpy()
+    for k in an:
+        assert np.array_equal(an[k], bn[k]), (geom, k)
+    for k in zn:
+        assert np.array_equal(zn[k], yn[k]), (geom, k)
+
+
 def test_end_to_end_loop_sketch(tw, oracle):
     """examples/ppo_loop_sketch.py: collect -> data_to_torch -> torch PPO update -> device policy sync -> evaluate, three
     iterations with nothing going through host lists; the losses are finite and the synced policy is the trained one."""
