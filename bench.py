@@ -98,12 +98,18 @@ def cpu_baseline(arrs, obs_perms, act_perms, side, difficulty, target_seconds, t
                       f"arithmetic, {cores} threads, {dt:.1f} s"}
 
 
-def main():
+STRONG_TOTAL_ENVS = 2_097_152      # BASELINE.json config 4: "2M envs sharded over 8 x MI355X"
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--envs", type=int, default=262_144, help="episodes per GPU per step")
+    ap.add_argument("--envs", type=int, default=262_144, help="episodes per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help=f"weak: --envs episodes on every GPU; strong: {STRONG_TOTAL_ENVS} episodes in total, split over the GPUs")
+    ap.add_argument("--total-envs", type=int, default=STRONG_TOTAL_ENVS, help="episodes in total with --scaling strong")
     ap.add_argument("--puzzle", type=int, default=15, choices=[8, 15])
     ap.add_argument("--difficulty", type=int, default=128)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "fp16x2"])
@@ -111,28 +117,84 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true", help="print the launch plan (ranks, command) as JSON and exit; needs no GPU")
+    return ap.parse_args(argv)
 
+
+def launch_plan(args, argv):
+    """How `bench.py --gpus N` gets its N ranks when it was NOT started under torchrun: one child process running
+    torch.distributed.run with N ranks of this very script (one process per GPU, RCCL)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    return {"n_ranks": args.gpus, "ranks": [{"rank": r, "local_rank": r, "device": f"cuda:{r}"} for r in range(args.gpus)], "command": cmd}
+
+
+def self_launch(args, argv) -> int:
+    """Runs the N-rank job as a fresh CHILD (never exec: nothing here has touched the GPU yet, and nothing will in this
+    process) and relays rank 0's JSON line."""
+    import subprocess
+    plan = launch_plan(args, argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    child = subprocess.run(plan["command"], env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if child.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank child exited with code {child.returncode}" + ("" if line else " without a result line"), file=sys.stderr)
+        return child.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    under_launcher = "RANK" in os.environ
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.dry_launch:
+        plan = launch_plan(args, argv) if (args.gpus > 1 and not under_launcher) else \
+            {"n_ranks": world if under_launcher else 1, "ranks": [{"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}"}], "command": None}
+        print(json.dumps(plan), flush=True)
+        return
+    if under_launcher and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.gpus > 1 and not under_launcher:
+        # started plainly (`python bench.py --gpus N`): become the launcher of N ranks BEFORE anything touches torch or HIP
+        raise SystemExit(self_launch(args, argv))
 
     import torch
     import twisterl_amd
     from twisterl_amd import _lib, twisterl
     if twisterl_amd.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP collector has no CPU fallback")
+    if local_rank >= twisterl_amd.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, {twisterl_amd.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     _lib.check(_lib.lib().tw_set_device(local_rank))
     dist = None
-    use_dist = world > 1 or "RANK" in os.environ        # under torchrun the distributed path runs even at N=1
+    # under torchrun the distributed path runs even at N=1; strong scaling at N=1 needs the chunked path as well
+    use_dist = world > 1 or under_launcher or args.scaling == "strong"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not under_launcher:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        from twisterl_amd.dist import collect_sharded
+        from twisterl_amd.dist import DEFAULT_RESERVE_CUS, TrajectoryGather, collect_sharded, pipeline_steps
 
     side = 4 if args.puzzle == 15 else 3
     n2 = side * side
@@ -140,19 +202,30 @@ def main():
     obs_perms, act_perms = ([], []) if args.no_twists else transpose_twist(side)
     policy = build_policy(arrs, obs_perms, act_perms)
     env = twisterl.env.Puzzle(side, side, args.difficulty, 2, 256)
-    E_total = args.envs * world
+    E_total = args.envs * world if args.scaling == "weak" else args.total_envs
+    envs_per_gpu = E_total / world
     coll = twisterl.collector.PPOCollector(**{"num_episodes": E_total, "gamma": 0.995, "lambda": 0.995, "num_cores": 32},
                                            precision=args.precision)
+    t_max = 2 * args.difficulty + 1                       # records per episode at most (depth_slope 2)
 
-    gather_chunks = int(os.environ.get("TW_GATHER_CHUNKS", "4" if world > 1 else "1"))
+    gatherer, reserve, step_eps = None, 0, None
+    if use_dist:
+        # N > 1: every rank's share is collected in pipeline steps so that a step's xGMI transfer to rank 0 overlaps with the
+        # collection of the next step (twisterl_amd.dist).  While a transfer can be in flight the persistent rollout grid
+        # leaves `reserve` CUs to RCCL's send/recv kernels; the untrained policy runs every episode to full length, so a step
+        # is one whole round of the resident lanes ((CUs - reserve) x 256 episodes per rank) -- anything else would leave most
+        # lanes idle for an episode's duration at the end of the step.
+        reserve = int(os.environ.get("TW_RESERVE_CUS", str(DEFAULT_RESERVE_CUS if world > 1 else 0)))
+        cus = twisterl_amd.device_info()["compute_units"]
+        step_eps = int(os.environ.get("TW_STEP_EPISODES", str((cus - reserve) * 256)))
+        K = pipeline_steps(E_total, world, 1, step_eps)
+        gatherer = TrajectoryGather(dst=0, steps=K, max_records=E_total * t_max if K > 1 else None, max_episode_records=t_max)
 
     def step(i):
         seed = 1000 + i
         if use_dist:
-            # N > 1: the shard is collected in chunks so that each chunk's xGMI transfer to rank 0 overlaps with the
-            # collection of the next one (twisterl_amd.dist.PipelinedGather); the gather is inside the timed region
-            merged, data = collect_sharded(coll, env, policy, seed=seed, dst=0, chunks=gather_chunks)
-            datas = data if isinstance(data, list) else [data]
+            merged, datas = collect_sharded(coll, env, policy, seed=seed, dst=0, max_episode_records=t_max, gatherer=gatherer,
+                                            reserve_cus=reserve, step_episodes=step_eps)       # the gather is inside the timed region
             n = sum(len(d) for d in datas)
             del merged
             return n, {"ms_rollout": sum(d.stats["ms_rollout"] for d in datas)}
@@ -205,17 +278,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "fp16": "f16", "fp16x2": "f16x2 (f32-equivalent: two f16 terms per operand)"}[args.precision],
             "data": "synthetic",
             "config": {
-                "workload": f"Puzzle-{args.puzzle} PPO rollout + GAE + merge: {args.envs} envs/GPU, difficulty {args.difficulty} "
+                "workload": f"Puzzle-{args.puzzle} PPO rollout + GAE + merge: {envs_per_gpu:g} envs/GPU, difficulty {args.difficulty} "
                             f"(<= {2 * args.difficulty + 1} records/episode), twists "
                             f"{'none' if args.no_twists else '{identity, transpose}'}, BasicPolicy {n2 * n2}->512->256->4|1, "
                             f"gamma=lambda=0.995, torch-default-init weights seed 0",
-                "envs_per_gpu": args.envs, "records_per_step": rec_per_launch * world,
-                "mean_records_per_episode": rec_per_launch / args.envs, "parallelism": f"episodes sharded x{world}",
+                "envs_per_gpu": envs_per_gpu, "total_envs": E_total, "records_per_step": total_records / args.steps,
+                "mean_records_per_episode": total_records / args.steps / E_total, "parallelism": f"episodes sharded x{world}",
+                "gather": None if not use_dist else {"pipeline_steps": gatherer.steps, "episodes_per_rank_and_step": step_eps,
+                                                    "reserved_cus": reserve, "transport": "RCCL send/recv at final offsets"},
             },
             "roofline": {
                 "bound": "mfma", "kernel": "tw::rollout_f32_kernel" if args.precision == "fp32" else "tw::rollout_f16_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -228,7 +303,7 @@ def main():
                 "hbm_frac": rec_per_launch * BYTES_PER_RECORD[n2] / kern_s / 8e12,
             },
         }
-        if world == 1 and args.precision == "fp32":
+        if world == 1 and args.precision == "fp32" and not use_dist:
             # side measurements, not the headline: the same workload in the two f16-matrix-core modes.
             #   fp16x2: every f32 operand as two f16 terms -- logits within 5e-8 of the reference f32 arithmetic on sampled
             #           records (tests/tools/acc_modes.py; the exact f32 mode is within 2e-8), tests allow BASELINE.json's 1e-5
@@ -253,7 +328,7 @@ def main():
                     return {"error": str(e)}
             out["f16x2_mode_f32_equivalent"] = side_mode("fp16x2")
             out["f16_input_mode"] = side_mode("fp16")
-        if not args.no_cpu_baseline and world == 1:     # timed on rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not use_dist:     # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if dist is not None:

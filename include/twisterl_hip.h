@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 1
+#define TW_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -69,6 +69,16 @@ typedef struct {
     uint64_t lds_bytes_per_block;
 } tw_device_info;
 int tw_get_device_info(tw_device_info *out);
+/* Frees the cached device memory of the current process (trajectory workspace, pooled result arenas). */
+int tw_release_cached_memory(void);
+
+/* Diagnostic launch overrides -- test hooks (the parity tests pin launch shapes with them to show that every shape gives
+ * the same bytes); process-wide, 0 restores the default.  Not needed by a host of the reference's collector. */
+enum {
+    TW_OPT_FORCE_GEOM = 0,  /* 8: the 256-episode workgroup shape, 32: the 32-episode shape, 1: small-batch, 0: automatic */
+    TW_OPT_NO_PERSIST = 1   /* 1: never use persistent lanes + episode queue                                               */
+};
+int tw_set_launch_option(int option, int value);
 
 /* ---------------------------------------------------------------------------------------- */
 /* Env: host object with the PyBaseEnv / Puzzle surface.  Collectors only read its          */
@@ -171,6 +181,9 @@ typedef struct {
     uint32_t precision;       /* TW_PREC_*                                                     */
     uint32_t merge_order;     /* 1: reference order [E-1, 0, .., E-2] (collector.rs:40-46)     */
                               /* 0: episode-index order (shards, before the cross-GPU gather)  */
+    uint32_t reserve_cus;     /* multi-GPU: compute units the persistent rollout grid leaves    */
+                              /* free, so that RCCL's send/recv kernels of the previous chunk's */
+                              /* gather can run beside it (0 = use every CU)                    */
 } tw_ppo_params;
 
 typedef struct {
@@ -181,6 +194,7 @@ typedef struct {
     uint64_t seed;
     uint32_t precision;
     uint32_t merge_order;
+    uint32_t reserve_cus;         /* as in tw_ppo_params                                        */
 } tw_az_params;
 
 /* solve / evaluate (rust/src/rl/solve.rs:73-101, rust/src/rl/evaluate.rs:22-89; PyO3 functions

@@ -13,7 +13,8 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 coll = twisterl.collector.PPOCollector(E, 0.995, 0.995, 1)
 for mode in ("persistent", "plain"):
     if mode == "plain":
-        os.environ["TW_NO_PERSIST"] = "1"
+        from twisterl_amd import _lib
+        _lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_NO_PERSIST, 1))
     coll.collect(env, pol, seed=0)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 0

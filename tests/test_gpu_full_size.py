@@ -1,0 +1,133 @@
+"""GPU: the configurations the published numbers are quoted on, AT FULL SIZE, against the oracle.
+
+* BASELINE config 3 exactly as bench.py runs it (Puzzle-15, 262,144 envs, difficulty 128, twists {identity,
+  transpose}, BasicPolicy 256->512->256->4|1 with torch-default-init weights seed 0, merge order): the launch is the
+  8-wave x 32-episode shape with persistent lanes and the episode queue -- the kernel the bench times.
+* BASELINE config 5 at the reference's per-GPU batch (4,096 episodes x 100 and x 1,000 searches, Puzzle-15, the
+  same policy).
+
+The RNG is keyed by the GLOBAL episode index, so `oracle.*_collect(num_episodes=1, episode_offset=e)` is the oracle's
+version of episode e of the big batch: sampled episodes are compared bit for bit on every field; size-independent
+properties (determinism, record-count identities, the [E-1, 0, .., E-2] rotation) cover the rest.  The big buffers stay
+on the device (torch views); only the sampled slices and the per-episode tables are copied to the host.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import f32_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tw():
+    import twisterl_amd
+    assert twisterl_amd.device_count() >= 1, "no GPU visible: the -m gpu tests need the MI355X box"
+    return twisterl_amd.twisterl
+
+
+def _bench_policy(oracle, twists):
+    import bench
+    arrs = bench.synthetic_weights(16, seed=0)
+    op, ap = bench.transpose_twist(4) if twists else ([], [])
+    return bench.build_policy(arrs, op, ap), oracle.Policy(*arrs, op, ap)
+
+
+def _sample_episodes(E, n, seed):
+    rng = np.random.default_rng(seed)
+    return sorted(set([0, 1, E - 2, E - 1] + [int(x) for x in rng.choice(E, size=n, replace=False)]))
+
+
+def test_config3_as_benched_full_size_vs_oracle(tw, oracle):
+    import twisterl_amd
+    gp, op = _bench_policy(oracle, twists=True)
+    E, D = 262_144, 128
+    env, oenv = tw.env.Puzzle(4, 4, D, 2, 256), oracle.Puzzle(4, 4, D, 2, 256)
+    coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32})
+    g = coll.collect(env, gp, seed=1000)
+    # the launch shape of the bench: 8 waves x 32 episodes per workgroup, one persistent workgroup per CU
+    assert g.stats["rollout_threads"] == 512
+    assert g.stats["rollout_blocks"] == twisterl_amd.device_info()["compute_units"]
+    t = g.to_torch()
+    n = len(g)
+    L = t["ep_len"].cpu().numpy().astype(np.int64)
+    S = t["ep_start"].cpu().numpy().astype(np.int64)
+    # record-count identities
+    assert L.shape == (E,) and L.sum() == n == g.stats["records"] and L.min() >= 1 and L.max() <= 2 * D + 1
+    for k, w in (("obs", 16), ("logits", 4)):
+        assert tuple(t[k].shape) == (n, w)
+    for k in ("perms", "values", "rewards", "actions", "advs", "rets"):
+        assert tuple(t[k].shape) == (n,)
+    # merge order [E-1, 0, 1, .., E-2] (collector.rs:40-46): episode E-1 first, then the index order
+    order = np.concatenate([[E - 1], np.arange(E - 1)])
+    assert np.array_equal(S[order], np.concatenate([[0], np.cumsum(L[order])[:-1]]))
+    # integer sanity of the whole buffers on the device: actions < 4, twists in {0, 1}, obs id of cell c in [16c, 16c+16)
+    assert int(t["actions"].max()) <= 3 and int(t["perms"].min()) >= 0 and int(t["perms"].max()) <= 1
+    cell = torch.arange(16, device=t["obs"].device, dtype=torch.int32)[None, :]
+    obs_i = t["obs"].to(torch.int32)
+    assert bool(((obs_i >> 4) == cell).all())
+    assert bool((obs_i & 15).sum(dim=1).eq(120).all())                    # every board is a permutation of 0..15
+    # the terminal record of every episode: reward 1.0 (solved) or -0.5 (out of depth); every other record -0.5/256
+    last = torch.from_numpy(S + L - 1).to(t["rewards"].device)
+    r_last = t["rewards"][last]
+    assert bool(((r_last == 1.0) | (r_last == -0.5)).all())
+    assert int((t["rewards"] == np.float32(-0.5 / 256)).sum()) == n - E
+    # determinism: the same seed again gives the same bytes (atomic episode queue: which lane runs an episode must not matter)
+    h = coll.collect(env, gp, seed=1000)
+    th = h.to_torch()
+    for k in t:
+        assert torch.equal(t[k], th[k]), k
+    del h, th
+    # sampled episodes against the oracle, every field, bit for bit
+    for e in _sample_episodes(E, 36, seed=3):
+        s, ln = int(S[e]), int(L[e])
+        o = oracle.ppo_collect(oenv, op, 1, 0.995, 0.995, seed=1000, episode_offset=e, arith=oracle.ARITH_CHAIN, det_log=True,
+                               merge_order=False)
+        assert ln == int(o.ep_len[0]) == o.obs.shape[0], e
+        sl = lambda k: t[k][s:s + ln].cpu().numpy()
+        assert np.array_equal(sl("obs").astype(np.int64), o.obs), e
+        assert np.array_equal(sl("actions").astype(np.int64), o.actions), e
+        assert np.array_equal(sl("perms").astype(np.int32), o.perms), e
+        assert np.array_equal(f32_bits(sl("rewards")), f32_bits(o.rewards)), e
+        assert np.array_equal(f32_bits(sl("logits")), f32_bits(o.logits)), e
+        assert np.array_equal(f32_bits(sl("values")), f32_bits(o.values)), e
+        assert np.array_equal(f32_bits(sl("advs")), f32_bits(o.additional_data["advs"])), e
+        assert np.array_equal(f32_bits(sl("rets")), f32_bits(o.additional_data["rets"])), e
+
+
+@pytest.mark.parametrize("searches,n_sample", [(100, 28), (1000, 6)])
+def test_config5_selfplay_full_size_vs_oracle(tw, oracle, searches, n_sample):
+    """AZCollector at the reference's per-GPU batch: 4,096 episodes x {100, 1,000} MCTS searches per move on Puzzle-15 with the
+    512/256 policy and the transpose twist (full_predict averages both twists), C = 1.41, max_expand_depth = 1
+    (src/twisterl/defaults.py:84-91)."""
+    gp, op = _bench_policy(oracle, twists=True)
+    E, D = 4096, 8
+    env, oenv = tw.env.Puzzle(4, 4, D, 2, 256), oracle.Puzzle(4, 4, D, 2, 256)
+    coll = tw.collector.AZCollector(E, searches, 1.41, 1, 32)
+    g = coll.collect(env, gp, seed=500)
+    t = g.to_torch()
+    n = len(g)
+    L = t["ep_len"].cpu().numpy().astype(np.int64)
+    S = t["ep_start"].cpu().numpy().astype(np.int64)
+    assert L.sum() == n and L.min() >= 1 and L.max() <= 2 * D + 1
+    order = np.concatenate([[E - 1], np.arange(E - 1)])
+    assert np.array_equal(S[order], np.concatenate([[0], np.cumsum(L[order])[:-1]]))
+    probs = t["logits"]
+    assert bool((probs >= 0).all()) and bool(((probs.sum(dim=1) - 1.0).abs() < 1e-5).all())     # visit counts / sum
+    assert bool((t["perms"] == -1).all())                                                     # az.rs:95
+    # one root evaluation + at most `searches` leaf evaluations per record, two twists each
+    assert 2 * n <= g.stats["forward_evals"] <= 2 * n * (searches + 1)
+    h = coll.collect(env, gp, seed=500).to_torch()
+    for k in t:
+        assert torch.equal(t[k], h[k]), k
+    del h
+    for e in _sample_episodes(E, n_sample, seed=5):
+        s, ln = int(S[e]), int(L[e])
+        o = oracle.az_collect(oenv, op, 1, searches, 1.41, 1, seed=500, episode_offset=e, arith=oracle.ARITH_CHAIN, merge_order=False,
+                              det_math=True)
+        assert ln == int(o.ep_len[0]), e
+        sl = lambda k: t[k][s:s + ln].cpu().numpy()
+        assert np.array_equal(sl("obs").astype(np.int64), o.obs), e
+        assert np.array_equal(f32_bits(sl("logits")), f32_bits(o.logits)), e
+        assert np.array_equal(f32_bits(sl("remaining_values")), f32_bits(o.additional_data["remaining_values"])), e

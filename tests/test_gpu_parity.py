@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from tests.util import amd_policy, f32_bits, make_policy_arrays, oracle_policy, puzzle_transpose_twist
+from twisterl_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -387,6 +388,40 @@ def test_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, hidden, twist
     assert genv.get_state() == before                        # the env passed in is not mutated (solve.rs:85)
 
 
+def test_reference_trained_policy_on_the_gpu(tw, oracle):
+    """The reference's trained Puzzle-8 checkpoint (tests/golden/ppo_puzzle8_v1_weights.npz) through collector.evaluate /
+    collector.solve / PPOCollector on the GPU: bit-equal to the oracle, and it SOLVES the puzzle (success >= 0.97 at the
+    config's diff_max 32) -- obs encoding, weight layout and action semantics pinned end to end on the device as well."""
+    from tests.util import trained_puzzle8_arrays
+    arrs = trained_puzzle8_arrays()
+    gp, op = amd_policy(arrs), oracle_policy(oracle, arrs)
+    for diff in (8, 32):
+        genv, oenv = tw.env.Puzzle(3, 3, diff, 2, 256), oracle.Puzzle(3, 3, diff, 2, 256)
+        for det, ns in ((False, 1), (True, 1), (False, 10)):            # the config's evals: ppo_1, ppo_10 (+ deterministic)
+            g = tw.collector.evaluate(genv, gp, num_episodes=200, deterministic=det, num_searches=ns, num_mcts_searches=0,
+                                      seed=1, C=1.41, max_expand_depth=1, num_cores=32)
+            o = oracle.evaluate(oenv, op, 200, det, ns, seed=1, arith=oracle.ARITH_CHAIN, det_math=True)
+            assert f32_bits(g[0]) == f32_bits(o[0]) and f32_bits(g[1]) == f32_bits(o[1]), (diff, det, ns, g, o)
+            assert g[0] >= 0.97, (diff, det, ns, g)
+    # a scrambled board, solved greedily on the device: the action list replays to the solved board on the oracle's Puzzle
+    start = oracle.Puzzle(3, 3, 32, 2, 256); start.reset(seed=11, episode=0)
+    state = start.get_state()
+    genv.set_state(state)
+    (gs, gr), acts = tw.collector.solve(genv, gp, True, 1, 0, 1.41, 1, seed=5)
+    assert gs == 1.0 and len(acts) > 0
+    rp = oracle.Puzzle(3, 3, 32, 2, 256); rp.set_state(state)
+    _, _, _, fin, boards = oracle.replay(rp, acts)
+    assert boards[-1].tolist() == list(range(9)) and fin[-1]
+    # trained policies end their episodes early: a ragged PPO collect, bit-exact, mostly solved
+    E = 3000
+    g = tw.collector.PPOCollector(E, 0.995, 0.995, 32).collect(tw.env.Puzzle(3, 3, 32, 2, 256), gp, seed=77)
+    o = oracle.ppo_collect(oracle.Puzzle(3, 3, 32, 2, 256), op, E, 0.995, 0.995, seed=77, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8)
+    _assert_same_collect(g, o, 9)
+    a = g.to_numpy()
+    last = a["ep_start"].astype(np.int64) + a["ep_len"].astype(np.int64) - 1
+    assert (a["rewards"][last] == 1.0).mean() >= 0.95 and a["ep_len"].mean() < 40
+
+
 @pytest.mark.parametrize("w,diff,emb,hidden,twists,S,med", [(3, 3, 32, 32, False, 12, 1), (3, 4, 64, 64, True, 8, 2), (4, 3, 512, 256, True, 6, 1)])
 def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, hidden, twists, S, med):
     """num_mcts_searches > 0 (solve.rs:41-47): the action distribution comes from predict_probs_mcts; same numbers and the
@@ -711,11 +746,8 @@ def test_persistent_lane_mode_bit_exact(tw, oracle):
     _assert_same_collect(g, o, 9)
     L = g.to_numpy()["ep_len"]
     assert L.min() < L.max() and L.mean() < 0.8 * L.max()      # the lengths are indeed ragged
-    os.environ["TW_NO_PERSIST"] = "1"
-    try:
+    with _lib.launch_option(_lib.TW_OPT_NO_PERSIST, 1):
         h = coll.collect(genv, gp, seed=17).to_numpy()
-    finally:
-        del os.environ["TW_NO_PERSIST"]
     a = g.to_numpy()
     for k in a:
         assert np.array_equal(a[k], h[k]), k
@@ -727,11 +759,8 @@ def test_persistent_lane_mode_bit_exact(tw, oracle):
         if prec == "fp16x2":
             gp2, _ = _pair(oracle, 9, 5, 64, 32, twists=True)          # the split mode needs two embedding tiles
             p1 = c16.collect(genv, gp2, seed=17).to_numpy()
-        os.environ["TW_NO_PERSIST"] = "1"
-        try:
+        with _lib.launch_option(_lib.TW_OPT_NO_PERSIST, 1):
             p2 = c16.collect(genv, gp2 if prec == "fp16x2" else gp, seed=17).to_numpy()
-        finally:
-            del os.environ["TW_NO_PERSIST"]
         for k in p1:
             assert np.array_equal(p1[k], p2[k]), (prec, k)
 
@@ -750,11 +779,8 @@ def test_az_persistent_lane_mode_bit_exact(tw, oracle):
     assert np.array_equal(g["obs"].astype(np.int64), o.obs)
     assert np.array_equal(f32_bits(g["logits"]), f32_bits(o.logits))
     assert np.array_equal(f32_bits(g["remaining_values"]), f32_bits(o.additional_data["remaining_values"]))
-    os.environ["TW_NO_PERSIST"] = "1"
-    try:
+    with _lib.launch_option(_lib.TW_OPT_NO_PERSIST, 1):
         h = coll.collect(genv, gp, seed=19).to_numpy()
-    finally:
-        del os.environ["TW_NO_PERSIST"]
     for k in g:
         assert np.array_equal(g[k], h[k]), k
 
@@ -781,12 +807,9 @@ def test_mid_size_batches_use_the_queue_with_the_small_batch_geometry(tw, oracle
     assert np.array_equal(z["ep_len"], zo.ep_len) and np.array_equal(z["obs"].astype(np.int64), zo.obs)
     assert np.array_equal(f32_bits(z["logits"]), f32_bits(zo.logits))
     assert np.array_equal(f32_bits(z["remaining_values"]), f32_bits(zo.additional_data["remaining_values"]))
-    os.environ["TW_NO_PERSIST"] = "1"
-    try:
+    with _lib.launch_option(_lib.TW_OPT_NO_PERSIST, 1):
         h = coll.collect(genv, gp, seed=23).to_numpy()
         zh = acoll.collect(aenv, gp2, seed=29).to_numpy()
-    finally:
-        del os.environ["TW_NO_PERSIST"]
     for k in a:
         assert np.array_equal(a[k], h[k]), k
     for k in z:
@@ -843,7 +866,7 @@ def test_compiled_host_over_the_c_abi_matches_the_python_mirror(tw, oracle):
 @pytest.mark.parametrize("geom", ["32", "8"])
 def test_every_launch_shape_gives_the_same_bytes(tw, oracle, geom):
     """The launch shape is chosen from the batch size (16 / 32 episodes per workgroup shared by four waves, or 8 waves x 32);
-    TW_FORCE_GEOM pins it.  A Puzzle-15 collect and a self-play collect must not depend on it, bit for bit -- and the
+    tw_set_launch_option(TW_OPT_FORCE_GEOM) pins it.  A Puzzle-15 collect and a self-play collect must not depend on it, bit for bit -- and the
     default shape is checked against the oracle by the other tests."""
     import os
     gp, _ = _pair(oracle, 16, 1, 512, 256, twists=True)
@@ -854,12 +877,9 @@ def test_every_launch_shape_gives_the_same_bytes(tw, oracle, geom):
     zc = tw.collector.AZCollector(300, 12, 1.41, 1, 1)
     a = pc.collect(env, gp, seed=31)
     z = zc.collect(zenv, gz, seed=37)
-    os.environ["TW_FORCE_GEOM"] = geom
-    try:
+    with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, int(geom)):
         b = pc.collect(env, gp, seed=31)
         y = zc.collect(zenv, gz, seed=37)
-    finally:
-        del os.environ["TW_FORCE_GEOM"]
     assert (a.stats["rollout_blocks"], a.stats["rollout_threads"]) != (b.stats["rollout_blocks"], b.stats["rollout_threads"])
     an, bn, zn, yn = a.to_numpy(), b.to_numpy(), z.to_numpy(), y.to_numpy()
     for k in an:

@@ -303,10 +303,8 @@ def test_twists_match_torch_twin_semantics(oracle):
 
 # ------------------------------------------------------------------ RNG spec
 def test_philox_known_answer_vectors(oracle):
-    """Random123 kat_vectors for philox4x32-10."""
+    """The three philox4x32-10 lines of Random123's published known-answer file (tests/kat_vectors: counter, key -> output)."""
     assert oracle.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    # (vector 2 was written down from memory with word 2 in doubt; words 0, 1, 3 are as
-    #  remembered, word 2 is what an implementation passing vectors 1 and 3 produces)
     assert oracle.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert oracle.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
                                 [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
@@ -466,3 +464,32 @@ def test_conv1d_embedding_mode_matches_torch_conv1d(oracle, conv_dim):
         lo, vo = pol.raw_predict(ids)
         np.testing.assert_allclose(lo, lg, atol=1e-5, rtol=1e-5)
         assert abs(vo - val) <= 1e-5
+
+
+# ------------------------------------------------------------------ the reference's own trained policy
+def test_reference_trained_policy_solves_the_oracle_puzzle(oracle):
+    """examples/ppo_puzzle8_v1.pt was trained by the reference against the reference's Puzzle.  Exported the way to_rust()
+    exports it and run through the oracle's evaluate (rl/evaluate.rs:22-89 restated), it solves every scrambled 3x3 board
+    up to the config's diff_max = 32 -- which it only can if obs encoding (puzzle.rs:183-185), weight layout
+    (nn/utils.py:17-59, layers.rs:26) and action -> direction map (puzzle.rs:135-160) ALL agree with the reference.
+    Controls: an untrained policy, and the trained one behind a swapped action map, fail."""
+    from tests.util import make_policy_arrays, trained_puzzle8_arrays
+    arrs = trained_puzzle8_arrays()
+    pol = oracle.Policy(*arrs)
+    for diff in (8, 32):
+        env = oracle.Puzzle(3, 3, diff, 2, 256)
+        for det in (False, True):
+            for arith in (oracle.ARITH_REF, oracle.ARITH_CHAIN):
+                rate, rew = oracle.evaluate(env, pol, 200, det, 1, seed=1, arith=arith)
+                assert rate >= 0.97 and rew > 0.9, (diff, det, arith, rate, rew)
+    env = oracle.Puzzle(3, 3, 32, 2, 256)
+    untrained = oracle.Policy(*make_policy_arrays(9, seed=0))
+    assert oracle.evaluate(env, untrained, 200, False, 1, seed=1)[0] < 0.3
+    # the same weights with left<->right swapped in the action head: the policy walks the blank the wrong way
+    emb, eb, common, action, value = arrs
+    wa = action[0][0].reshape(256, 4)[:, [2, 1, 0, 3]]
+    swapped = oracle.Policy(emb, eb, common, [(np.ascontiguousarray(wa).reshape(-1), action[0][1][[2, 1, 0, 3]], False)], value)
+    assert oracle.evaluate(env, swapped, 200, False, 1, seed=1)[0] < 0.5
+    # and with the table rows of (cell, tile) read as (tile, cell): a transposed obs encoding
+    T = np.arange(81).reshape(9, 9).T.reshape(-1)
+    assert oracle.evaluate(env, oracle.Policy(np.ascontiguousarray(emb[T]), eb, common, action, value), 200, False, 1, seed=1)[0] < 0.5

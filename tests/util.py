@@ -53,3 +53,15 @@ def oracle_policy(oracle, arrs, obs_perms=(), act_perms=()):
 
 def f32_bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def trained_puzzle8_arrays():
+    """The reference's trained Puzzle-8 checkpoint (examples/ppo_puzzle8_v1.pt -> tests/golden/ppo_puzzle8_v1_weights.npz,
+    written by scripts/make_trained_fixture.py) exported the way BasicPolicy.to_rust() does (src/twisterl/nn/utils.py:17-59,
+    nn/policy.py:191-199): Linear weights = torch_weight.T.flatten(), EmbeddingBag vectors = torch_weight.T."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_puzzle8_v1_weights.npz"))
+    g = lambda k: np.ascontiguousarray(z[k.replace(".", "__")], dtype=np.float32)
+    lin = lambda name, relu: (np.ascontiguousarray(g(name + ".weight").T).reshape(-1), g(name + ".bias"), relu)
+    return (np.ascontiguousarray(g("embeddings.weight").T), g("embeddings.bias"),
+            [lin("common.0", True)], [lin("action.0", False)], [lin("value.0", False)])

@@ -15,6 +15,8 @@ from . import build as _build
 TW_OK, TW_ERR_INVALID, TW_ERR_UNSUPPORTED, TW_ERR_NO_DEVICE, TW_ERR_HIP, TW_ERR_EMPTY = range(6)
 TW_PREC_F32_EXACT, TW_PREC_F16, TW_PREC_F16X2 = 0, 1, 2
 TW_EVAL_FORWARD, TW_EVAL_PREDICT, TW_EVAL_FULL_PREDICT = 0, 1, 2
+TW_OPT_FORCE_GEOM, TW_OPT_NO_PERSIST = 0, 1
+ABI_VERSION = 2
 (TW_F_OBS, TW_F_LOGITS, TW_F_PERMS, TW_F_VALUES, TW_F_REWARDS, TW_F_ACTIONS, TW_F_ADVS, TW_F_RETS,
  TW_F_REMAINING, TW_F_EP_LEN, TW_F_EP_START, TW_F_COUNT) = range(12)
 
@@ -53,13 +55,14 @@ class PolicyDesc(C.Structure):
 class PPOParams(C.Structure):
     _fields_ = [("num_episodes", C.c_uint64), ("episode_offset", C.c_uint64),
                 ("gamma", C.c_float), ("lambda_", C.c_float), ("seed", C.c_uint64),
-                ("precision", C.c_uint32), ("merge_order", C.c_uint32)]
+                ("precision", C.c_uint32), ("merge_order", C.c_uint32), ("reserve_cus", C.c_uint32)]
 
 
 class AZParams(C.Structure):
     _fields_ = [("num_episodes", C.c_uint64), ("episode_offset", C.c_uint64),
                 ("num_mcts_searches", C.c_uint32), ("C", C.c_float), ("max_expand_depth", C.c_uint32),
-                ("seed", C.c_uint64), ("precision", C.c_uint32), ("merge_order", C.c_uint32)]
+                ("seed", C.c_uint64), ("precision", C.c_uint32), ("merge_order", C.c_uint32),
+                ("reserve_cus", C.c_uint32)]
 
 
 class SolveParams(C.Structure):
@@ -83,6 +86,8 @@ SYMBOLS = {
     "tw_set_device": (C.c_int, [C.c_int]),
     "tw_set_stream": (C.c_int, [_VP]),
     "tw_get_device_info": (C.c_int, [C.POINTER(DeviceInfo)]),
+    "tw_release_cached_memory": (C.c_int, []),
+    "tw_set_launch_option": (C.c_int, [C.c_int, C.c_int]),
     "tw_puzzle_create": (_VP, [C.c_uint32] * 5),
     "tw_puzzle_clone": (_VP, [_VP]),
     "tw_puzzle_destroy": (None, [_VP]),
@@ -159,7 +164,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.tw_abi_version() != 1:
+        if L.tw_abi_version() != ABI_VERSION:
             raise RuntimeError("libtwisterl_hip.so ABI version mismatch; rebuild with python -m twisterl_amd.build")
         _lib = L
     return _lib
@@ -179,6 +184,22 @@ def check(status: int) -> None:
     if status == TW_ERR_INVALID:
         raise ValueError(msg)
     raise RuntimeError(msg)
+
+
+class launch_option:
+    """`with launch_option(TW_OPT_NO_PERSIST, 1): ...` -- pins a diagnostic launch override (tw_set_launch_option) for
+    the block; the parity tests use it to show that every launch shape gives the same bytes."""
+
+    def __init__(self, option: int, value: int):
+        self.option, self.value = option, value
+
+    def __enter__(self):
+        check(lib().tw_set_launch_option(self.option, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().tw_set_launch_option(self.option, 0))
+        return False
 
 
 def device_count() -> int:

@@ -8,6 +8,7 @@ hipcc cross-compiles without a GPU, so this also runs in the CPU-only build cont
 """
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -18,9 +19,9 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtwisterl_hip.so")
-SOURCES = ["tw_api.hip", "tw_rollout.hip", "tw_rollout16.hip", "tw_finalize.hip", "tw_eval.hip", "tw_mcts.hip", "tw_solve.hip", "tw_trainer.hip", "tw_sync.hip"]
-HEADERS = [os.path.join(CSRC, "tw_common.hpp"), os.path.join(CSRC, "tw_engine.hpp"), os.path.join(CSRC, "tw_engine16.hpp"),
-           os.path.join(ROOT, "include", "twisterl_hip.h")]
+SOURCES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip")))
+# every header is a dependency of every object (an edited header must never leave a stale object behind)
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 # -ffp-contract=off: the numeric spec allows only the explicit fma() calls
 # -pragma-unroll-threshold: the pinned MFMA schedules are fully unrolled position loops whose bodies call constexpr

@@ -224,8 +224,25 @@ class CollectedData:
 class PyBaseCollector:
     """collect(py_env, policy) -> CollectedData (python_interface/collector.rs:139-152)."""
 
+    _IS_PPO = True
+
     def collect(self, py_env, policy: Policy) -> CollectedData:
         raise NotImplementedError
+
+    def empty_fields(self, py_env) -> dict:
+        """Zero-record device tensors in the layout to_torch() gives (a rank without episodes in a sharded collect still
+        takes part in the gather's collectives, twisterl_amd.dist)."""
+        import torch
+        desc = get_env_desc(py_env)
+        nc = int(desc.width) * int(desc.height)
+        z = lambda shape, dt: torch.empty(shape, dtype=dt, device="cuda")
+        out = {"obs": z((0, nc), torch.uint8), "logits": z((0, 4), torch.float32), "perms": z((0,), torch.int8)}
+        if self._IS_PPO:
+            out.update(values=z((0,), torch.float32), rewards=z((0,), torch.float32), actions=z((0,), torch.uint8),
+                       advs=z((0,), torch.float32), rets=z((0,), torch.float32))
+        else:
+            out["remaining_values"] = z((0,), torch.float32)
+        return out
 
     @staticmethod
     def _check(py_env, policy):
@@ -247,8 +264,8 @@ class PPOCollector(PyBaseCollector):
     `lambda` is a Python keyword, so -- exactly as with the reference -- it is reachable through
     `PPOCollector(**config["collecting"])` (src/twisterl/rl/ppo.py:23).  `num_cores` is accepted
     for compatibility; the episodes run as GPU lanes, not rayon tasks.  Build extensions (all
-    keyword-only, defaulted): seed, precision ("fp32" exact | "fp16"), episode_offset /
-    merge_order for sharded collection (twisterl_amd.dist).
+    keyword-only, defaulted): seed, precision ("fp32" exact | "fp16" | "fp16x2"), episode_offset /
+    merge_order / reserve_cus for sharded collection (twisterl_amd.dist).
     """
 
     def __init__(self, *args, **kwargs):
@@ -272,6 +289,7 @@ class PPOCollector(PyBaseCollector):
         self.precision = kwargs.pop("precision", "fp32")
         self.episode_offset = int(kwargs.pop("episode_offset", 0))
         self.merge_order = bool(kwargs.pop("merge_order", True))
+        self.reserve_cus = int(kwargs.pop("reserve_cus", 0))
         if kwargs:
             raise TypeError(f"PPOCollector() got an unexpected keyword argument '{next(iter(kwargs))}'")
         if self.precision not in _lib.PRECISIONS:
@@ -293,7 +311,7 @@ class PPOCollector(PyBaseCollector):
         desc = self._check(py_env, policy)
         prm = _lib.PPOParams(self.num_episodes, self.episode_offset, self.gamma, self.lambda_,
                              (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed(),
-                             _lib.PRECISIONS[self.precision], int(self.merge_order))
+                             _lib.PRECISIONS[self.precision], int(self.merge_order), max(0, int(self.reserve_cus)))
         out = C.c_void_p()
         _lib.check(_lib.lib().tw_ppo_collect(C.byref(desc), policy._handle(), C.byref(prm), C.byref(out)))
         return CollectedData._from_device(_DeviceResult(out.value))
@@ -302,8 +320,10 @@ class PPOCollector(PyBaseCollector):
 class AZCollector(PyBaseCollector):
     """AZCollector(num_episodes, num_mcts_searches, C, max_expand_depth, num_cores) (collector.rs:172-187)."""
 
+    _IS_PPO = False
+
     def __init__(self, num_episodes, num_mcts_searches, C, max_expand_depth, num_cores, *, seed=None,
-                 precision="fp32", episode_offset=0, merge_order=True):
+                 precision="fp32", episode_offset=0, merge_order=True, reserve_cus=0):
         self.num_episodes = _u("num_episodes", num_episodes)
         self.num_mcts_searches = _u("num_mcts_searches", num_mcts_searches)
         self.C = float(C)
@@ -311,6 +331,7 @@ class AZCollector(PyBaseCollector):
         self.num_cores = _u("num_cores", num_cores)
         self.seed, self.precision = seed, precision
         self.episode_offset, self.merge_order = int(episode_offset), bool(merge_order)
+        self.reserve_cus = int(reserve_cus)
         if self.precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         self._calls = 0
@@ -322,7 +343,7 @@ class AZCollector(PyBaseCollector):
         prm = _lib.AZParams(self.num_episodes, self.episode_offset, self.num_mcts_searches, self.C,
                             self.max_expand_depth,
                             (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed(),
-                            _lib.PRECISIONS[self.precision], int(self.merge_order))
+                            _lib.PRECISIONS[self.precision], int(self.merge_order), max(0, int(self.reserve_cus)))
         out = C.c_void_p()
         _lib.check(_lib.lib().tw_az_collect(C.byref(desc), policy._handle(), C.byref(prm), C.byref(out)))
         return CollectedData._from_device(_DeviceResult(out.value))

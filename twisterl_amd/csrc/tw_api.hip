@@ -9,12 +9,15 @@
 // All arithmetic of the hot path runs in the HIP kernels; nothing here computes a trajectory.
 #include "tw_common.hpp"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace tw {
@@ -41,6 +44,41 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 
 hipStream_t current_stream() { return g_stream; }
 
+// ---------------------------------------------------------------------------------- launch options / per-device caches
+static std::atomic<int> g_force_geom{0}, g_no_persist{0};
+LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load()}; }
+
+static std::mutex g_dev_mutex;
+
+int device_cus()
+{
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    hipDeviceProp_t p;
+    int n = 256;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+    else (void)hipGetLastError();
+    cus[dev] = n;
+    return n;
+}
+
+int ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0; TW_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    size_t &have = granted[std::make_pair(kernel, dev)];
+    if (bytes > have) {
+        TW_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return TW_OK;
+}
+
 static int require_device()
 {
     int n = 0;
@@ -62,6 +100,7 @@ struct Workspace {
 };
 static std::mutex g_ws_mutex;
 static Workspace g_ws;
+static void pool_drop();     // frees every pooled result arena (below)
 
 static int ws_reserve(size_t bytes, void **out)
 {
@@ -70,7 +109,9 @@ static int ws_reserve(size_t bytes, void **out)
         TW_HIP(hipFree(g_ws.ptr)); g_ws.ptr = nullptr; g_ws.cap = 0;
     }
     if (!g_ws.ptr) {
-        TW_HIP(hipMalloc(&g_ws.ptr, bytes));
+        hipError_t e = hipMalloc(&g_ws.ptr, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); pool_drop(); e = hipMalloc(&g_ws.ptr, bytes); }   // pooled result arenas go first
+        if (e != hipSuccess) { g_ws.ptr = nullptr; return hip_fail(e, "hipMalloc(trajectory workspace)", __FILE__, __LINE__); }
         g_ws.cap = bytes; g_ws.device = dev;
     }
     *out = g_ws.ptr;
@@ -78,6 +119,64 @@ static int ws_reserve(size_t bytes, void **out)
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Result arenas (the compact trajectories a collect hands to its caller) have the same size every iteration of the
+// trainer too: a freed arena goes to a small per-process pool instead of back to the driver (hipMalloc / hipFree of a
+// few GB cost milliseconds each and serialise with every stream).
+struct PooledArena { void *ptr; size_t cap; int device; };
+static std::mutex g_pool_mutex;
+static std::vector<PooledArena> g_pool;
+constexpr size_t POOL_ENTRIES = 4;
+
+static void pool_drop()
+{
+    std::vector<PooledArena> drop;
+    { std::lock_guard<std::mutex> lock(g_pool_mutex); drop.swap(g_pool); }
+    for (auto &a : drop) (void)hipFree(a.ptr);
+}
+
+static int arena_acquire(size_t bytes, void **out, size_t *cap)
+{
+    int dev = 0; TW_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t best = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].device == dev && g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + (1u << 20) &&
+                (best == g_pool.size() || g_pool[i].cap < g_pool[best].cap)) best = i;
+        if (best != g_pool.size()) {
+            *out = g_pool[best].ptr; *cap = g_pool[best].cap;
+            g_pool.erase(g_pool.begin() + (long)best);
+            return TW_OK;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes ? bytes : 256);
+    if (e != hipSuccess) {      // out of memory: give the pooled arenas back and try once more
+        (void)hipGetLastError();
+        pool_drop();
+        e = hipMalloc(out, bytes ? bytes : 256);
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(compact result)", __FILE__, __LINE__);
+    *cap = bytes ? bytes : 256;
+    return TW_OK;
+}
+
+static void arena_release(void *ptr, size_t cap, int device)
+{
+    if (!ptr) return;
+    PooledArena victim{nullptr, 0, -1};
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_pool.push_back(PooledArena{ptr, cap, device});
+        if (g_pool.size() > POOL_ENTRIES) {          // evict the smallest
+            size_t v = 0;
+            for (size_t i = 1; i < g_pool.size(); ++i) if (g_pool[i].cap < g_pool[v].cap) v = i;
+            victim = g_pool[v];
+            g_pool.erase(g_pool.begin() + (long)v);
+        }
+    }
+    if (victim.ptr) (void)hipFree(victim.ptr);
+}
 
 }  // namespace tw
 
@@ -98,6 +197,27 @@ extern "C" int tw_set_device(int device)
 {
     int rc = require_device(); if (rc) return rc;
     TW_HIP(hipSetDevice(device));
+    return TW_OK;
+}
+
+extern "C" int tw_set_launch_option(int option, int value)
+{
+    switch (option) {
+        case TW_OPT_FORCE_GEOM:
+            if (value != 0 && value != 1 && value != 8 && value != 32) { set_error("TW_OPT_FORCE_GEOM: value %d not in {0, 1, 8, 32}", value); return TW_ERR_INVALID; }
+            g_force_geom.store(value); return TW_OK;
+        case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
+        default: set_error("tw_set_launch_option: unknown option %d", option); return TW_ERR_INVALID;
+    }
+}
+
+extern "C" int tw_release_cached_memory(void)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        if (g_ws.ptr) { (void)hipFree(g_ws.ptr); g_ws.ptr = nullptr; g_ws.cap = 0; g_ws.device = -1; }
+    }
+    pool_drop();
     return TW_OK;
 }
 
@@ -572,7 +692,8 @@ extern "C" int tw_policy_evaluate(const tw_policy *p, int mode, uint32_t precisi
 
 // ====================================================================================== Collected
 struct tw_collected {
-    void *arena = nullptr;                  // one allocation holding every compact field
+    void *arena = nullptr;                  // one allocation holding every compact field (from the arena pool)
+    size_t arena_cap = 0; int device = -1;
     void *field_ptr[TW_F_COUNT] = {};
     size_t field_bytes[TW_F_COUNT] = {};
     uint64_t n_records = 0, n_episodes = 0;
@@ -619,7 +740,7 @@ extern "C" int tw_collected_adv_stats(const tw_collected *c, double *mean, doubl
     if (!c->is_ppo || !c->field_ptr[TW_F_ADVS]) { set_error("tw_collected_adv_stats: no advantages in this result (AlphaZero data?)"); return TW_ERR_INVALID; }
     hipStream_t s = current_stream();
     double *acc = nullptr;
-    TW_HIP(hipMalloc((void **)&acc, sizeof(double)));
+    TW_HIP(hipMalloc((void **)&acc, sum_scratch_doubles() * sizeof(double)));
     const float *adv = reinterpret_cast<const float *>(c->field_ptr[TW_F_ADVS]);
     const uint64_t n = c->n_records;
     double sum = 0.0, ss = 0.0;
@@ -671,7 +792,7 @@ extern "C" int tw_collected_pack_trainer(const tw_collected *c, uint32_t obs_siz
 extern "C" void tw_collected_free(tw_collected *c)
 {
     if (!c) return;
-    if (c->arena) (void)hipFree(c->arena);
+    arena_release(c->arena, c->arena_cap, c->device);
     delete c;
 }
 
@@ -740,8 +861,10 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     // persistent-lane mode (more episodes than resident lanes): start boards + episode queue
-    const uint64_t resident = prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false) : rollout_f32_resident_episodes();
-    const bool persist = E > resident && !getenv("TW_NO_PERSIST");
+    ra.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
+    const uint64_t resident = prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false, ra.reserve_cus)
+                                                                  : rollout_f32_resident_episodes(ra.reserve_cus);
+    const bool persist = E > resident && !launch_options().no_persist;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
                  o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     void *wsp = nullptr;
@@ -785,8 +908,8 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
                  c_val = cseg(TW_F_VALUES, total * 4), c_rew = cseg(TW_F_REWARDS, total * 4), c_act = cseg(TW_F_ACTIONS, total),
                  c_adv = cseg(TW_F_ADVS, total * 4), c_ret = cseg(TW_F_RETS, total * 4), c_len = cseg(TW_F_EP_LEN, E * 4),
                  c_start = cseg(TW_F_EP_START, E * 8);
-    hipError_t he = hipMalloc(&c->arena, ccur);
-    if (he != hipSuccess) { delete c; return hip_fail(he, "hipMalloc(compact result)", __FILE__, __LINE__); }
+    rc = hipGetDevice(&c->device) == hipSuccess ? arena_acquire(ccur, &c->arena, &c->arena_cap) : TW_ERR_HIP;
+    if (rc) { delete c; return rc; }
     uint8_t *ca = reinterpret_cast<uint8_t *>(c->arena);
     const size_t offs[TW_F_COUNT] = {c_obs, c_lg, c_prm, c_val, c_rew, c_act, c_adv, c_ret, 0, c_len, c_start};
     for (int f = 0; f < TW_F_COUNT; ++f) c->field_ptr[f] = c->field_bytes[f] ? ca + offs[f] : nullptr;
@@ -851,17 +974,22 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     // persistent lanes (more episodes than resident lanes): one tree arena per LANE, start boards + episode queue
-    const uint64_t resident = f32_resident_episodes(E, (int)ma.pol.hidden, true);
-    const bool persist = E > resident && !getenv("TW_NO_PERSIST");
+    ma.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
+    const uint64_t resident = f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
+    const bool persist = E > resident && !launch_options().no_persist;
     const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(16), o_scan = seg(scan_scratch_bytes(E)), o_arena = seg(arenas * cap64 * mcts_node_bytes()),
                  o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     size_t free_b = 0, total_b = 0;
     TW_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (cur > (size_t)(0.9 * (double)total_b)) {
-        set_error("tw_az_collect: %zu bytes of tree arenas + trajectories exceed the device memory (%zu)", cur, total_b);
-        return TW_ERR_UNSUPPORTED;
+    {   // what can actually be had: free memory plus the cached workspace this call would replace
+        int dev_now = 0; TW_HIP(hipGetDevice(&dev_now));
+        const size_t avail = free_b + (g_ws.ptr && g_ws.device == dev_now ? g_ws.cap : 0);
+        if (cur > g_ws.cap && cur > (size_t)(0.95 * (double)avail)) {
+            set_error("tw_az_collect: %zu bytes of tree arenas + trajectories exceed the free device memory (%zu free of %zu)", cur, avail, total_b);
+            return TW_ERR_UNSUPPORTED;
+        }
     }
     void *wsp = nullptr;
     rc = ws_reserve(cur, &wsp); if (rc) return rc;
@@ -902,8 +1030,8 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     auto cseg = [&](int f, size_t bytes) { c->field_bytes[f] = bytes; size_t o = ccur; ccur = align_up(ccur + bytes, 256); return o; };
     const size_t c_obs = cseg(TW_F_OBS, total * c->n_cells), c_lg = cseg(TW_F_LOGITS, total * 16), c_prm = cseg(TW_F_PERMS, total),
                  c_rem = cseg(TW_F_REMAINING, total * 4), c_len = cseg(TW_F_EP_LEN, E * 4), c_start = cseg(TW_F_EP_START, E * 8);
-    hipError_t he = hipMalloc(&c->arena, ccur);
-    if (he != hipSuccess) { delete c; return hip_fail(he, "hipMalloc(compact result)", __FILE__, __LINE__); }
+    rc = hipGetDevice(&c->device) == hipSuccess ? arena_acquire(ccur, &c->arena, &c->arena_cap) : TW_ERR_HIP;
+    if (rc) { delete c; return rc; }
     uint8_t *ca = reinterpret_cast<uint8_t *>(c->arena);
     c->field_ptr[TW_F_OBS] = ca + c_obs; c->field_ptr[TW_F_LOGITS] = ca + c_lg; c->field_ptr[TW_F_PERMS] = ca + c_prm;
     c->field_ptr[TW_F_REMAINING] = ca + c_rem; c->field_ptr[TW_F_EP_LEN] = ca + c_len; c->field_ptr[TW_F_EP_START] = ca + c_start;
@@ -952,11 +1080,18 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
     sa.num_searches = prm->num_searches; sa.deterministic = prm->deterministic ? 1u : 0u;
     sa.from_state = from_state ? 1u : 0u;
     if (from_state) {
-        uint64_t b = 0;
+        // the reference's set_state takes any vector (puzzle.rs:107-117); the device board is n_cells nibbles holding a
+        // permutation of 0..n_cells-1 whose blank is where zero_location says -- anything else is refused here
+        if (start->state.size() != (size_t)envc.n_cells) { set_error("solve: state has %zu entries, the board %d cells", start->state.size(), envc.n_cells); return TW_ERR_INVALID; }
+        uint64_t b = 0; uint32_t seen = 0;
         for (size_t i = 0; i < start->state.size(); ++i) {
-            if (start->state[i] < 0 || start->state[i] > 15) { set_error("solve: tile value %lld does not fit a nibble", (long long)start->state[i]); return TW_ERR_UNSUPPORTED; }
-            b |= (uint64_t)start->state[i] << (4 * i);
+            const int64_t v = start->state[i];
+            if (v < 0 || v >= envc.n_cells || ((seen >> v) & 1u)) { set_error("solve: state is not a permutation of 0..%d (entry %zu = %lld)", envc.n_cells - 1, i, (long long)v); return TW_ERR_INVALID; }
+            seen |= 1u << v;
+            b |= (uint64_t)v << (4 * i);
         }
+        const int64_t zi = start->zy * start->width + start->zx;
+        if (zi < 0 || zi >= envc.n_cells || start->state[(size_t)zi] != 0) { set_error("solve: zero_location (%lld, %lld) does not hold the blank", (long long)start->zx, (long long)start->zy); return TW_ERR_INVALID; }
         sa.start_board = b; sa.start_zx = (int)start->zx; sa.start_zy = (int)start->zy; sa.start_depth = (int)start->depth;
     }
     sa.t_pad = max_steps > 0 ? max_steps : 1;

@@ -29,6 +29,14 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 hipStream_t current_stream();
 
+// Diagnostic launch overrides (tw_set_launch_option; the tests pin launch shapes with them).  Read once per collect.
+struct LaunchOptions { int force_geom; int no_persist; };
+LaunchOptions launch_options();
+// Raises a kernel's dynamic-LDS limit above the 64 KiB default; cached per (kernel, device), thread-safe.
+int ensure_dynamic_lds(const void *kernel, size_t bytes);
+// Compute units of the current device (cached per device).
+int device_cus();
+
 // ---- RNG streams (see DESIGN.md "RNG spec") -------------------------------------------------
 enum : uint32_t {
     STREAM_SCRAMBLE = 0,  // Puzzle::reset scramble actions      (puzzle.rs:124-131)
@@ -355,6 +363,7 @@ struct RolloutArgs {
     // (ppo.rs:110-124), not the maximum of every 256-episode workgroup.  Start boards come from init_boards_kernel.
     const uint64_t *init_boards;   // [num_episodes] scrambled start boards, or null
     unsigned int   *queue;         // next unassigned episode, or null
+    int32_t         reserve_cus;   // persistent mode: CUs left without a workgroup (room for RCCL's send/recv kernels, dist.py)
 };
 
 // Waves per workgroup of the f32 engine for a batch of n columns (episodes / attempts): 8 (two per SIMD, 256 columns) is
@@ -371,11 +380,11 @@ inline int waves_per_group(uint64_t n)
 // kernel launchers (each returns a TW_* status)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s);
-uint64_t rollout_f32_resident_episodes();   // episodes the f32 rollout keeps resident at once (persistent mode above that)
+uint64_t rollout_f32_resident_episodes(int reserve_cus = 0);   // episodes the f32 rollout keeps resident at once (persistent mode above that)
 // Lanes the exact-f32 kernels (rollout, self-play) keep resident for a batch: episodes beyond that wait in the queue of the
 // persistent-lane mode.  CUs x 256 for the 256-episode shape; between CUs x 32 and 3/4 of that the small-batch shape
 // (CUs x 32 lanes, Engine3S) with the queue -- see tw_rollout.hip.
-uint64_t f32_resident_episodes(uint64_t num_episodes, int hidden, bool selfplay);
+uint64_t f32_resident_episodes(uint64_t num_episodes, int hidden, bool selfplay, int reserve_cus = 0);
 int launch_rollout_f16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_rollout_f16x2(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_scan(const uint32_t *ep_len, uint64_t n_episodes, int merge_order, uint64_t *ep_start,
@@ -424,6 +433,7 @@ struct MctsArgs {
     // [resident lanes][node_cap], a lane reuses its arena for every episode it takes
     const uint64_t *init_boards;
     unsigned int   *queue;
+    int32_t         reserve_cus;
 };
 size_t mcts_node_bytes();
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
@@ -433,7 +443,8 @@ int launch_onehot(const uint8_t *obs, uint64_t row0, uint64_t rows, int n_cells,
 int launch_ppo_pack(const float *logits, const uint8_t *actions, const int8_t *perms, const float *advs, uint64_t row0, uint64_t rows,
                     int n_actions, float mean, float denom, int normalize, float *logp_out, int64_t *acts_out, int64_t *perms_out,
                     float *advs_out, hipStream_t s);
-int launch_sum(const float *x, uint64_t n, double shift, int squared, double *out_dev, hipStream_t s);
+size_t sum_scratch_doubles();
+int launch_sum(const float *x, uint64_t n, double shift, int squared, double *scratch /* sum_scratch_doubles(); result in [0] */, hipStream_t s);
 // device-to-device policy sync (tw_sync.hip)
 struct SyncArgs {
     // torch-layout sources (device)

@@ -836,10 +836,11 @@ template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -16> { using Eng = E
 template <int NT> inline int geometry_for(uint64_t n)
 {
     int nw = waves_per_group(n);
-    if (const char *f = getenv("TW_FORCE_GEOM")) nw = atoi(f) == 8 ? 8 : 1;     // diagnostic: 8 = throughput shape, else small-batch
+    const int force = launch_options().force_geom;                 // diagnostic (tw_set_launch_option): 8 = throughput shape, else small-batch
+    if (force) nw = force == 8 ? 8 : 1;
     if (nw == 8 || NT < 2) return nw;
-    // up to one 16-episode workgroup per CU (4,096 episodes on an MI355X): the tiny-batch shape; TW_FORCE_GEOM=32 keeps the 32-episode one
-    if (NT >= 4 && n <= rollout_f32_resident_episodes() / 16 && !(getenv("TW_FORCE_GEOM") && atoi(getenv("TW_FORCE_GEOM")) == 32)) return -16;
+    // up to one 16-episode workgroup per CU (4,096 episodes on an MI355X): the tiny-batch shape; force_geom 32 keeps the 32-episode one
+    if (NT >= 4 && n <= rollout_f32_resident_episodes() / 16 && force != 32) return -16;
     return NT >= 4 ? -4 : -2;
 }
 

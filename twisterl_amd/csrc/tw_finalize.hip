@@ -130,20 +130,20 @@ int launch_scan(const uint32_t *ep_len, uint64_t E, int merge_order, uint64_t *e
 }
 
 // ---- GAE + compaction ---------------------------------------------------------------------
-constexpr int FIN_WAVES = 4;   // episodes per workgroup (one per wave)
+constexpr int FIN_WAVES = 4;   // episodes per workgroup (one per wave); fewer when the episode tile would not fit 64 KiB of LDS
 
 __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const PaddedTraj in, const uint64_t *ep_start,
                                                                       uint64_t E, int n_cells, float gamma, float lambda,
                                                                       const CompactTraj out)
 {
     extern __shared__ __attribute__((aligned(16))) float fin_lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int t_pad = in.t_pad;
     float *sr = fin_lds + (size_t)wave * 5 * t_pad;   // rewards | values | advs | rets | action/perm word
     float *sv = sr + t_pad, *sa = sv + t_pad, *st = sa + t_pad;
     uint32_t *sz = reinterpret_cast<uint32_t *>(st + t_pad);
 
-    for (uint64_t e = (uint64_t)blockIdx.x * FIN_WAVES + wave; e < E; e += (uint64_t)gridDim.x * FIN_WAVES) {
+    for (uint64_t e = (uint64_t)blockIdx.x * n_waves + wave; e < E; e += (uint64_t)gridDim.x * n_waves) {
         const int      n     = (int)in.ep_len[e];
         const uint64_t src   = e * (uint64_t)t_pad;
         const uint64_t dst   = ep_start[e];
@@ -197,11 +197,14 @@ int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t
                         float lambda, const CompactTraj &out, hipStream_t s)
 {
     if (E == 0) return TW_OK;
-    const size_t lds_bytes = (size_t)FIN_WAVES * 5 * in.t_pad * sizeof(float);
+    const size_t per_wave = (size_t)5 * in.t_pad * sizeof(float);
+    int waves = FIN_WAVES;
+    while (waves > 1 && waves * per_wave > 64 * 1024) waves >>= 1;           // long horizons (t_pad > 819): fewer episodes per workgroup
+    const size_t lds_bytes = waves * per_wave;
     if (lds_bytes > 64 * 1024) { set_error("finalize: t_pad %d too large for the LDS tile", in.t_pad); return TW_ERR_UNSUPPORTED; }
-    uint64_t blocks = (E + FIN_WAVES - 1) / FIN_WAVES;
+    uint64_t blocks = (E + waves - 1) / waves;
     if (blocks > 256ull * 16) blocks = 256ull * 16;   // grid-stride the rest
-    hipLaunchKernelGGL(finalize_ppo_kernel, dim3((unsigned)blocks), dim3(FIN_WAVES * 64), lds_bytes, s, in, ep_start, E,
+    hipLaunchKernelGGL(finalize_ppo_kernel, dim3((unsigned)blocks), dim3(waves * 64), lds_bytes, s, in, ep_start, E,
                        n_cells, gamma, lambda, out);
     TW_HIP(hipGetLastError());
     return TW_OK;

@@ -423,16 +423,11 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
 {
     using G = Geom<NT, NC, 0, NW>;
     constexpr int EPB = G::Eng::EPB;
-    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / (8 * EPW) : (a.num_episodes + EPB - 1) / EPB;   // persistent: one workgroup per CU
+    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes(a.reserve_cus) / (8 * EPW) : (a.num_episodes + EPB - 1) / EPB;   // persistent: one workgroup per CU
     if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = (G::Eng::lds_floats(a.pol.obs_size) + (size_t)3 * PATH_DEPTH * EPB) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
-    static size_t attr_bytes = 0;
-    if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC, NW, PERSIST>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_bytes = lds_bytes;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC, NW, PERSIST>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
     unsigned long long zeros[16] = {0};
     if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mcts_stamps), zeros, sizeof(zeros)));
@@ -460,9 +455,9 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
 template <int NT, int NC>
 static int launch_mcts_one(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    const uint64_t resident = f32_resident_episodes(a.num_episodes, a.pol.hidden, true);
+    const uint64_t resident = f32_resident_episodes(a.num_episodes, a.pol.hidden, true, a.reserve_cus);
     if (!a.solve.on && a.queue && a.init_boards && a.num_episodes > resident) {
-        if constexpr (NT >= 4) { if (resident < rollout_f32_resident_episodes()) return launch_mcts_geom<NT, NC, -4, true>(a, s, blocks, threads); }
+        if constexpr (NT >= 4) { if (resident < rollout_f32_resident_episodes(a.reserve_cus)) return launch_mcts_geom<NT, NC, -4, true>(a, s, blocks, threads); }
         return launch_mcts_geom<NT, NC, 8, true>(a, s, blocks, threads);
     }
     const int nw = geometry_for<NT>(a.num_episodes);

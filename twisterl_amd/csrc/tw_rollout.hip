@@ -153,18 +153,14 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32
 
 // persistent mode: one 256-episode workgroup per CU of the current device (256 on an MI355X; every rollout kernel needs
 // most of a CU's LDS, so one workgroup is resident per CU)
-static uint64_t persist_blocks()
+static uint64_t persist_blocks(int reserve_cus)
 {
-    static int cached_dev = -1; static uint64_t cached = 256;
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
-        hipDeviceProp_t p;
-        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) { cached = (uint64_t)p.multiProcessorCount; cached_dev = dev; }
-    }
-    return cached;
+    const int cus = device_cus();
+    const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);   // reserve_cus CUs stay free (RCCL beside the persistent grid)
+    return (uint64_t)(cus - r);
 }
 
-uint64_t rollout_f32_resident_episodes() { return persist_blocks() * 8 * EPW; }
+uint64_t rollout_f32_resident_episodes(int reserve_cus) { return persist_blocks(reserve_cus) * 8 * EPW; }
 
 // Episodes are ragged (a solved puzzle ends its episode), and a lane whose episode is over can only be refilled when there
 // are more episodes than lanes.  Between CUs x 32 episodes and 3/4 of CUs x 256 the small-batch shape with the episode
@@ -173,11 +169,11 @@ uint64_t rollout_f32_resident_episodes() { return persist_blocks() * 8 * EPW; }
 // episodes: 1.8x); from there on the 256-episode shape wins.
 // Upper end of that range: where the 256-episode shape overtakes with episodes of equal length (the rollout crossover of
 // waves_per_group()); self-play episodes are always ragged, there the range extends to 3/4 of CUs x 256.
-uint64_t f32_resident_episodes(uint64_t num_episodes, int hidden, bool selfplay)
+uint64_t f32_resident_episodes(uint64_t num_episodes, int hidden, bool selfplay, int reserve_cus)
 {
-    const uint64_t full = rollout_f32_resident_episodes(), small = full / 8;
+    const uint64_t full = rollout_f32_resident_episodes(reserve_cus), small = full / 8;
     const bool in_range = selfplay ? num_episodes * 4 <= full * 3 : waves_per_group(num_episodes) != 8;
-    if (hidden >= 128 && num_episodes > small && in_range && !getenv("TW_FORCE_GEOM")) return small;
+    if (hidden >= 128 && num_episodes > small && in_range && !launch_options().force_geom) return small;
     return full;
 }
 
@@ -186,16 +182,11 @@ static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
 {
     using G = Geom<NT, NC, DBG, NW>;
     constexpr int EPB = G::Eng::EPB, THREADS = 64 * G::WAVES;
-    const uint64_t nb = PERSIST ? persist_blocks() : (a.num_episodes + EPB - 1) / EPB;
+    const uint64_t nb = PERSIST ? persist_blocks(a.reserve_cus) : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
-    static size_t attr_bytes = 0;   // per instantiation: raise the dynamic-LDS limit above the 64 KiB default
-    if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_bytes = lds_bytes;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>), lds_bytes)) return rc;
     hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
@@ -219,9 +210,9 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
     }
 #endif
     // small batches: fewer waves per workgroup, so that the episodes spread over more CUs
-    const uint64_t resident = f32_resident_episodes(a.num_episodes, a.pol.hidden, false);
+    const uint64_t resident = f32_resident_episodes(a.num_episodes, a.pol.hidden, false, a.reserve_cus);
     if (a.queue && a.init_boards && a.num_episodes > resident) {
-        if constexpr (NT >= 4) { if (resident < rollout_f32_resident_episodes()) return launch_geom<NT, NC, 0, -4, true>(a, s, blocks, threads); }
+        if constexpr (NT >= 4) { if (resident < rollout_f32_resident_episodes(a.reserve_cus)) return launch_geom<NT, NC, 0, -4, true>(a, s, blocks, threads); }
         return launch_geom<NT, NC, 0, 8, true>(a, s, blocks, threads);
     }
     const int nw = geometry_for<NT>(a.num_episodes);

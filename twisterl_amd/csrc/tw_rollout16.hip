@@ -174,15 +174,10 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
 template <class Eng, int NC, bool PERSIST>
 static int launch16p(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads, size_t lds_bytes)
 {
-    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes() / Eng::EPB : (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
+    const uint64_t nb = PERSIST ? rollout_f32_resident_episodes(a.reserve_cus) / Eng::EPB : (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout16: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     if (lds_bytes > 159 * 1024) { set_error("rollout16: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
-    static size_t attr_bytes = 0;
-    if (lds_bytes > attr_bytes) {
-        TW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_f16_kernel<Eng, NC, PERSIST>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_bytes = lds_bytes;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_f16_kernel<Eng, NC, PERSIST>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
     static const unsigned long long zeros[8] = {};
     if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps16), zeros, sizeof(zeros)));
@@ -208,7 +203,7 @@ template <class Eng, int NC>
 static int launch16(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads, size_t lds_bytes)
 {
     // more episodes than resident lanes: persistent lanes that take the next episode from a queue (tw_rollout.hip)
-    if (a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes()) return launch16p<Eng, NC, true>(a, s, blocks, threads, lds_bytes);
+    if (a.queue && a.init_boards && a.num_episodes > rollout_f32_resident_episodes(a.reserve_cus)) return launch16p<Eng, NC, true>(a, s, blocks, threads, lds_bytes);
     return launch16p<Eng, NC, false>(a, s, blocks, threads, lds_bytes);
 }
 

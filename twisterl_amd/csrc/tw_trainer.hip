@@ -64,8 +64,11 @@ __global__ void __launch_bounds__(256) ppo_pack_kernel(const float *logits, cons
     if (advs_out) advs_out[i] = normalize ? (advs[r] - mean) / denom : advs[r];
 }
 
-// sum and sum of squared deviations in double (two passes: mean first)
-__global__ void __launch_bounds__(256) sum_kernel(const float *x, uint64_t n, double shift, int squared, double *out)
+// sum and sum of squared deviations in double (two passes: mean first).  Bit-reproducible: every block writes its partial,
+// one workgroup adds the partials in block order (no float atomics anywhere in the library).
+constexpr unsigned SUM_BLOCKS = 2048;
+
+__global__ void __launch_bounds__(256) sum_kernel(const float *x, uint64_t n, double shift, int squared, double *partials)
 {
     __shared__ double sm[4];
     double acc = 0.0;
@@ -76,7 +79,16 @@ __global__ void __launch_bounds__(256) sum_kernel(const float *x, uint64_t n, do
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+__global__ void __launch_bounds__(64) sum_partials_kernel(const double *partials, unsigned n_blocks, double *out)
+{
+    // lane l adds partials l, l+64, ... in order; then a fixed-shape tree over the lanes
+    double acc = 0.0;
+    for (unsigned i = threadIdx.x; i < n_blocks; i += 64) acc += partials[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (threadIdx.x == 0) *out = acc;
 }
 
 int launch_onehot(const uint8_t *obs, uint64_t row0, uint64_t rows, int n_cells, int obs_size, float *out, hipStream_t s)
@@ -106,13 +118,17 @@ int launch_ppo_pack(const float *logits, const uint8_t *actions, const int8_t *p
     return TW_OK;
 }
 
-int launch_sum(const float *x, uint64_t n, double shift, int squared, double *out_dev, hipStream_t s)
+size_t sum_scratch_doubles() { return SUM_BLOCKS + 1; }
+
+// scratch: sum_scratch_doubles() doubles on the device; the result lands in scratch[0]
+int launch_sum(const float *x, uint64_t n, double shift, int squared, double *scratch, hipStream_t s)
 {
-    TW_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), s));
+    TW_HIP(hipMemsetAsync(scratch, 0, sizeof(double), s));
     if (n == 0) return TW_OK;
     uint64_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, shift, squared, out_dev);
+    if (blocks > SUM_BLOCKS) blocks = SUM_BLOCKS;
+    hipLaunchKernelGGL(sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, shift, squared, scratch + 1);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, scratch + 1, (unsigned)blocks, scratch);
     TW_HIP(hipGetLastError());
     return TW_OK;
 }

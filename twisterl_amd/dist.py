@@ -2,106 +2,116 @@
 trajectories to the root.
 
 One process per GPU, `torch.distributed` ("nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU
-tests).  Rank g collects the global episodes [g*E/G, (g+1)*E/G) with the RNG keyed by the GLOBAL
-episode index, so the gathered result is bit-identical to a single-GPU collect of all E episodes.
-There is no collective on the data path while collecting; afterwards
-  1. all_gather of (records, records of the rank's last episode)   -- 16 B per rank
-  2. point-to-point send of each rank's compact SoA buffers to the root (each non-root rank has
-     its own direct xGMI link to the root, so the 7 transfers run concurrently; a ring would be
-     per-link bound), placed so that the final order is the reference merge order
-     [E-1, 0, 1, ..., E-2] (rust/src/collector/collector.rs:40-46).
+tests).  The RNG is keyed by the GLOBAL episode index, so whichever rank collects an episode the
+gathered result is bit-identical to a single-GPU collect of all E episodes.  There is no
+collective on the data path while collecting.
+
+Episode ranges are dealt out CHUNK-MAJOR: the E episodes are cut into K steps (step_bounds) and
+every step's range evenly into G contiguous pieces ("global chunks", K = pipeline steps, G =
+ranks); in step s rank r collects global chunk s*G + r.
+After each step:
+  1. all_gather of (records, records of the chunk's last episode)   -- 16 B per rank
+  2. point-to-point sends of every rank's compact SoA buffers to the root, received AT THEIR FINAL
+     OFFSETS in the root's output buffers: the offset of global chunk g depends only on the record
+     counts of the chunks before it, all of which are known once step s's counts have been
+     gathered.  Each non-root rank has its own direct xGMI link to the root, so the G-1 transfers of
+     a step run concurrently (a ring would be per-link bound), and the transfer of step s overlaps
+     with the collection of step s+1.
+The final order is the reference merge order [E-1, 0, 1, ..., E-2]
+(rust/src/collector/collector.rs:40-46): the records of episode E-1 -- the tail of the very last
+global chunk -- are received in front of everything else.  They are at most one episode long, so
+the output buffers keep `max_episode_records` of slack in front and the result is a view; nothing
+is staged and nothing is re-ordered on the device.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+import copy
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 FIELD_ORDER = ("obs", "logits", "perms", "values", "rewards", "actions", "advs", "rets", "remaining_values")
 
+# Compute units the persistent rollout grid leaves free on every rank while a gather is in flight (tw_ppo_params.reserve_cus):
+# RCCL's send/recv kernels are ordinary workgroups, and a rollout workgroup (512 threads, ~122 KB of LDS, 2 x 213 VGPRs per
+# SIMD lane) leaves no room for another workgroup on its CU.  One CU per XCD.
+DEFAULT_RESERVE_CUS = 8
+
 
 def shard_range(num_episodes: int, rank: int, world: int):
-    """Episode index range [start, end) owned by `rank`."""
+    """Episode index range [start, end) owned by `rank` (one step)."""
     return (rank * num_episodes) // world, ((rank + 1) * num_episodes) // world
 
 
-def gather_trajectories(fields: Dict[str, torch.Tensor], ep_len: torch.Tensor, dst: int = 0,
-                        group=None) -> Optional[Dict[str, torch.Tensor]]:
-    """Gather per-rank compact trajectories (episode-index order inside each rank) to `dst` in the
-    reference merge order.  `fields[name]` has the record axis first; `ep_len` is this rank's
-    per-episode record count.  Returns the merged dict on `dst`, None elsewhere."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    names = [n for n in FIELD_ORDER if n in fields]
-    n_local = int(fields[names[0]].shape[0])
-    last_len = int(ep_len[-1].item()) if ep_len.numel() else 0
-    dev = fields[names[0]].device
-    mine = torch.tensor([n_local, last_len], dtype=torch.int64, device=dev)
-    allc = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allc, mine, group=group)
-    counts = [int(c[0].item()) for c in allc]
-    tail = int(allc[world - 1][1].item())           # records of global episode E-1
-    total = sum(counts)
-    # destination offsets: [tail of last rank][rank 0][rank 1]...[rank G-1 without its tail]
-    starts, pos = [], tail
-    for r in range(world):
-        starts.append(pos)
-        pos += counts[r] - (tail if r == world - 1 else 0)
-    assert pos == total
-
-    def pieces(r):
-        """(src_lo, src_hi, dst_lo) slices rank r contributes"""
-        if r == world - 1:
-            body = counts[r] - tail
-            return [(body, counts[r], 0), (0, body, starts[r])]
-        return [(0, counts[r], starts[r])]
-
-    out = None
-    ops = []
-    if rank == dst:
-        out = {n: torch.empty((total,) + tuple(fields[n].shape[1:]), dtype=fields[n].dtype, device=dev) for n in names}
-        for r in range(world):
-            for (lo, hi, d) in pieces(r):
-                if hi <= lo:
-                    continue
-                for n in names:
-                    if r == rank:
-                        out[n][d:d + hi - lo].copy_(fields[n][lo:hi])
-                    else:
-                        ops.append(dist.P2POp(dist.irecv, out[n][d:d + hi - lo], r, group))
-    else:
-        for (lo, hi, _) in pieces(rank):
-            if hi <= lo:
-                continue
-            for n in names:
-                ops.append(dist.P2POp(dist.isend, fields[n][lo:hi].contiguous(), dst, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    return out
+def step_bounds(num_episodes: int, world: int, chunks: int = 1, step_episodes: Optional[int] = None) -> List[int]:
+    """Cumulative episode boundaries of the pipeline steps, from globally known quantities only (every rank issues the
+    same collectives): step s covers the episodes [b[s-1], b[s]) (b[-1] = 0), dealt out evenly over the ranks.
+    `step_episodes` (episodes per rank and step, e.g. the lanes a GPU keeps resident) takes precedence over `chunks`
+    (that many steps of equal size)."""
+    E, G = int(num_episodes), int(world)
+    per_rank = -(-E // G)
+    if step_episodes:
+        K = max(1, -(-per_rank // int(step_episodes)))
+        return [min(E, (s + 1) * G * int(step_episodes)) for s in range(K - 1)] + [E]
+    K = max(1, min(int(chunks), per_rank))
+    return [((s + 1) * E) // K for s in range(K)]
 
 
-class PipelinedGather:
-    """Gather that overlaps with collection: a rank's shard is collected in K chunks of episodes; the trajectories
-    of chunk c travel to `dst` (point-to-point, as in gather_trajectories) while chunk c+1 is being collected, so
-    only the last chunk's transfer and one on-device reorder at `dst` are exposed.  xGMI moves ~3.4 GB per rank and
-    Puzzle-15 step into the root at link rate (~50 ms for 7 senders): a third of the collection time if serialised.
+def pipeline_steps(num_episodes: int, world: int, chunks: int = 1, step_episodes: Optional[int] = None) -> int:
+    return len(step_bounds(num_episodes, world, chunks, step_episodes))
 
-    submit(fields, ep_len): chunk in episode-index order (merge_order=0), asynchronous (keeps the tensors alive);
-    finish(): waits and returns, on `dst`, every field in the reference merge order [E-1, 0, ..., E-2]
-    (rust/src/collector/collector.rs:40-46), bit-identical to gather_trajectories of the un-chunked shard."""
 
-    def __init__(self, dst: int = 0, group=None):
-        self.dst, self.group = dst, group
+def chunk_range(bounds: List[int], step: int, rank: int, world: int) -> Tuple[int, int]:
+    """Episode index range [start, end) (possibly empty) that `rank` collects in `step` (chunk-major order)."""
+    a = bounds[step - 1] if step > 0 else 0
+    lo, hi = shard_range(bounds[step] - a, rank, world)
+    return a + lo, a + hi
+
+
+class TrajectoryGather:
+    """Gathers compact trajectories to `dst` in the reference merge order, step by step (see the module docstring).
+
+    submit(fields, ep_len): this rank's chunk of the current step, episode-index order (merge_order=0): `fields[name]` has
+        the record axis first; may be empty (zero records).  Asynchronous: the tensors are kept alive until finish().
+    finish(): waits; on `dst` returns {name: tensor} in merge order (views of the output buffers), None elsewhere.
+
+    steps > 1 needs `max_records` (an upper bound of the records of ALL ranks and steps, e.g. episodes x (horizon+1)) because
+    the output buffers are allocated before the totals are known; they are kept and reused by the next round (`reset()`).
+    """
+
+    def __init__(self, dst: int = 0, group=None, steps: int = 1, max_records: Optional[int] = None,
+                 max_episode_records: Optional[int] = None):
+        self.dst, self.group, self.steps = dst, group, int(steps)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.chunks = []          # per chunk: (counts per rank, tail of the last rank, staging dict | None)
-        self.works, self.keep = [], []
-        self.names = None
+        if self.steps > 1 and (max_records is None or max_episode_records is None):
+            raise ValueError("TrajectoryGather: steps > 1 needs max_records and max_episode_records")
+        self.max_records, self.max_episode_records = max_records, max_episode_records
+        self.buf: Optional[Dict[str, torch.Tensor]] = None
+        self.reset()
+
+    def reset(self):
+        self.step, self.pos, self.front, self.tail = 0, 0, 0, 0
+        self.works, self.keep, self.names = [], [], None
+
+    def _alloc(self, fields, names, total_first_step, tail_first_step):
+        if self.steps == 1:                      # everything is known: exact size, no slack
+            self.front, cap = tail_first_step, total_first_step
+        else:
+            self.front, cap = int(self.max_episode_records), int(self.max_records) + int(self.max_episode_records)
+        ok = self.buf is not None and all(
+            n in self.buf and self.buf[n].shape[0] >= cap and self.buf[n].shape[1:] == fields[n].shape[1:]
+            and self.buf[n].dtype == fields[n].dtype and self.buf[n].device == fields[n].device for n in names)
+        if not ok:
+            self.buf = {n: torch.empty((cap,) + tuple(fields[n].shape[1:]), dtype=fields[n].dtype, device=fields[n].device)
+                        for n in names}
 
     def submit(self, fields: Dict[str, torch.Tensor], ep_len: torch.Tensor) -> None:
+        if self.step >= self.steps:
+            raise RuntimeError("TrajectoryGather: more submits than steps")
         names = [n for n in FIELD_ORDER if n in fields]
         self.names = names
+        last_step = self.step == self.steps - 1
         n_local = int(fields[names[0]].shape[0])
         last_len = int(ep_len[-1].item()) if ep_len.numel() else 0
         dev = fields[names[0]].device
@@ -109,66 +119,77 @@ class PipelinedGather:
         allc = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(allc, mine, group=self.group)
         counts = [int(c[0].item()) for c in allc]
-        tail = int(allc[self.world - 1][1].item())
-        ops, staging = [], None
+        lasts = [int(c[1].item()) for c in allc]
+        # episode E-1 is the last episode of the last NON-EMPTY chunk of the last step (with E >= 1 there is one)
+        tail, tail_rank = 0, -1
+        if last_step:
+            for r in range(self.world - 1, -1, -1):
+                if counts[r] > 0:
+                    tail, tail_rank = lasts[r], r
+                    break
+        if self.rank == self.dst and self.step == 0:
+            self._alloc(fields, names, sum(counts), tail)
+        if last_step:
+            self.tail = tail
+
+        # (src_lo, src_hi, dst_lo) pieces per rank for this step; dst_lo relative to the start of the output buffers
+        def pieces(r):
+            n = counts[r]
+            if r == tail_rank:
+                body = n - tail
+                out = [(body, n, self.front - tail)]
+                if body > 0:
+                    out.append((0, body, self.front + pos_of[r]))
+                return out
+            return [(0, n, self.front + pos_of[r])] if n > 0 else []
+
+        pos_of, p = [], self.pos
+        for r in range(self.world):
+            pos_of.append(p)
+            p += counts[r] - (tail if r == tail_rank else 0)
+        if self.rank == self.dst and self.front + p > next(iter(self.buf.values())).shape[0]:
+            raise RuntimeError(f"TrajectoryGather: {p} records exceed max_records={self.max_records}")
+
+        ops = []
         if self.rank == self.dst:
-            total = sum(counts)
-            staging = {n: torch.empty((total,) + tuple(fields[n].shape[1:]), dtype=fields[n].dtype, device=dev) for n in names}
-            off = 0
             for r in range(self.world):
-                if counts[r]:
+                for (lo, hi, d) in pieces(r):
                     for n in names:
                         if r == self.rank:
-                            staging[n][off:off + counts[r]].copy_(fields[n])
+                            self.buf[n][d:d + hi - lo].copy_(fields[n][lo:hi])
                         else:
-                            ops.append(dist.P2POp(dist.irecv, staging[n][off:off + counts[r]], r, self.group))
-                off += counts[r]
-        elif n_local:
-            for n in names:
-                t = fields[n].contiguous()
-                self.keep.append(t)
-                ops.append(dist.P2POp(dist.isend, t, self.dst, self.group))
+                            ops.append(dist.P2POp(dist.irecv, self.buf[n][d:d + hi - lo], r, self.group))
+        else:
+            for (lo, hi, _) in pieces(self.rank):
+                for n in names:
+                    t = fields[n][lo:hi].contiguous()
+                    self.keep.append(t)
+                    ops.append(dist.P2POp(dist.isend, t, self.dst, self.group))
         self.keep.append(fields)
-        self.works.append(dist.batch_isend_irecv(ops) if ops else [])      # per chunk: finish() waits chunk by chunk
-        self.chunks.append((counts, tail, staging))
+        self.works.append(dist.batch_isend_irecv(ops) if ops else [])
+        self.pos = p
+        self.step += 1
 
     def finish(self) -> Optional[Dict[str, torch.Tensor]]:
-        if self.rank != self.dst:
-            for ws in self.works:
-                for w in ws:
-                    w.wait()
-            self.works, self.keep = [], []
-            return None
-        names, world, K = self.names, self.world, len(self.chunks)
-        tail = self.chunks[-1][1] if K else 0                       # records of global episode E-1
-        total = sum(sum(c[0]) for c in self.chunks)
-        first = self.chunks[0][2]
-        out = {n: torch.empty((total,) + tuple(first[n].shape[1:]), dtype=first[n].dtype, device=first[n].device) for n in names}
-        # [tail][rank 0: chunk 0..K-1][rank 1: ...]...[rank G-1: ... without its tail]
-        plan = [[] for _ in range(K)]          # per chunk: (src_lo, src_hi, dst_lo)
-        pos = tail
-        for r in range(world):
-            for c, (counts, _, _) in enumerate(self.chunks):
-                src = sum(counts[:r])
-                n_rec = counts[r]
-                if r == world - 1 and c == K - 1:
-                    body = n_rec - tail
-                    plan[c].append((src + body, src + n_rec, 0))
-                    n_rec = body
-                if n_rec > 0:
-                    plan[c].append((src, src + n_rec, pos))
-                pos += n_rec
-        assert pos == total
-        # chunk by chunk: the reorder of the early chunks runs while the last chunk is still arriving
-        for c, (_, _, staging) in enumerate(self.chunks):
-            for w in self.works[c]:
+        if self.step != self.steps:
+            raise RuntimeError(f"TrajectoryGather: {self.step} of {self.steps} steps submitted")
+        for ws in self.works:
+            for w in ws:
                 w.wait()
-            for (lo, hi, d) in plan[c]:
-                if hi > lo:
-                    for n in names:
-                        out[n][d:d + hi - lo].copy_(staging[n][lo:hi])
-        self.works, self.keep, self.chunks = [], [], []
+        out = None
+        if self.rank == self.dst:
+            total, a = self.pos + self.tail, self.front - self.tail
+            out = {n: self.buf[n][a:a + total] for n in self.names}
+        self.reset()
         return out
+
+
+def gather_trajectories(fields: Dict[str, torch.Tensor], ep_len: torch.Tensor, dst: int = 0,
+                        group=None) -> Optional[Dict[str, torch.Tensor]]:
+    """One-step gather: every rank holds the compact trajectories of ITS contiguous episode shard (index order)."""
+    tg = TrajectoryGather(dst=dst, group=group, steps=1)
+    tg.submit(fields, ep_len)
+    return tg.finish()
 
 
 def broadcast_weights(tensors, src: int = 0, group=None) -> None:
@@ -182,41 +203,68 @@ def broadcast_weights(tensors, src: int = 0, group=None) -> None:
         off += n
 
 
-def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None, gather: bool = True, chunks: int = 1):
-    """Run `collector` (a PPOCollector/AZCollector configured with the GLOBAL num_episodes) on this
-    rank's shard and gather to `dst`.  Returns (merged dict of device tensors or None, local
-    CollectedData -- a list of them, one per chunk, when chunks > 1).  chunks > 1 collects the shard in that
-    many pieces and overlaps each piece's transfer with the collection of the next (PipelinedGather)."""
-    import copy
+def _split_fields(data):
+    t = data.to_torch()
+    ep_len = t.pop("ep_len")
+    t.pop("ep_start", None)
+    return t, ep_len
+
+
+def _empty_like_fields(template: Dict[str, torch.Tensor]):
+    return {k: v[:0] for k, v in template.items()}, torch.zeros((0,), dtype=torch.int64)
+
+
+def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None, gather: bool = True, chunks: int = 1,
+                    max_episode_records: Optional[int] = None, gatherer: Optional[TrajectoryGather] = None,
+                    reserve_cus: Optional[int] = None, step_episodes: Optional[int] = None):
+    """Run `collector` (a PPOCollector/AZCollector configured with the GLOBAL num_episodes) over all ranks and gather to
+    `dst`.  Returns (merged dict of device tensors on `dst` else None, list of this rank's CollectedData, one per non-empty
+    chunk).  chunks > 1 collects in that many pipeline steps so that each step's transfer overlaps with the next step's
+    collection; `max_episode_records` (= depth_slope*difficulty + 1 for Puzzle) is then required.  Pass a `gatherer` to
+    reuse its output buffers between calls.  `reserve_cus` compute units stay free of rollout workgroups while a transfer
+    can be in flight (default DEFAULT_RESERVE_CUS when pipelining on more than one rank, else 0).  `step_episodes` sets the
+    episodes per rank and step instead of `chunks` -- with episodes of equal length a step should be a whole number of
+    rounds of the GPU's resident lanes ((CUs - reserve_cus) x 256)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    lo, hi = shard_range(collector.num_episodes, rank, world)
-    chunks = max(1, min(int(chunks), hi - lo)) if hi > lo else 1
+    E = int(collector.num_episodes)
+    bounds = step_bounds(E, world, chunks, step_episodes)
+    K = len(bounds)
+    if reserve_cus is None:
+        reserve_cus = DEFAULT_RESERVE_CUS if (world > 1 and K > 1 and gather) else 0
 
     def run(a, b):
         local = copy.copy(collector)
         local.num_episodes = b - a
         local.episode_offset = collector.episode_offset + a
         local.merge_order = False
+        if hasattr(local, "reserve_cus"):
+            local.reserve_cus = int(reserve_cus)
         return local.collect(env, policy, seed=seed)
 
-    if chunks == 1:
-        data = run(lo, hi)
-        if not gather:
-            return None, data
-        t = data.to_torch()
-        ep_len = t.pop("ep_len")
-        t.pop("ep_start", None)
-        return gather_trajectories(t, ep_len, dst=dst, group=group), data
-    pg = PipelinedGather(dst=dst, group=group) if gather else None
-    datas = []
-    for c in range(chunks):
-        a, b = lo + ((hi - lo) * c) // chunks, lo + ((hi - lo) * (c + 1)) // chunks
-        d = run(a, b)
-        datas.append(d)
-        if pg is not None:
-            t = d.to_torch()
-            ep_len = t.pop("ep_len")
-            t.pop("ep_start", None)
-            pg.submit(t, ep_len)
-    return (pg.finish() if pg is not None else None), datas
+    tg = None
+    if gather:
+        if K > 1 and max_episode_records is None:
+            raise ValueError("collect_sharded: chunks > 1 needs max_episode_records")
+        tg = gatherer
+        if tg is None or tg.steps != K:
+            tg = TrajectoryGather(dst=dst, group=group, steps=K,
+                                  max_records=E * int(max_episode_records) if K > 1 else None,
+                                  max_episode_records=max_episode_records)
+    datas: List = []
+    template = None
+    for s in range(K):
+        a, b = chunk_range(bounds, s, rank, world)
+        if b > a:
+            d = run(a, b)
+            datas.append(d)
+            if tg is not None:
+                template, ep_len = _split_fields(d)
+                tg.submit(template, ep_len)
+        elif tg is not None:
+            # nothing to collect in this step (E < ranks x steps): the rank still joins the step's collectives, with
+            # zero-length fields of the collector's layout
+            if template is None:
+                template = collector.empty_fields(env)
+            tg.submit(*_empty_like_fields(template))
+    return (tg.finish() if tg is not None else None), datas
