@@ -211,8 +211,14 @@ def test_zero_copy_torch_views_and_single_rank_gather(tw, oracle):
         for k in ("obs", "logits", "values", "actions", "advs", "rets"):
             assert np.array_equal(merged[k].cpu().numpy(), a[k]), k
         # the same shard collected in 3 chunks with the pipelined gather: identical result
-        piped, parts = collect_sharded(tw.collector.PPOCollector(200, 0.99, 0.95, 1), env, gp, seed=3, chunks=3)
+        piped, parts = collect_sharded(tw.collector.PPOCollector(200, 0.99, 0.95, 1), env, gp, seed=3, chunks=3, max_episode_records=11)
         assert isinstance(parts, list) and len(parts) == 3 and sum(len(p) for p in parts) == a["obs"].shape[0]
+        for k in ("obs", "logits", "values", "actions", "advs", "rets", "perms", "rewards"):
+            assert np.array_equal(piped[k].cpu().numpy(), a[k]), k
+        # steps sized in episodes (what bench.py does at N > 1), with CUs reserved for the transfer kernels
+        piped, parts = collect_sharded(tw.collector.PPOCollector(200, 0.99, 0.95, 1), env, gp, seed=3, step_episodes=64,
+                                       max_episode_records=11, reserve_cus=8)
+        assert len(parts) == 4 and [p.stats["episodes"] for p in parts] == [64, 64, 64, 8]
         for k in ("obs", "logits", "values", "actions", "advs", "rets", "perms", "rewards"):
             assert np.array_equal(piped[k].cpu().numpy(), a[k]), k
     finally:
