@@ -259,7 +259,10 @@ typedef struct {
     uint64_t episodes;
     uint64_t padded_bytes;  /* workspace used by the padded trajectory buffers                  */
     uint32_t rollout_blocks, rollout_threads;
-    uint64_t forward_evals; /* policy forwards executed (AZ: leaf evaluations x twists)         */
+    uint64_t forward_evals; /* policy forwards the searches consumed (AZ: leaf evaluations x    */
+                            /* twists) = what the reference computes                            */
+    uint64_t speculative_evals; /* AZ, few deep searches: frontier nodes evaluated on otherwise */
+                            /* idle MFMA columns before a search asked for them (x twists)      */
 } tw_collect_stats;
 int  tw_collected_stats(const tw_collected *c, tw_collect_stats *out);
 void tw_collected_free(tw_collected *c);

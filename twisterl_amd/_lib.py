@@ -74,7 +74,7 @@ class CollectStats(C.Structure):
     _fields_ = [("ms_rollout", C.c_float), ("ms_scan", C.c_float), ("ms_finalize", C.c_float),
                 ("ms_total", C.c_float), ("records", C.c_uint64), ("episodes", C.c_uint64),
                 ("padded_bytes", C.c_uint64), ("rollout_blocks", C.c_uint32),
-                ("rollout_threads", C.c_uint32), ("forward_evals", C.c_uint64)]
+                ("rollout_threads", C.c_uint32), ("forward_evals", C.c_uint64), ("speculative_evals", C.c_uint64)]
 
 
 # every symbol include/twisterl_hip.h declares: name -> (restype, argtypes)

@@ -975,11 +975,14 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     // persistent lanes (more episodes than resident lanes): one tree arena per LANE, start boards + episode queue
     ma.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
-    const uint64_t resident = f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
-    const bool persist = E > resident && !launch_options().no_persist;
+    // few, deep searches: the walker-per-wave shape (tw_mcts_deep.hip) -- always persistent, 64-byte nodes, one arena per walker
+    const bool deep = mcts_deep_applies(ma);
+    const uint64_t resident = deep ? mcts_deep_walkers(E, ma.reserve_cus) : f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
+    const bool persist = deep || (E > resident && !launch_options().no_persist);
     const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
-                 o_total = seg(16), o_scan = seg(scan_scratch_bytes(E)), o_arena = seg(arenas * cap64 * mcts_node_bytes()),
+                 o_total = seg(32), o_scan = seg(scan_scratch_bytes(E)),
+                 o_arena = seg(arenas * cap64 * (deep ? mcts_deep_node_bytes() : mcts_node_bytes())),
                  o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     size_t free_b = 0, total_b = 0;
     TW_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1003,23 +1006,25 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
 
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
-    TW_HIP(hipMemsetAsync(ws + o_total, 0, 16, s));
+    TW_HIP(hipMemsetAsync(ws + o_total, 0, 32, s));
     if (persist) {
         ma.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
         ma.queue = reinterpret_cast<unsigned int *>(ws + o_queue);
-        const unsigned int first = (unsigned int)resident;
+        const unsigned int first = (unsigned int)(resident < E ? resident : E);      // episodes handed out at launch
         TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
         rc = launch_init_boards(ma.env, ma.seed, ma.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
         if (rc) return rc;
     }
     TW_HIP(hipEventRecord(ev.ev[0], s));
-    rc = launch_mcts_f32(ma, s, &st.rollout_blocks, &st.rollout_threads); if (rc) return rc;
+    rc = deep ? launch_mcts_deep(ma, s, &st.rollout_blocks, &st.rollout_threads)
+              : launch_mcts_f32(ma, s, &st.rollout_blocks, &st.rollout_threads);
+    if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[1], s));
     rc = launch_scan(ma.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
     if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[2], s));
-    uint64_t host_tot[2] = {0, 0};
-    TW_HIP(hipMemcpyAsync(host_tot, ws + o_total, 16, hipMemcpyDeviceToHost, s));
+    uint64_t host_tot[3] = {0, 0, 0};
+    TW_HIP(hipMemcpyAsync(host_tot, ws + o_total, 24, hipMemcpyDeviceToHost, s));
     TW_HIP(hipStreamSynchronize(s));
     const uint64_t total = host_tot[0];
     if (total == 0 || total > R) { set_error("az collect: inconsistent record count %llu (max %llu)", (unsigned long long)total, (unsigned long long)R); return TW_ERR_HIP; }
@@ -1053,6 +1058,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
 #undef TW_HIP_C
     st.records = total; st.episodes = E; st.padded_bytes = cur;
     st.forward_evals = host_tot[1] * (uint64_t)(ma.pol.n_perms > 0 ? ma.pol.n_perms : 1);
+    st.speculative_evals = host_tot[2] * (uint64_t)(ma.pol.n_perms > 0 ? ma.pol.n_perms : 1);
     c->stats = st;
     *out = c;
     return TW_OK;

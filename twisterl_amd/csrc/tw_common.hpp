@@ -176,6 +176,36 @@ __host__ __device__ inline int sample_weighted(const float *w, int n, float u)
     return idx;
 }
 
+// The same for at most four weights, without an indexed local array: `cum[idx]` with a run-time index puts the array in
+// scratch (= device memory: a 1-2k-cycle round trip per access, and the tree walk of the self-play kernels calls this once
+// per search).  Same operation sequence, same result.
+__host__ __device__ inline int sample_weighted4(const float (&w)[4], int n, float u)
+{
+    if (n <= 0) return 0;
+    if (n > 4) n = 4;
+    float total = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < n) {
+            if (!(w[i] >= 0.0f)) bad = true;
+            total = bad ? total : total + w[i];
+            if (i == 0) c0 = total; else if (i == 1) c1 = total; else if (i == 2) c2 = total;
+        }
+    }
+    if (bad || !(total > 0.0f)) return 0;
+    const float chosen = u * total;
+    int idx = 0;
+    if (0 < n - 1 && c0 <= chosen) {
+        idx = 1;
+        if (1 < n - 1 && c1 <= chosen) {
+            idx = 2;
+            if (2 < n - 1 && c2 <= chosen) idx = 3;
+        }
+    }
+    return idx;
+}
+
 // Gumbel-max over 4 masked logits with injected uniforms (policy.rs:130-151,169-172):
 // argmax_i( l_i - ln(|ln(u_i)|) ), strict '>' => first max wins, NaN never wins.
 __host__ __device__ inline int gumbel_argmax4(const float l[4], const u32x4 w)
@@ -427,15 +457,21 @@ struct MctsArgs {
     float        C;
     MctsNode    *arena;        // [num_episodes][node_cap]
     uint32_t     node_cap;
-    unsigned long long *eval_count;   // number of policy evaluations (leaf + root), for the stats
+    unsigned long long *eval_count;   // [0] policy evaluations the searches consumed (leaf + root), [1] speculative ones (deep shape)
     MctsSolve    solve;        // on == 0: AlphaZero self-play (records into `out`)
     // persistent-lane mode (self-play with more episodes than resident lanes, see RolloutArgs): the arena is then
     // [resident lanes][node_cap], a lane reuses its arena for every episode it takes
     const uint64_t *init_boards;
     unsigned int   *queue;
     int32_t         reserve_cus;
+    uint32_t        lds_nodes;     // deep shape: nodes per tree whose statistics live in LDS (set by the launcher)
 };
 size_t mcts_node_bytes();
+// the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue
+bool     mcts_deep_applies(const MctsArgs &a);
+uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus);   // tree arenas = episodes in flight
+size_t   mcts_deep_node_bytes();
+int      launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_finalize_az(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,
                        uint8_t *obs_out, float *probs_out, int8_t *perms_out, float *remaining_out, hipStream_t s);

@@ -36,7 +36,7 @@ size_t mcts_node_bytes() { return sizeof(MctsNode); }
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr int PATH_DEPTH = 8;     // levels of the search path kept in LDS per episode (deeper paths fall back to parent chasing)
 #ifdef TW_ABLATE   // diagnostic build: per-wave cycle accounting (forward | tree phase | loop trips | searches consumed | max trips)
-__device__ unsigned long long g_mcts_stamps[16];
+__device__ unsigned long long g_mcts_stamps[24];
 #endif
 enum { PH_ROOT = 0, PH_LEAF = 1, PH_DONE = 2 };
 
@@ -127,9 +127,15 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
 #define TW_MS(var)
 #define TW_MA(acc, a, b)
 #endif
-    while (__syncthreads_or(phase != PH_DONE ? 1 : 0)) {
+#ifdef TW_ABLATE
+    unsigned long long x_or = 0, x_rows = 0, x_eng = 0, x_soft = 0, x_own = 0, x_mir = 0;
+#endif
+    for (;;) {
+        TW_MS(z0);
+        if (!__syncthreads_or(phase != PH_DONE ? 1 : 0)) break;
 #ifdef TW_ABLATE
         const unsigned long long s0 = __builtin_readcyclecounter();
+        x_or += s0 - z0;
 #endif
         // ---- (2) Policy::full_predict of the pending leaf (policy.rs:102-126) ------------------
         float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
@@ -138,9 +144,13 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
         for (int pass = 0; pass < n_pass; ++pass) {
             const int perm = eng.pol.n_perms > 0 ? pass : -1;
             int rowoff[NC];
+            TW_MS(z1);
             eng.rows_of(leaf.board, env.n_cells, perm, rowoff);
             float lg[4], v;
+            TW_MS(z2);
             eng.forward(rowoff, lg, v);
+            TW_MS(z3);
+            TW_MA(x_rows, z1, z2); TW_MA(x_eng, z2, z3);
             eng.act_perm(perm, lg);
             if (eng.pol.n_perms > 0) {
                 vsum = vsum + v / np;                                            // policy.rs:111
@@ -160,6 +170,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
         const unsigned long long s1 = __builtin_readcyclecounter();
         c_fwd += s1 - s0; ++c_trips;
 #endif
+        TW_MS(z4);
         // ---- (1) per-episode tree work on the owner lane ---------------------------------------
         if (owner && phase != PH_DONE) {
             ++evals;
@@ -218,7 +229,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                 const uint32_t nch = expand(node, leaf);
                 if (nch > 0) {
                     const u32x4 w = rng_draw(a.seed, e_global, it * MED + expanded, STREAM_MCTS | ((uint32_t)t << 8));
-                    node = cb + (uint32_t)sample_weighted(pri, (int)nch, u32_to_unit(w.x));
+                    node = cb + (uint32_t)sample_weighted4(pri, (int)nch, u32_to_unit(w.x));
                     push(node, 0.0f, 0u);
                 }
                 value = nn_value;
@@ -273,7 +284,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                                 for (int i = 1; i < 4; ++i) if (mp[i] > bv) { bv = mp[i]; action = i; }
                             } else {
                                 const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_SOLVE);
-                                action = sample_weighted(mp, 4, u32_to_unit(w.x));
+                                action = sample_weighted4(mp, 4, u32_to_unit(w.x));
                             }
                             if (sv.actions) sv.actions[e_local * (uint64_t)sv.act_pad + (uint64_t)t] = (uint8_t)action;
                             puzzle_step(st, env, action);
@@ -284,7 +295,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
                         }
                         // az.rs:72-81: action = sample(mcts_probs); val = env.reward(); store record
                         const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
-                        const int action = sample_weighted(mp, 4, u32_to_unit(w.x));
+                        const int action = sample_weighted4(mp, 4, u32_to_unit(w.x));
                         const uint64_t rec = rec_base + (uint64_t)t;
                         uint32_t pk[4];
                         obs_bytes(st.board, obs_base, pk);
@@ -370,6 +381,8 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
 #ifdef TW_ABLATE
         c_tree += __builtin_readcyclecounter() - s1;
 #endif
+        TW_MS(z5);
+        TW_MA(x_own, z4, z5);
         // mirror what the other lanes of the episode need for the next collective evaluation
         if constexpr (Eng::SPLIT) {        // lanes j / j+32 of every wave of the workgroup: through LDS
             uint32_t *bc = reinterpret_cast<uint32_t *>(eng.lds_user) + j * 8;
@@ -388,6 +401,8 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
             leaf.zy    = __shfl(leaf.zy, j, 64);
             leaf.depth = __shfl(leaf.depth, j, 64);
         }
+        TW_MS(z6);
+        TW_MA(x_mir, z5, z6);
     }
     if (owner) {
         if (sv.on) {
@@ -401,6 +416,11 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
 #ifdef TW_ABLATE
     {   // wave-level: cycles from lane 0; per-lane counters: sum and max over the wave's owners
         unsigned long long mx = c_inner, sm = owner ? c_inner : 0, ds = owner ? c_desc : 0;
+        unsigned long long own_work = c_pre + c_dsc + c_bp;      // wave-uniform clock: the max over the lanes is the wave's own tree work
+        for (int o = 32; o; o >>= 1) {
+            const unsigned long long w2 = ((unsigned long long)__shfl_xor((unsigned)(own_work >> 32), o, 64) << 32) | __shfl_xor((unsigned)own_work, o, 64);
+            own_work = w2 > own_work ? w2 : own_work;
+        }
         for (int o = 32; o; o >>= 1) {
             const unsigned long long m2 = ((unsigned long long)__shfl_xor((unsigned)(mx >> 32), o, 64) << 32) | __shfl_xor((unsigned)mx, o, 64);
             mx = m2 > mx ? m2 : mx;
@@ -412,6 +432,8 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_ke
             if constexpr (Eng::SPLIT) { for (int i = 0; i < 5; ++i) atomicAdd(&g_mcts_stamps[8 + i], eng.stq[i]); }
             atomicAdd(&g_mcts_stamps[13], c_pre); atomicAdd(&g_mcts_stamps[14], c_dsc); atomicAdd(&g_mcts_stamps[15], c_bp);
             atomicAdd(&g_mcts_stamps[3], sm); atomicAdd(&g_mcts_stamps[4], mx); atomicAdd(&g_mcts_stamps[5], ds); atomicAdd(&g_mcts_stamps[6], 1ull);
+            atomicAdd(&g_mcts_stamps[16], x_or); atomicAdd(&g_mcts_stamps[17], x_rows); atomicAdd(&g_mcts_stamps[18], x_eng);
+            atomicAdd(&g_mcts_stamps[19], x_own); atomicAdd(&g_mcts_stamps[20], x_mir); atomicAdd(&g_mcts_stamps[21], own_work);
         }
     }
 #endif
@@ -429,20 +451,22 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC, NW, PERSIST>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
-    unsigned long long zeros[16] = {0};
+    unsigned long long zeros[24] = {0};
     if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mcts_stamps), zeros, sizeof(zeros)));
 #endif
     hipLaunchKernelGGL((mcts_f32_kernel<NT, NC, NW, PERSIST>), dim3((unsigned)nb), dim3(64 * G::WAVES), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
-        unsigned long long h[16];
+        unsigned long long h[24];
         TW_HIP(hipStreamSynchronize(s));
         TW_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mcts_stamps), sizeof(h)));
         const double w = (double)h[6];
         fprintf(stderr, "mcts stamps: waves %.0f | per wave: fwd %.0f cyc, tree %.0f cyc, trips %.1f | per trip: fwd %.0f, tree %.0f | inner per lane-trip %.2f, max-lane inner per trip %.2f, descents per inner %.2f\n",
                 w, h[0] / w, h[1] / w, h[2] / w, (double)h[0] / h[2], (double)h[1] / h[2], (double)h[3] / (32.0 * h[2]), (double)h[4] / h[2], (double)h[5] / (double)h[3]);
         fprintf(stderr, "  tree phase per trip: expand+sample %.0f, descents %.0f, backprops %.0f\n", (double)h[13] / h[2], (double)h[14] / h[2], (double)h[15] / h[2]);
+        fprintf(stderr, "  per trip: loop-top barrier %.0f, rows_of %.0f, engine forward %.0f, (softmax = fwd - these), owner block %.0f (of which expand/descend/backprop, busiest lane %.0f), mirror + barrier %.0f\n",
+                (double)h[16] / h[2], (double)h[17] / h[2], (double)h[18] / h[2], (double)h[19] / h[2], (double)h[21] / h[2], (double)h[20] / h[2]);
         fprintf(stderr, "  split engine per trip: prologue %.0f, chunk compute %.0f, vmcnt wait %.0f, barrier wait %.0f, heads %.0f\n",
                 (double)h[8] / h[2], (double)h[9] / h[2], (double)h[10] / h[2], (double)h[11] / h[2], (double)h[12] / h[2]);
     }

@@ -1,0 +1,605 @@
+// tw_mcts_deep.hip -- AlphaZero self-play for FEW, DEEP searches: one wave = one episode ("walker"), every policy
+// forward evaluates the leaf each walker is waiting for PLUS frontier nodes of its tree that no search has asked for yet.
+//
+// Same reference semantics as tw_mcts.hip (AZCollector::single_collect, rust/src/collector/az.rs:51-109, over
+// predict_probs_mcts, rust/src/rl/search.rs:104-189), same RNG keys, same arithmetic: bit-identical results.
+//
+// Why a second kernel.  At the reference's batch (4,096 episodes per GPU x 100..1,000 searches per move) the collect is as
+// long as its LONGEST episode's chain of searches: every search needs the value of the previous one (search.rs:132-164), so
+// an episode of 17 moves x 101 evaluations is 1,717 dependent (tree walk -> policy forward) steps however many episodes run
+// beside it.  The lane-per-episode kernel pays one whole forward (~45k cycles for the 16 MFMA columns of a workgroup) plus
+// the slowest lane's tree walk for each of them -- while 2/3 of the columns belong to episodes that are already over.
+// Here a workgroup runs only FOUR episodes at a time on the same 16 (or 32) columns:
+//   * column 0 of a walker's share carries the leaf its search is blocked on (the "demand"), the other 3 (7) columns
+//     carry nodes of its tree that exist but have not been evaluated, in creation order -- UCB with an untrained
+//     (flat) prior visits nodes nearly breadth-first, so 60 % (77 %) of the later demands find their network output already
+//     stored in the node and the search goes on without waiting for a forward (measured: scripts/spec_sim.py);
+//   * a policy forward is a pure function of the board, evaluated per MFMA column as one k-ordered fma chain: which column
+//     and which batch evaluates a node does not change a bit of its output.  Every node is evaluated at most once and its
+//     output consumed at most once -- nothing is cached across demands (the root of every move is evaluated again, as the
+//     reference does);
+//   * the tree walk is wave-parallel instead of lane-serial: the (up to four) children of a node are scored by four lanes,
+//     expanded by four lanes, the search path lives one level per lane (back-propagation is ONE store instruction);
+//   * workgroups are persistent: a walker whose episode is over takes the next one from the queue (start boards from
+//     init_boards_kernel), its tree arena is reused.
+// A 64-byte node record (DeepNode) holds the statistics, the board and the stored network output.
+#include "tw_engine.hpp"
+
+namespace tw {
+
+struct __attribute__((aligned(16))) DeepNode {
+    uint4 q0;   // HOT quad: value_sum (f32 bits), visit_count, prior (f32 bits), link = child_base | n_children << 24 | action << 27 | has_output << 29
+                //           -- for the first `lds_nodes` nodes of a tree this quad lives in LDS instead (same layout)
+    uint4 q1;   // board.lo, board.hi, parent, depth
+    uint4 q2;   // masked-softmax probs[4] of full_predict (f32 bits), once evaluated ahead of the search
+    uint4 q3;   // network value (f32 bits), 0, 0, 0
+};
+static_assert(sizeof(DeepNode) == 64, "DeepNode must be 64 bytes");
+size_t mcts_deep_node_bytes() { return sizeof(DeepNode); }
+
+constexpr uint32_t DNONE = 0xffffffffu;
+constexpr int DEEP_WALKERS = 4;          // walkers (= waves) per workgroup
+constexpr int DEEP_POOL = 24;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
+constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
+enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
+
+__device__ __forceinline__ uint32_t rdl(uint32_t v, int lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform); }
+__device__ __forceinline__ float    rdlf(float v, int lane_uniform) { return __uint_as_float(rdl(__float_as_uint(v), lane_uniform)); }
+__device__ __forceinline__ int      uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t lk_nch(uint32_t link) { return (link >> 24) & 7u; }
+__device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >> 27) & 3u); }
+
+// floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | pool idx [POOL] | pool outputs [POOL][8]
+__host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes)
+{
+    return (size_t)columns * 10 + (size_t)DEEP_WALKERS * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);
+}
+
+#ifdef TW_ABLATE
+__device__ unsigned long long g_deep_stamps[16];
+#endif
+
+template <int NT, int NC, int NW>
+__global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
+{
+    using Eng = typename Geom<NT, NC, 0, NW>::Eng;
+    typedef unsigned int ux4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int ux2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) ux4 lds_u4;
+    typedef __attribute__((address_space(3))) ux2 lds_u2;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) float lds_f32;
+    constexpr int C = Eng::EPB, CPW = C / DEEP_WALKERS;    // MFMA columns of the workgroup, columns per walker
+    static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WALKERS && CPW >= 2, "one walker per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Eng eng;
+    eng.begin1(a.pol, lds);
+
+    const PuzzleConsts env = a.env;
+    const int lane = eng.lane, wave = eng.wave;
+    const int col  = eng.ep_lane();                           // this lane's MFMA column in the engine's mapping
+    const uint32_t NL = a.lds_nodes;                          // nodes of a tree whose hot quad lives in LDS
+    float *xbase = lds + Eng::lds_floats(a.pol.obs_size);
+    uint2 *req = reinterpret_cast<uint2 *>(xbase);                               // request boards [C]
+    float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
+    float *wbase = res + 8 * C + (size_t)wave * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
+    lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
+    lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 4);                         // pool: node index (DNONE = free)
+    lds_f32 *pout = (lds_f32 *)(wbase + (size_t)NL * 4 + DEEP_POOL);             // pool: probs[4], value, - - -
+
+    const uint32_t S = a.num_searches, MED = a.max_expand_depth;
+    const uint64_t E = a.num_episodes;
+    const uint64_t slot = (uint64_t)blockIdx.x * DEEP_WALKERS + (uint64_t)wave;        // walker = tree arena index
+    DeepNode *nodes = reinterpret_cast<DeepNode *>(a.arena) + slot * (uint64_t)a.node_cap;
+
+    // hot quad of node idx: LDS for the first NL nodes of the tree, the arena beyond
+    auto hot_ld = [&](uint32_t idx) -> ux4 { if (idx < NL) return tbl[idx]; return *reinterpret_cast<const ux4 *>(&nodes[idx].q0); };
+    auto hot_st = [&](uint32_t idx, ux4 v) { if (idx < NL) tbl[idx] = v; else *reinterpret_cast<ux4 *>(&nodes[idx].q0) = v; };
+    auto hot_st_stats = [&](uint32_t idx, float vs, uint32_t vis) {                // value_sum, visit_count: one 8-byte store
+        ux2 w; w.x = __float_as_uint(vs); w.y = vis;
+        if (idx < NL) *reinterpret_cast<lds_u2 *>(tbl + idx) = w;
+        else *reinterpret_cast<ux2 *>(&nodes[idx].q0) = w;
+    };
+    auto hot_st_link = [&](uint32_t idx, uint32_t link) {
+        if (idx < NL) reinterpret_cast<lds_u32 *>(tbl + idx)[3] = link;
+        else reinterpret_cast<uint32_t *>(&nodes[idx].q0)[3] = link;
+    };
+
+    // ---- walker state (wave-uniform) ----------------------------------------------------------------------------------
+    PuzzleLane st;  st.board = env.ident; st.zx = 0; st.zy = 0; st.depth = 0;      // the episode's env (az.rs:56-57)
+    PuzzleLane cur = st;                                                            // state of `node` (the leaf being worked on)
+    uint64_t e_local = slot, e_global = a.episode_offset + slot, rec_base = 0;
+    int      phase = DP_DEAD;
+    int      t = 0;
+    uint32_t it = 0, expanded = 0, node = 0, n_nodes = 0, cursor = 1, cur_link = 0;
+    float    value = 0.0f;
+    float    root_vs = 0.0f; uint32_t root_visit = 0, root_cb = 0, root_nc = 0;
+    uint32_t dem_idx = 0;
+    unsigned long long evals = 0, spec_evals = 0;
+    bool more = true;
+    // search path, one level per lane: node index, value_sum and visit_count read on the way down
+    uint32_t p_idx = 0, p_vis = 0; float p_vs = 0.0f; int plen = 0; bool overflow = false;
+    // the request this lane issued ahead of the search in the last assembly (stored into its node when the forward is done)
+    bool my_take = false; uint32_t my_idx = 0; int my_rank = 0;
+    uint32_t pool_head = 0; int n_spec = 0;
+
+    auto take = [&](uint64_t e) {
+        e_local = e; e_global = a.episode_offset + e; rec_base = e * (uint64_t)a.out.t_pad;
+        st.board = a.init_boards[e];
+        const int z = blank_cell(st.board);
+        st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
+        t = 0; phase = DP_ROOT;
+    };
+    if (slot < E) take(slot);
+    if (lane < DEEP_POOL) pidx[lane] = DNONE;
+
+    uint32_t obs_base[4];
+    obs_base_words(env.n_cells, obs_base);
+
+    auto push = [&](uint32_t idx, float vs, uint32_t vis) {
+        if (plen < 64) { if (lane == plen) { p_idx = idx; p_vs = vs; p_vis = vis; } ++plen; }
+        else overflow = true;
+    };
+
+    // request columns of this walker for the next forward: the demand + up to CPW-1 unevaluated frontier nodes in creation order
+    auto assemble = [&]() {
+        my_take = false; n_spec = 0;
+        const uint64_t ident = env.ident;
+        if (phase == DP_DEAD) {
+            if (lane < CPW) req[wave * CPW + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
+            return;
+        }
+        uint64_t db = cur.board;
+        if (phase == DP_ROOT) db = st.board;
+        if (lane == 0) req[wave * CPW] = make_uint2((uint32_t)db, (uint32_t)(db >> 32));
+        // 64 candidates in one round trip: nodes cursor .. cursor+63
+        const uint32_t idx = cursor + (uint32_t)lane;
+        const bool in_tree = phase == DP_LEAF && idx < n_nodes;         // (a new move's tree does not exist yet)
+        uint4 c1 = make_uint4(0, 0, 0, 0); ux4 ch = {0u, 0u, 0u, 0u};
+        if (in_tree) { c1 = nodes[idx].q1; ch = hot_ld(idx); }
+        const uint64_t cb64 = ((uint64_t)c1.y << 32) | c1.x;
+        // a node needs the network if it is not final (search.rs:149), not expanded and holds no output yet
+        const bool valid = in_tree && !(ch.w & LK_OUT) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && idx != dem_idx;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
+        const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        const int n_valid = __builtin_popcountll(m);
+        if (valid && rank < CPW - 1) {
+            req[wave * CPW + 1 + rank] = make_uint2(c1.x, c1.y);
+            my_take = true; my_idx = idx; my_rank = rank;
+        }
+        const int n_take = n_valid < CPW - 1 ? n_valid : CPW - 1;
+        if (lane >= 1 + n_take && lane < CPW) req[wave * CPW + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
+        // everything below the cursor is evaluated, expanded, final or being evaluated now
+        uint32_t nc2;
+        if (n_valid >= CPW - 1) {
+            const unsigned long long last = __builtin_amdgcn_ballot_w64(valid && rank == CPW - 2);
+            nc2 = cursor + (uint32_t)__builtin_ctzll(last) + 1u;
+        } else {
+            nc2 = cursor + 64u < n_nodes ? cursor + 64u : (phase == DP_LEAF ? n_nodes : cursor);
+        }
+        cursor = nc2;
+        n_spec = n_take;
+        spec_evals += (unsigned long long)n_take;
+    };
+
+    eng.begin2();
+    assemble();
+
+#ifdef TW_ABLATE
+    unsigned long long c_fwd = 0, c_tree = 0, c_bar = 0, c_trips = 0, c_search = 0, c_hits = 0, c_asm = 0;
+    unsigned long long c_pre = 0, c_desc = 0, c_leaf = 0, c_bp = 0, c_fin = 0, c_res = 0, c_lvl = 0;
+#define TW_DS(var) const unsigned long long var = __builtin_readcyclecounter()
+#define TW_DA(acc, x, y) acc += (y) - (x)
+#else
+#define TW_DS(var)
+#define TW_DA(acc, x, y)
+#endif
+    for (;;) {
+        TW_DS(z0);
+        if (!__syncthreads_or(phase != DP_DEAD ? 1 : 0)) break;
+        TW_DS(z1);
+        TW_DA(c_bar, z0, z1);
+        // ---- Policy::full_predict of the C requested boards (policy.rs:102-126) -------------------------------------
+        {
+            const uint2 rb = req[col];
+            const uint64_t board = ((uint64_t)rb.y << 32) | rb.x;
+            float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
+            const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
+            const float np = (float)eng.pol.n_perms;
+            for (int pass = 0; pass < n_pass; ++pass) {
+                const int perm = eng.pol.n_perms > 0 ? pass : -1;
+                int rowoff[NC];
+                eng.rows_of(board, env.n_cells, perm, rowoff);
+                float lg[4], v;
+                eng.forward(rowoff, lg, v);
+                eng.act_perm(perm, lg);
+                if (eng.pol.n_perms > 0) {
+                    vsum = vsum + v / np;                                            // policy.rs:111
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lsum[i] = lsum[i] + lg[i] / np;      // policy.rs:112-114
+                } else {
+                    vsum = v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lsum[i] = lg[i];
+                }
+            }
+            PuzzleLane lf; lf.board = board; lf.depth = 0;
+            const int z = blank_cell(board);
+            lf.zx = z % env.width; lf.zy = z / env.width;
+            float probs[4];
+            masked_softmax4(lsum, puzzle_maskbits(lf, env), probs);
+            // every wave holds every column's output: wave w publishes the columns of walker w, for itself
+            if (eng.h == 0 && col / CPW == wave) {
+                float4 *dst = reinterpret_cast<float4 *>(res + col * 8);
+                dst[0] = make_float4(probs[0], probs[1], probs[2], probs[3]);
+                dst[1] = make_float4(vsum, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        TW_DS(z2);
+        TW_DA(c_fwd, z1, z2);
+#ifdef TW_ABLATE
+        ++c_trips;
+#endif
+
+        // ---- tree phase of this wave's walker ------------------------------------------------------------------------
+        if (phase != DP_DEAD) {
+            TW_DS(y0);
+            // outputs evaluated ahead of the search -> their nodes (arena) and the LDS pool; the node's hot quad gets the flag
+            if (my_take) {
+                const float4 *src = reinterpret_cast<const float4 *>(res + (wave * CPW + 1 + my_rank) * 8);
+                const float4 pr = src[0]; const float4 vv = src[1];
+                nodes[my_idx].q2 = make_uint4(__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w));
+                nodes[my_idx].q3 = make_uint4(__float_as_uint(vv.x), 0u, 0u, 0u);
+                const uint32_t ps = (pool_head + (uint32_t)my_rank) % (uint32_t)DEEP_POOL;
+                pidx[ps] = my_idx;
+                lds_f32 *po = pout + ps * 8;
+                po[0] = pr.x; po[1] = pr.y; po[2] = pr.z; po[3] = pr.w; po[4] = vv.x;
+                const ux4 hq = hot_ld(my_idx);
+                hot_st_link(my_idx, hq.w | LK_OUT);
+                my_take = false;
+            }
+            pool_head = (pool_head + (uint32_t)n_spec) % (uint32_t)DEEP_POOL;
+            // the demanded output
+            float probs[4], nn_value;
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(res + (wave * CPW) * 8);
+                const float4 pr = src[0]; const float4 vv = src[1];
+                probs[0] = pr.x; probs[1] = pr.y; probs[2] = pr.z; probs[3] = pr.w; nn_value = vv.x;
+            }
+
+            const int ca = lane & 3;                               // the child / action this lane works on
+            // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step; four lanes, one child each
+            float pri[4] = {0.0f, 0.0f, 0.0f, 0.0f};               // priors of the children just created, in child order
+            uint32_t act_mask = 0;                                 // bit a: action a got a child
+            auto expand = [&](uint32_t idx, uint32_t idx_link, const PuzzleLane s, const float (&pb)[4]) -> uint32_t {
+                const float mine = ca == 0 ? pb[0] : (ca == 1 ? pb[1] : (ca == 2 ? pb[2] : pb[3]));
+                const bool has = mine > 0.0f;
+                act_mask = (uint32_t)(__builtin_amdgcn_ballot_w64(has && lane < 4)) & 15u;
+                const uint32_t cnt = (uint32_t)__builtin_popcount(act_mask);
+                const uint32_t pos = (uint32_t)__builtin_popcount(act_mask & ((1u << ca) - 1u));
+                PuzzleLane c = s;
+                puzzle_step(c, env, ca);
+                if (has && lane < 4) {
+                    const uint32_t ni = n_nodes + pos;
+                    hot_st(ni, ux4{0u, 0u, __float_as_uint(mine), (uint32_t)ca << 27});
+                    nodes[ni].q1 = make_uint4((uint32_t)c.board, (uint32_t)(c.board >> 32), idx, (uint32_t)c.depth);
+                }
+                if (lane == 0) hot_st_link(idx, (idx_link & ~(LK_CB | (7u << 24))) | n_nodes | (cnt << 24));
+                // priors in child order (uniform)
+                uint32_t k = 0;
+#pragma unroll
+                for (int act = 0; act < 4; ++act) {
+                    if (!((act_mask >> act) & 1u)) continue;
+                    if (k == 0) pri[0] = pb[act]; else if (k == 1) pri[1] = pb[act]; else if (k == 2) pri[2] = pb[act]; else pri[3] = pb[act];
+                    ++k;
+                }
+                n_nodes += cnt;
+                return cnt;
+            };
+            // next_sample (search.rs:94-100): a child of `node` by its priors; `cur` follows
+            auto sample_child = [&](uint32_t cb, uint32_t nch) {
+                const u32x4 w = rng_draw(a.seed, e_global, it * MED + expanded, STREAM_MCTS | ((uint32_t)t << 8));
+                const int k = sample_weighted4(pri, (int)nch, u32_to_unit(w.x));
+                int act = 0, seen = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if ((act_mask >> x) & 1u) { if (seen == k) act = x; ++seen; }
+                node = cb + (uint32_t)k;
+                puzzle_step(cur, env, act);
+                cur_link = (uint32_t)act << 27;
+                push(node, 0.0f, 0u);
+            };
+            // backpropagate (search.rs:45-53): value_sum += v, visit_count += 1 on every node of the path -- one store per level
+            auto backprop = [&](uint32_t idx, float val) {
+                if (!overflow) {
+                    if (lane < plen && p_idx != 0u) hot_st_stats(p_idx, p_vs + val, p_vis + 1u);   // (the root's statistics live in registers)
+                } else if (lane == 0) {
+                    while (idx != DNONE && idx != 0u) {
+                        const ux4 hq = hot_ld(idx);
+                        hot_st_stats(idx, __uint_as_float(hq.x) + val, hq.y + 1u);
+                        idx = nodes[idx].q1.z;
+                    }
+                }
+                root_vs = root_vs + val; root_visit += 1u;
+            };
+
+            bool resume = false;
+            TW_DS(y1);
+            TW_DA(c_pre, y0, y1);
+            if (phase == DP_ROOT) {
+                // root node (search.rs:120-129): visit_count 1, expanded with the root priors
+                ++evals;
+                n_nodes = 1; cursor = 1;
+                if (lane < DEEP_POOL) pidx[lane] = DNONE;                // outputs of the previous move's tree
+                root_vs = 0.0f; root_visit = 1u; root_cb = 1u;
+                root_nc = expand(0u, 0u, st, probs);
+                it = 0;
+                phase = DP_LEAF;
+            } else {
+                resume = true;                                   // the leaf `node` just got its output
+            }
+
+            for (;;) {
+#ifdef TW_ABLATE
+                ++c_search;
+#endif
+                bool need_nn = false;
+                TW_DS(y2);
+                if (!resume) {
+                    if (it == S) {
+                        // ---- move finished: visit counts -> probs (search.rs:166-188) ------------------------------
+                        float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (root_nc > 0) {
+                            const ux4 rq = hot_ld(root_cb + ((uint32_t)ca < root_nc ? (uint32_t)ca : root_nc - 1u));
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if ((uint32_t)c >= root_nc) continue;
+                                const int act = lk_act(rdl(rq.w, c));
+                                const float vis = (float)rdl(rq.y, c);
+                                mp[0] = act == 0 ? vis : mp[0]; mp[1] = act == 1 ? vis : mp[1];
+                                mp[2] = act == 2 ? vis : mp[2]; mp[3] = act == 3 ? vis : mp[3];
+                            }
+                        }
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sum = sum + mp[i];
+                        if (sum > 0.0f) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) mp[i] = mp[i] / sum;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) mp[i] = 1.0f / 4.0f;
+                        }
+                        // az.rs:72-81: action = sample(mcts_probs); val = env.reward(); store the record
+                        const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
+                        const int action = sample_weighted4(mp, 4, u32_to_unit(w.x));
+                        if (lane == 0) {
+                            uint32_t pk[4];
+                            obs_bytes(st.board, obs_base, pk);
+                            store_rec(a.out.rec + rec_base + (uint64_t)t, pk, mp, 0.0f, puzzle_reward(st, env), 0, -1);
+                        }
+                        if (puzzle_final(st, env)) {                                                     // az.rs:84
+                            if (lane == 0) a.out.ep_len[e_local] = (uint32_t)t + 1u;
+                            unsigned got = 0xffffffffu;
+                            if (more) {
+                                if (lane == 0) got = atomicAdd(a.queue, 1u);
+                                got = (unsigned)uni((int)got);
+                            }
+                            if ((uint64_t)got < E) take((uint64_t)got);
+                            else { more = false; phase = DP_DEAD; }
+                            TW_DS(y9); TW_DA(c_fin, y2, y9);
+                            break;
+                        }
+                        puzzle_step(st, env, action);                                                   // az.rs:89
+                        ++t;
+                        phase = DP_ROOT;
+                        TW_DS(y9); TW_DA(c_fin, y2, y9);
+                        break;
+                    }
+                    // ---- descend to a leaf by UCB (search.rs:133-138, next :77-91, ucb :29-39): four lanes score the four
+                    //      children; the state follows the chosen actions (a child's state IS step(parent state, action))
+                    node = 0; plen = 0; overflow = false;
+                    push(0u, root_vs, root_visit);
+                    uint32_t cur_nc = root_nc, cur_cb = root_cb, cur_visit = root_visit;
+                    cur = st; cur_link = 0u;                   // (a root without children is evaluated again, like any childless node)
+                    while (cur_nc > 0) {
+                        const ux4 kq = hot_ld(cur_cb + ((uint32_t)ca < cur_nc ? (uint32_t)ca : cur_nc - 1u));
+                        const float sq = sqrtf((float)cur_visit);
+                        const float qv = kq.y == 0u ? 0.0f : __uint_as_float(kq.x) / (float)kq.y;
+                        float d = sq / ((float)kq.y + 1.0f);
+                        d = a.C * d;
+                        d = d * __uint_as_float(kq.z);
+                        const float u = qv + d;
+                        int best = -1; float best_ucb = -__builtin_inff();
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float uc = rdlf(u, c);
+                            if ((uint32_t)c < cur_nc && uc > best_ucb) { best = c; best_ucb = uc; }
+                        }
+                        if (best < 0) break;                       // all-NaN UCB: the reference panics here
+                        best = uni(best);
+                        node = cur_cb + (uint32_t)best;
+                        const uint32_t bvs = rdl(kq.x, best), bvis = rdl(kq.y, best);
+                        cur_link = rdl(kq.w, best);
+                        puzzle_step(cur, env, lk_act(cur_link));
+                        push(node, __uint_as_float(bvs), bvis);
+                        cur_cb = cur_link & LK_CB; cur_nc = lk_nch(cur_link); cur_visit = bvis;
+#ifdef TW_ABLATE
+                        ++c_lvl;
+#endif
+                    }
+                    value = 0.0f; expanded = 0;
+                    TW_DS(y3); TW_DA(c_desc, y2, y3);
+                    // leaf phase (search.rs:143-160)
+                    while (expanded < MED) {
+                        value = puzzle_reward(cur, env);                                  // :146
+                        if (puzzle_final(cur, env)) break;                                // :149
+                        if (!(cur_link & LK_OUT)) { need_nn = true; break; }              // :154 needs the network: demand it
+                        // the node was evaluated ahead of this search: take its output (LDS pool, else the arena) and go on
+                        float lp[4]; float lv;
+                        {
+                            const bool hit = lane < DEEP_POOL && pidx[lane < DEEP_POOL ? lane : 0] == node;
+                            const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+                            if (hm != 0ull) {
+                                const int ps = __builtin_ctzll(hm);
+                                lds_f32 *po = pout + ps * 8;
+                                lp[0] = po[0]; lp[1] = po[1]; lp[2] = po[2]; lp[3] = po[3]; lv = po[4];
+                                if (lane == ps) pidx[ps] = DNONE;
+                            } else {
+                                const uint4 o2 = nodes[node].q2; const uint4 o3 = nodes[node].q3;
+                                lp[0] = __uint_as_float(o2.x); lp[1] = __uint_as_float(o2.y); lp[2] = __uint_as_float(o2.z); lp[3] = __uint_as_float(o2.w);
+                                lv = __uint_as_float(o3.x);
+                            }
+                        }
+                        ++evals;
+#ifdef TW_ABLATE
+                        ++c_hits;
+#endif
+                        const uint32_t cb = n_nodes;
+                        const uint32_t nch = expand(node, cur_link, cur, lp);             // :156
+                        cur_link &= ~LK_OUT;                                              // (no children: the same node is looked at again)
+                        if (nch > 0) sample_child(cb, nch);                               // :157
+                        value = lv;                                                       // :158
+                        ++expanded;
+                    }
+                    TW_DS(y4); TW_DA(c_leaf, y3, y4);
+                } else {
+                    // ---- the demanded leaf's output has arrived (search.rs:154-159): expand, sample a child by the priors ---
+                    resume = false;
+                    ++evals;
+                    const uint32_t cb = n_nodes;
+                    const uint32_t nch = expand(node, cur_link, cur, probs);
+                    if (nch > 0) sample_child(cb, nch);
+                    value = nn_value;
+                    ++expanded;
+                    // further expansion levels of the same search (max_expand_depth > 1): the child sampled a moment ago holds no
+                    // output yet, so unless it is a final state it is the next demand
+                    if (expanded < MED) {
+                        value = puzzle_reward(cur, env);
+                        need_nn = !puzzle_final(cur, env);
+                    }
+                    TW_DS(y5); TW_DA(c_res, y2, y5);
+                }
+                if (need_nn) { dem_idx = node; break; }
+                TW_DS(y6);
+                backprop(node, value);                                                    // :163
+                ++it;
+                TW_DS(y7); TW_DA(c_bp, y6, y7);
+            }
+        }
+        TW_DS(z3);
+        TW_DA(c_tree, z2, z3);
+        assemble();
+        TW_DS(z4);
+        TW_DA(c_asm, z3, z4);
+    }
+    if (lane == 0) { atomicAdd(a.eval_count, evals); atomicAdd(a.eval_count + 1, spec_evals); }
+#ifdef TW_ABLATE
+    if (lane == 0) {
+        atomicAdd(&g_deep_stamps[0], c_fwd); atomicAdd(&g_deep_stamps[1], c_tree); atomicAdd(&g_deep_stamps[2], c_bar);
+        atomicAdd(&g_deep_stamps[3], c_trips); atomicAdd(&g_deep_stamps[4], c_search); atomicAdd(&g_deep_stamps[5], c_hits);
+        atomicAdd(&g_deep_stamps[6], 1ull); atomicAdd(&g_deep_stamps[7], c_asm);
+        atomicAdd(&g_deep_stamps[8], c_pre); atomicAdd(&g_deep_stamps[9], c_desc); atomicAdd(&g_deep_stamps[10], c_leaf);
+        atomicAdd(&g_deep_stamps[11], c_bp); atomicAdd(&g_deep_stamps[12], c_fin); atomicAdd(&g_deep_stamps[13], c_res); atomicAdd(&g_deep_stamps[14], c_lvl);
+    }
+#endif
+    eng.end();
+}
+
+// ---- launch ---------------------------------------------------------------------------------------------------------
+// The deep shape serves AlphaZero self-play of up to DEEP_MAX_EPISODES episodes on policies the 16-episode engine supports
+// (128 or 256 hidden units); everything else runs the lane-per-episode kernel of tw_mcts.hip.
+constexpr uint64_t DEEP_MAX_EPISODES = 40960;
+
+bool mcts_deep_applies(const MctsArgs &a)
+{
+    const int force = launch_options().force_geom;
+    if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
+    if (force == 8 || force == 1) return false;                 // diagnostic: pin the lane-per-episode shapes
+    return a.num_episodes <= DEEP_MAX_EPISODES;
+}
+
+uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus)
+{
+    const int cus = device_cus();
+    const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
+    const uint64_t blocks = (num_episodes + DEEP_WALKERS - 1) / DEEP_WALKERS;
+    return (blocks < (uint64_t)(cus - r) ? blocks : (uint64_t)(cus - r)) * DEEP_WALKERS;
+}
+
+template <int NT, int NC, int NW>
+static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    using G = Geom<NT, NC, 0, NW>;
+    constexpr int C = G::Eng::EPB;
+    const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus) / DEEP_WALKERS;
+    // the hot quads of the first lds_nodes nodes of every tree live in LDS: as many as fit beside the engine
+    MctsArgs b = a;
+    const size_t eng_floats = G::Eng::lds_floats(a.pol.obs_size);
+    const size_t budget = (size_t)159 * 1024 / sizeof(float);
+    if (eng_floats + deep_extra_floats(C, 0) > budget) { set_error("mcts (deep): the policy engine alone needs %zu bytes of LDS", eng_floats * 4); return TW_ERR_UNSUPPORTED; }
+    size_t nl = (budget - eng_floats - deep_extra_floats(C, 0)) / ((size_t)DEEP_WALKERS * 4);
+    if (nl > a.node_cap) nl = a.node_cap;
+    b.lds_nodes = (uint32_t)nl;
+    const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes)) * sizeof(float);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW>), lds_bytes)) return rc;
+#ifdef TW_ABLATE
+    unsigned long long zeros[16] = {0};
+    if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros)));
+#endif
+    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(256), lds_bytes, s, b);
+    TW_HIP(hipGetLastError());
+#ifdef TW_ABLATE
+    if (getenv("TW_STAMPS")) {
+        unsigned long long h[16];
+        TW_HIP(hipStreamSynchronize(s));
+        TW_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_deep_stamps), sizeof(h)));
+        const double w = (double)h[6], tr = (double)h[3];
+        fprintf(stderr, "deep stamps: waves %.0f, lds nodes %u | per wave: fwd %.0f, tree %.0f, assembly %.0f, barrier wait %.0f cycles, trips %.1f | per trip: fwd %.0f, tree %.0f, assembly %.0f, barrier %.0f | "
+                        "search-loop passes per trip %.2f, stored outputs consumed per trip %.2f\n",
+                w, b.lds_nodes, h[0] / w, h[1] / w, h[7] / w, h[2] / w, tr / w, h[0] / tr, h[1] / tr, h[7] / tr, h[2] / tr, (double)h[4] / tr, (double)h[5] / tr);
+        fprintf(stderr, "  tree phase per trip: store ahead-outputs + read demand %.0f | descents %.0f (%.2f levels per trip) | leaf phase incl. stored-output expansions %.0f | "
+                        "resume (expand demanded leaf) %.0f | backprops %.0f | move finish %.0f\n",
+                h[8] / tr, h[9] / tr, h[14] / tr, h[10] / tr, h[13] / tr, h[11] / tr, h[12] / tr);
+    }
+#endif
+    if (blocks) *blocks = (uint32_t)nb;
+    if (threads) *threads = 256;
+    return TW_OK;
+}
+
+template <int NT>
+static int launch_deep_nt(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    const int nc = a.env.n_cells;
+    const bool wide = launch_options().force_geom == 32;          // diagnostic: 32 columns (8 per walker) instead of 16 (4 per walker)
+    if (wide) {
+        if (nc <= 4) return launch_deep_geom<NT, 4, -4>(a, s, blocks, threads);
+        if (nc <= 9) return launch_deep_geom<NT, 9, -4>(a, s, blocks, threads);
+        return launch_deep_geom<NT, 16, -4>(a, s, blocks, threads);
+    }
+    if (nc <= 4) return launch_deep_geom<NT, 4, -16>(a, s, blocks, threads);
+    if (nc <= 9) return launch_deep_geom<NT, 9, -16>(a, s, blocks, threads);
+    return launch_deep_geom<NT, 16, -16>(a, s, blocks, threads);
+}
+
+int launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    const uint64_t need = 5ull + 4ull * a.num_searches * (a.max_expand_depth ? a.max_expand_depth : 1u);
+    if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.obs_size > 256 ||
+        a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 || a.out.t_pad < a.env.depth0 + 1 || a.node_cap < need ||
+        !a.arena || !a.eval_count || !a.queue || !a.init_boards || a.solve.on) {
+        set_error("mcts (deep): unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d node_cap=%u need=%llu)",
+                  a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad, a.node_cap, (unsigned long long)need);
+        return TW_ERR_UNSUPPORTED;
+    }
+    switch (a.pol.hidden) {
+        case 128: return launch_deep_nt<4>(a, s, blocks, threads);
+        case 256: return launch_deep_nt<8>(a, s, blocks, threads);
+        default: set_error("mcts (deep): hidden size %d not in {128,256}", a.pol.hidden); return TW_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace tw

@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) solve_f32_k
                 for (int i = 1; i < 4; ++i) if (probs[i] > bv) { bv = probs[i]; action = i; }
             } else {                                                  // sample (policy.rs:153-167)
                 const u32x4 w = rng_draw(a.seed, key, (uint32_t)t, STREAM_SOLVE);
-                action = sample_weighted(probs, 4, u32_to_unit(w.x));
+                action = sample_weighted4(probs, 4, u32_to_unit(w.x));
             }
             if (a.actions && writer) a.actions[att * (uint64_t)a.t_pad + (uint64_t)t] = (uint8_t)action;
             puzzle_step(st, env, action);                             // solve.rs:56
