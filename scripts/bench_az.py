@@ -15,10 +15,14 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--searches", type=int, default=100)
 ap.add_argument("--difficulty", type=int, default=8)
 ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--geom", type=int, default=0, help="diagnostic: tw_set_launch_option(TW_OPT_FORCE_GEOM)")
+ap.add_argument("--variant", type=int, default=0, help="diagnostic: tw_set_launch_option(TW_OPT_AZ_VARIANT)")
 args = ap.parse_args()
 
 import twisterl_amd
-from twisterl_amd import twisterl
+from twisterl_amd import _lib, twisterl
+_lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_FORCE_GEOM, args.geom))
+_lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_AZ_VARIANT, args.variant))
 policy = build_policy(synthetic_weights(16, seed=0), [], [])      # AZ clears the twists (rl/az.py:24-26)
 env = twisterl.env.Puzzle(4, 4, args.difficulty, 2, 256)
 coll = twisterl.collector.AZCollector(args.envs, args.searches, 1.41, 1, 32)
@@ -30,5 +34,6 @@ for i in range(args.steps):
 dt = time.perf_counter() - t0
 print(json.dumps({"metric": "MCTS leaf evaluations/s (Puzzle-15 AlphaZero self-play, 1 GPU)", "value": ev / dt,
                   "records_per_s": rec / dt, "episodes": args.envs, "num_mcts_searches": args.searches,
-                  "difficulty": args.difficulty, "mcts_kernel_ms": sum(ms) / len(ms),
+                  "difficulty": args.difficulty, "mcts_kernel_ms": sum(ms) / len(ms), "speculative_evals": d.stats["speculative_evals"],
+                  "threads": d.stats["rollout_threads"], "blocks": d.stats["rollout_blocks"],
                   "mfma_tflops": ev / len(ms) * 272896 / (sum(ms) / len(ms) * 1e-3) / 1e12}))

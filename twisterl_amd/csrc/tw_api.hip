@@ -45,8 +45,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 hipStream_t current_stream() { return g_stream; }
 
 // ---------------------------------------------------------------------------------- launch options / per-device caches
-static std::atomic<int> g_force_geom{0}, g_no_persist{0};
-LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load()}; }
+static std::atomic<int> g_force_geom{0}, g_no_persist{0}, g_az_variant{0};
+LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load(), g_az_variant.load()}; }
 
 static std::mutex g_dev_mutex;
 
@@ -207,6 +207,9 @@ extern "C" int tw_set_launch_option(int option, int value)
             if (value != 0 && value != 1 && value != 8 && value != 32) { set_error("TW_OPT_FORCE_GEOM: value %d not in {0, 1, 8, 32}", value); return TW_ERR_INVALID; }
             g_force_geom.store(value); return TW_OK;
         case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
+        case TW_OPT_AZ_VARIANT:
+            if (value < 0 || value > 2) { set_error("TW_OPT_AZ_VARIANT: value %d not in {0, 1, 2}", value); return TW_ERR_INVALID; }
+            g_az_variant.store(value); return TW_OK;
         default: set_error("tw_set_launch_option: unknown option %d", option); return TW_ERR_INVALID;
     }
 }

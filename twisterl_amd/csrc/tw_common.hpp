@@ -30,7 +30,7 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
 hipStream_t current_stream();
 
 // Diagnostic launch overrides (tw_set_launch_option; the tests pin launch shapes with them).  Read once per collect.
-struct LaunchOptions { int force_geom; int no_persist; };
+struct LaunchOptions { int force_geom; int no_persist; int az_variant; };
 LaunchOptions launch_options();
 // Raises a kernel's dynamic-LDS limit above the 64 KiB default; cached per (kernel, device), thread-safe.
 int ensure_dynamic_lds(const void *kernel, size_t bytes);

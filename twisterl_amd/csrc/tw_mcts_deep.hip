@@ -39,13 +39,18 @@ size_t mcts_deep_node_bytes() { return sizeof(DeepNode); }
 
 constexpr uint32_t DNONE = 0xffffffffu;
 constexpr int DEEP_WALKERS = 4;          // walkers (= waves) per workgroup
-constexpr int DEEP_POOL = 24;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
+constexpr int DEEP_POOL = 40;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
 constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
+constexpr unsigned long long DEEP_TREE_BUDGET = 24000;   // cycles of tree walk per trip after which a walker stops at the next search
+                                                          // boundary (all its columns then carry frontier nodes): the other three
+                                                          // walkers and the engine do not wait for one long streak of stored outputs
 
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform); }
 __device__ __forceinline__ float    rdlf(float v, int lane_uniform) { return __uint_as_float(rdl(__float_as_uint(v), lane_uniform)); }
 __device__ __forceinline__ int      uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float    unif(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lk_nch(uint32_t link) { return (link >> 24) & 7u; }
 __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >> 27) & 3u); }
 
@@ -120,12 +125,17 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     // search path, one level per lane: node index, value_sum and visit_count read on the way down
     uint32_t p_idx = 0, p_vis = 0; float p_vs = 0.0f; int plen = 0; bool overflow = false;
     // the request this lane issued ahead of the search in the last assembly (stored into its node when the forward is done)
-    bool my_take = false; uint32_t my_idx = 0; int my_rank = 0;
+    bool my_take = false; uint32_t my_idx = 0; int my_rank = 0, my_slot = 0;
     uint32_t pool_head = 0; int n_spec = 0;
+    bool yielded = false;                                                           // stopped at a search boundary without a demand
 
     auto take = [&](uint64_t e) {
         e_local = e; e_global = a.episode_offset + e; rec_base = e * (uint64_t)a.out.t_pad;
-        st.board = a.init_boards[e];
+        {   // (wave-uniform values the search branches on are made provably uniform where they come from memory: the walk
+            //  then runs on scalar branches instead of exec masks)
+            const uint64_t b0 = a.init_boards[e];
+            st.board = ((uint64_t)uniu((uint32_t)(b0 >> 32)) << 32) | uniu((uint32_t)b0);
+        }
         const int z = blank_cell(st.board);
         st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
         t = 0; phase = DP_ROOT;
@@ -151,7 +161,8 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         }
         uint64_t db = cur.board;
         if (phase == DP_ROOT) db = st.board;
-        if (lane == 0) req[wave * CPW] = make_uint2((uint32_t)db, (uint32_t)(db >> 32));
+        const int col0 = yielded ? 0 : 1;                                // a walker that stopped between two searches has no demand
+        if (lane == 0 && !yielded) req[wave * CPW] = make_uint2((uint32_t)db, (uint32_t)(db >> 32));
         // 64 candidates in one round trip: nodes cursor .. cursor+63
         const uint32_t idx = cursor + (uint32_t)lane;
         const bool in_tree = phase == DP_LEAF && idx < n_nodes;         // (a new move's tree does not exist yet)
@@ -159,20 +170,21 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         if (in_tree) { c1 = nodes[idx].q1; ch = hot_ld(idx); }
         const uint64_t cb64 = ((uint64_t)c1.y << 32) | c1.x;
         // a node needs the network if it is not final (search.rs:149), not expanded and holds no output yet
-        const bool valid = in_tree && !(ch.w & LK_OUT) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && idx != dem_idx;
+        const bool valid = in_tree && !(ch.w & LK_OUT) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && (yielded || idx != dem_idx);
+        const int quota = CPW - col0;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
         const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
         const int n_valid = __builtin_popcountll(m);
-        if (valid && rank < CPW - 1) {
-            req[wave * CPW + 1 + rank] = make_uint2(c1.x, c1.y);
-            my_take = true; my_idx = idx; my_rank = rank;
+        if (valid && rank < quota) {
+            req[wave * CPW + col0 + rank] = make_uint2(c1.x, c1.y);
+            my_take = true; my_idx = idx; my_rank = col0 + rank; my_slot = rank;     // (my_rank: column inside the walker's share)
         }
-        const int n_take = n_valid < CPW - 1 ? n_valid : CPW - 1;
-        if (lane >= 1 + n_take && lane < CPW) req[wave * CPW + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
+        const int n_take = n_valid < quota ? n_valid : quota;
+        if (lane >= col0 + n_take && lane < CPW) req[wave * CPW + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
         // everything below the cursor is evaluated, expanded, final or being evaluated now
         uint32_t nc2;
-        if (n_valid >= CPW - 1) {
-            const unsigned long long last = __builtin_amdgcn_ballot_w64(valid && rank == CPW - 2);
+        if (n_valid >= quota) {
+            const unsigned long long last = __builtin_amdgcn_ballot_w64(valid && rank == quota - 1);
             nc2 = cursor + (uint32_t)__builtin_ctzll(last) + 1u;
         } else {
             nc2 = cursor + 64u < n_nodes ? cursor + 64u : (phase == DP_LEAF ? n_nodes : cursor);
@@ -249,11 +261,11 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
             TW_DS(y0);
             // outputs evaluated ahead of the search -> their nodes (arena) and the LDS pool; the node's hot quad gets the flag
             if (my_take) {
-                const float4 *src = reinterpret_cast<const float4 *>(res + (wave * CPW + 1 + my_rank) * 8);
+                const float4 *src = reinterpret_cast<const float4 *>(res + (wave * CPW + my_rank) * 8);
                 const float4 pr = src[0]; const float4 vv = src[1];
                 nodes[my_idx].q2 = make_uint4(__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w));
                 nodes[my_idx].q3 = make_uint4(__float_as_uint(vv.x), 0u, 0u, 0u);
-                const uint32_t ps = (pool_head + (uint32_t)my_rank) % (uint32_t)DEEP_POOL;
+                const uint32_t ps = (pool_head + (uint32_t)my_slot) % (uint32_t)DEEP_POOL;
                 pidx[ps] = my_idx;
                 lds_f32 *po = pout + ps * 8;
                 po[0] = pr.x; po[1] = pr.y; po[2] = pr.z; po[3] = pr.w; po[4] = vv.x;
@@ -267,7 +279,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
             {
                 const float4 *src = reinterpret_cast<const float4 *>(res + (wave * CPW) * 8);
                 const float4 pr = src[0]; const float4 vv = src[1];
-                probs[0] = pr.x; probs[1] = pr.y; probs[2] = pr.z; probs[3] = pr.w; nn_value = vv.x;
+                probs[0] = unif(pr.x); probs[1] = unif(pr.y); probs[2] = unif(pr.z); probs[3] = unif(pr.w); nn_value = unif(vv.x);
             }
 
             const int ca = lane & 3;                               // the child / action this lane works on
@@ -328,7 +340,10 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
             bool resume = false;
             TW_DS(y1);
             TW_DA(c_pre, y0, y1);
-            if (phase == DP_ROOT) {
+            const unsigned long long tree_t0 = __builtin_readcyclecounter();
+            if (yielded) {
+                yielded = false;                                 // stopped between two searches: go on searching
+            } else if (phase == DP_ROOT) {
                 // root node (search.rs:120-129): visit_count 1, expanded with the root priors
                 ++evals;
                 n_nodes = 1; cursor = 1;
@@ -348,6 +363,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
                 bool need_nn = false;
                 TW_DS(y2);
                 if (!resume) {
+                    if (it != S && __builtin_readcyclecounter() - tree_t0 > DEEP_TREE_BUDGET) { yielded = true; dem_idx = DNONE; break; }
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) ------------------------------
                         float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -445,12 +461,12 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
                             if (hm != 0ull) {
                                 const int ps = __builtin_ctzll(hm);
                                 lds_f32 *po = pout + ps * 8;
-                                lp[0] = po[0]; lp[1] = po[1]; lp[2] = po[2]; lp[3] = po[3]; lv = po[4];
+                                lp[0] = unif(po[0]); lp[1] = unif(po[1]); lp[2] = unif(po[2]); lp[3] = unif(po[3]); lv = unif(po[4]);
                                 if (lane == ps) pidx[ps] = DNONE;
                             } else {
                                 const uint4 o2 = nodes[node].q2; const uint4 o3 = nodes[node].q3;
-                                lp[0] = __uint_as_float(o2.x); lp[1] = __uint_as_float(o2.y); lp[2] = __uint_as_float(o2.z); lp[3] = __uint_as_float(o2.w);
-                                lv = __uint_as_float(o3.x);
+                                lp[0] = unif(__uint_as_float(o2.x)); lp[1] = unif(__uint_as_float(o2.y)); lp[2] = unif(__uint_as_float(o2.z));
+                                lp[3] = unif(__uint_as_float(o2.w)); lv = unif(__uint_as_float(o3.x));
                             }
                         }
                         ++evals;
@@ -509,16 +525,20 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
-// The deep shape serves AlphaZero self-play of up to DEEP_MAX_EPISODES episodes on policies the 16-episode engine supports
-// (128 or 256 hidden units); everything else runs the lane-per-episode kernel of tw_mcts.hip.
-constexpr uint64_t DEEP_MAX_EPISODES = 40960;
+// The deep shape serves AlphaZero self-play of up to CUs x 16 episodes (4,096 on an MI355X: the reference's per-GPU batch) on
+// policies the 16-episode engine supports (128 or 256 hidden units); everything else runs the lane-per-episode kernel of
+// tw_mcts.hip.  Measured (scripts/bench_az.py, Puzzle-15, 512/256 policy; walker kernel vs lane-per-episode kernel):
+//   1,024 x 100: 21.8 vs 48.9 ms    1,024 x 1,000: 211 vs 498 ms    4,096 x 100: 46.3 vs 47.3 ms    4,096 x 1,000: 319 vs 509 ms
+//   8,192 x 32: 11.5 vs 9.5 ms      16,384 x 32: 20.7 vs 12.1 ms    32,768 x 32: 39.5 vs 20.3 ms
+// One episode's chain of searches runs 2.2x faster here (about 2.2 evaluations per forward instead of one), but only
+// CUs x 4 episodes are in flight: beyond CUs x 16 episodes the lane-per-episode kernel's 16+ columns of distinct episodes win.
 
 bool mcts_deep_applies(const MctsArgs &a)
 {
     const int force = launch_options().force_geom;
     if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
-    if (force == 8 || force == 1) return false;                 // diagnostic: pin the lane-per-episode shapes
-    return a.num_episodes <= DEEP_MAX_EPISODES;
+    if (force == 8 || force == 1 || launch_options().az_variant == 2) return false;     // diagnostic: pin the lane-per-episode shapes
+    return a.num_episodes <= (uint64_t)device_cus() * 16u;
 }
 
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus)
