@@ -260,6 +260,13 @@ def _assert_same_az(g, o, n_cells):
     (4, 4, 3, 512, 256, 48, 12, 1, False),   # Puzzle-15 at the benchmark's network size
     (3, 3, 6, 64, 128, 40, 60, 1, False),    # hidden 128: four waves share 32 episodes, one row tile each
     (3, 3, 10, 32, 64, 12, 400, 1, False),   # deep trees: search paths longer than the 8 levels kept in LDS
+    # the walker-per-wave kernel (hidden 128 / 256, up to CUs x 16 episodes; tw_mcts_deep.hip):
+    (3, 3, 5, 64, 128, 30, 25, 2, True),     #   max_expand_depth 2 + twists, 9-cell boards
+    (4, 4, 10, 64, 256, 9, 300, 1, True),    #   trees larger than the LDS table (statistics in the arena), output pool wraps, yields
+    (2, 2, 2, 32, 128, 20, 9, 1, False),     #   2x2 board
+    (3, 3, 2, 32, 128, 1500, 6, 1, False),   #   more episodes than walkers: the episode queue, arenas reused
+    (3, 3, 0, 32, 128, 10, 5, 1, False),     #   difficulty 0: every root is final
+    (3, 3, 4, 32, 256, 16, 0, 1, False),     #   zero searches
 ])
 def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
     n2 = w * h
