@@ -194,7 +194,7 @@ def main():
                 so.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        from twisterl_amd.dist import DEFAULT_RESERVE_CUS, TrajectoryGather, collect_sharded, pipeline_steps
+        from twisterl_amd.dist import DEFAULT_RESERVE_CUS, Comm, TrajectoryGather, collect_sharded, pipeline_steps
 
     side = 4 if args.puzzle == 15 else 3
     n2 = side * side
@@ -208,7 +208,7 @@ def main():
                                            precision=args.precision)
     t_max = 2 * args.difficulty + 1                       # records per episode at most (depth_slope 2)
 
-    gatherer, reserve, step_eps = None, 0, None
+    gatherer, reserve, step_eps, comm = None, 0, None, None
     if use_dist:
         # N > 1: every rank's share is collected in pipeline steps so that a step's xGMI transfer to rank 0 overlaps with the
         # collection of the next step (twisterl_amd.dist).  While a transfer can be in flight the persistent rollout grid
@@ -220,12 +220,16 @@ def main():
         step_eps = int(os.environ.get("TW_STEP_EPISODES", str((cus - reserve) * 256)))
         K = pipeline_steps(E_total, world, 1, step_eps)
         gatherer = TrajectoryGather(dst=0, steps=K, max_records=E_total * t_max if K > 1 else None, max_episode_records=t_max)
+        # transport of the gather: torch.distributed's point-to-point ops (default), or TW_GATHER=cabi: RCCL issued by the
+        # library itself (tw_gather_*, what a non-Python host uses) -- same steps, same placement, same result
+        if os.environ.get("TW_GATHER", "torch") == "cabi":
+            comm = Comm()
 
     def step(i):
         seed = 1000 + i
         if use_dist:
             merged, datas = collect_sharded(coll, env, policy, seed=seed, dst=0, max_episode_records=t_max, gatherer=gatherer,
-                                            reserve_cus=reserve, step_episodes=step_eps)       # the gather is inside the timed region
+                                            reserve_cus=reserve, step_episodes=step_eps, comm=comm)       # the gather is inside the timed region
             n = sum(len(d) for d in datas)
             del merged
             return n, {"ms_rollout": sum(d.stats["ms_rollout"] for d in datas)}
@@ -290,7 +294,8 @@ def main():
                 "envs_per_gpu": envs_per_gpu, "total_envs": E_total, "records_per_step": total_records / args.steps,
                 "mean_records_per_episode": total_records / args.steps / E_total, "parallelism": f"episodes sharded x{world}",
                 "gather": None if not use_dist else {"pipeline_steps": gatherer.steps, "episodes_per_rank_and_step": step_eps,
-                                                    "reserved_cus": reserve, "transport": "RCCL send/recv at final offsets"},
+                                                    "reserved_cus": reserve,
+                                                    "transport": "RCCL send/recv at final offsets, issued by " + ("the library (tw_gather_*)" if comm is not None else "torch.distributed")},
             },
             "roofline": {
                 "bound": "mfma", "kernel": "tw::rollout_f32_kernel" if args.precision == "fp32" else "tw::rollout_f16_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -284,6 +284,41 @@ int tw_collected_pack_trainer(const tw_collected *c, uint32_t obs_size, int norm
 /* mean and unbiased standard deviation (torch.std) of the advantages of the whole collect */
 int tw_collected_adv_stats(const tw_collected *c, double *mean, double *std_unbiased);
 
+/* ---------------------------------------------------------------------------------------- */
+/* Multi-GPU exchange: one process per GPU, RCCL over xGMI (resolved with dlopen at first use).*/
+/* The reference has no distributed backend; its episodes are independent                      */
+/* (rust/src/collector/ppo.rs:59,110-124), so ranks collect disjoint episode ranges            */
+/* (tw_*_params.episode_offset, merge_order 0) and exchange only:                              */
+/*   tw_comm_broadcast_policy  the policy's device image -- the multi-GPU half of              */
+/*                             Algorithm.sync_rs_policy (src/twisterl/rl/algorithm.py:90-93)   */
+/*   tw_gather_*               finished trajectories -> root in the reference merge order      */
+/*                             [E-1, 0, .., E-2] (rust/src/collector/collector.rs:40-46)       */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct { char bytes[128]; } tw_comm_id;     /* an ncclUniqueId: rank 0 creates it, the host hands it to the other ranks */
+typedef struct tw_comm tw_comm;
+int  tw_comm_get_unique_id(tw_comm_id *out);
+int  tw_comm_init(int rank, int world, const tw_comm_id *id, tw_comm **out);   /* collective; binds the current device */
+void tw_comm_destroy(tw_comm *c);
+int  tw_comm_rank(const tw_comm *c);
+int  tw_comm_world(const tw_comm *c);
+/* every rank holds a policy created from the same shapes; afterwards all hold the root's weights */
+int  tw_comm_broadcast_policy(tw_comm *c, tw_policy *p, int root);
+
+/* Gather in `steps` pipeline steps (collective; every rank makes the same calls).  In step s rank r submits the
+ * trajectories of ITS chunk of episodes -- chunk-major order: the episode ranges of (step 0: rank 0, 1, ..), (step 1:
+ * rank 0, 1, ..) ... are consecutive -- collected with merge_order 0; NULL = no episodes in this step.  The transfer of a
+ * step runs on the communicator's own stream, beside the collection of the next one (give that collection
+ * tw_*_params.reserve_cus so that RCCL's kernels find a compute unit).  Every chunk is received at its final offset in the
+ * root's result.  steps > 1: max_records bounds the records of all ranks and steps, max_episode_records those of one
+ * episode.  episode_offset: index of the chunk's first episode inside the gathered range [0, total_episodes).
+ * The submitted objects must stay alive until tw_gather_finish, which waits, frees the gather and (root only) returns the
+ * merged result -- an ordinary tw_collected. */
+typedef struct tw_gather tw_gather;
+int tw_gather_begin(tw_comm *c, int root, uint32_t steps, uint64_t max_records, uint32_t max_episode_records,
+                    uint64_t total_episodes, int is_ppo, uint32_t n_cells, tw_gather **out);
+int tw_gather_submit(tw_gather *g, const tw_collected *local, uint64_t episode_offset);
+int tw_gather_finish(tw_gather *g, tw_collected **merged);
+
 #ifdef __cplusplus
 }
 #endif

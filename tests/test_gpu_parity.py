@@ -225,6 +225,40 @@ def test_zero_copy_torch_views_and_single_rank_gather(tw, oracle):
         dist.destroy_process_group()
 
 
+def test_rccl_exchange_behind_the_c_abi_single_rank(tw, oracle):
+    """tw_comm_* / tw_gather_* (RCCL issued by the library) with a one-rank communicator: the unique-id / init plumbing, the
+    policy broadcast, and the gather's placement (tail of the last episode first, chunks at their final offsets, ep_len /
+    ep_start of the merged result) for one step and for several, PPO and AlphaZero data.  The multi-rank logic is the one the
+    gloo tests cover in Python; the C++ twin is checked against it here through identical results."""
+    import os
+    import torch.distributed as dist
+    from twisterl_amd.dist import Comm, collect_sharded
+    gp, _ = _pair(oracle, 9, 9, 32, 32, twists=True)
+    env = tw.env.Puzzle(3, 3, 5, 2, 256)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        comm = Comm()
+        assert (comm.rank, comm.world) == (0, 1)
+        comm.broadcast_policy(gp, root=0)
+        coll = tw.collector.PPOCollector(300, 0.99, 0.95, 1)
+        want = coll.collect(env, gp, seed=3).to_numpy()                       # merge order
+        for kw in ({}, {"chunks": 3, "max_episode_records": 11}, {"step_episodes": 64, "max_episode_records": 11, "reserve_cus": 8}):
+            merged, parts = collect_sharded(coll, env, gp, seed=3, comm=comm, **kw)
+            assert sum(len(p) for p in parts) == want["obs"].shape[0]
+            for k in ("obs", "logits", "perms", "values", "rewards", "actions", "advs", "rets", "ep_len", "ep_start"):
+                assert np.array_equal(merged[k].cpu().numpy(), want[k]), (kw, k)
+        az = tw.collector.AZCollector(90, 12, 1.41, 1, 1)
+        zwant = az.collect(env, gp, seed=5).to_numpy()
+        merged, _ = collect_sharded(az, env, gp, seed=5, comm=comm, chunks=4, max_episode_records=11)
+        for k in ("obs", "logits", "perms", "remaining_values", "ep_len", "ep_start"):
+            assert np.array_equal(merged[k].cpu().numpy(), zwant[k]), k
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_errors(tw, oracle):
     gp, _ = _pair(oracle, 9, 8, 32, 32)
     with pytest.raises(RuntimeError, match="No data in collected data chunks to merge"):

@@ -77,6 +77,10 @@ class CollectStats(C.Structure):
                 ("rollout_threads", C.c_uint32), ("forward_evals", C.c_uint64), ("speculative_evals", C.c_uint64)]
 
 
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_ubyte * 128)]      # (c_ubyte: a c_char array field would read back truncated at the first NUL)
+
+
 # every symbol include/twisterl_hip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
@@ -133,6 +137,15 @@ SYMBOLS = {
     "tw_collected_free": (None, [_VP]),
     "tw_collected_pack_trainer": (C.c_int, [_VP, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, _VP, _VP, _VP, _VP, _VP]),
     "tw_collected_adv_stats": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tw_comm_get_unique_id": (C.c_int, [C.POINTER(CommId)]),
+    "tw_comm_init": (C.c_int, [C.c_int, C.c_int, C.POINTER(CommId), C.POINTER(_VP)]),
+    "tw_comm_destroy": (None, [_VP]),
+    "tw_comm_rank": (C.c_int, [_VP]),
+    "tw_comm_world": (C.c_int, [_VP]),
+    "tw_comm_broadcast_policy": (C.c_int, [_VP, _VP, C.c_int]),
+    "tw_gather_begin": (C.c_int, [_VP, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_VP)]),
+    "tw_gather_submit": (C.c_int, [_VP, _VP, C.c_uint64]),
+    "tw_gather_finish": (C.c_int, [_VP, C.POINTER(_VP)]),
 }
 
 _lib = None

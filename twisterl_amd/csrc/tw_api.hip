@@ -359,6 +359,7 @@ extern "C" int64_t tw_puzzle_get_position(const tw_puzzle *p, uint32_t x, uint32
 struct tw_policy {
     PolicyDev dev{};
     void *arena = nullptr;
+    size_t arena_bytes = 0;
     int device = -1;
     uint32_t n16 = 0, sp16 = 0, sps = 0;      // f16 / split-f16 image geometry (tw_policy_update_device)
 };
@@ -579,6 +580,7 @@ extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
 
     tw_policy *pol = new tw_policy();
     hipError_t e = hipGetDevice(&pol->device);
+    pol->arena_bytes = img.size();
     if (e == hipSuccess) e = hipMalloc(&pol->arena, img.size());
     if (e == hipSuccess) e = hipMemcpy(pol->arena, img.data(), img.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -791,6 +793,33 @@ extern "C" int tw_collected_pack_trainer(const tw_collected *c, uint32_t obs_siz
                              c->is_ppo ? log_probs : nullptr, c->is_ppo ? actions : nullptr, perms, c->is_ppo ? advs : nullptr, s);
     return rc;
 }
+
+namespace tw {
+int policy_device_image(tw_policy *p, void **image, size_t *bytes)
+{
+    if (!p || !p->arena) { set_error("policy: no device image"); return TW_ERR_INVALID; }
+    *image = p->arena; *bytes = p->arena_bytes;
+    return TW_OK;
+}
+int collected_describe(const tw_collected *c, int *is_ppo, uint32_t *n_cells, uint32_t *n_actions, uint64_t *n_records, uint64_t *n_episodes)
+{
+    if (!c) { set_error("null collected data"); return TW_ERR_INVALID; }
+    *is_ppo = c->is_ppo; *n_cells = c->n_cells; *n_actions = c->n_actions; *n_records = c->n_records; *n_episodes = c->n_episodes;
+    return TW_OK;
+}
+const void *collected_field(const tw_collected *c, int field) { return c->field_ptr[field]; }
+int collected_adopt(void *arena, size_t arena_bytes, int device, int is_ppo, uint32_t n_cells, uint32_t n_actions, uint64_t n_records,
+                    uint64_t n_episodes, void *const (&field_ptr)[TW_F_COUNT], const size_t (&field_bytes)[TW_F_COUNT], tw_collected **out)
+{
+    tw_collected *c = new tw_collected();
+    c->arena = arena; c->arena_cap = arena_bytes; c->device = device;
+    c->is_ppo = is_ppo; c->n_cells = n_cells; c->n_actions = n_actions; c->n_records = n_records; c->n_episodes = n_episodes;
+    for (int f = 0; f < TW_F_COUNT; ++f) { c->field_ptr[f] = field_ptr[f]; c->field_bytes[f] = field_bytes[f]; }
+    c->stats.records = n_records; c->stats.episodes = n_episodes;
+    *out = c;
+    return TW_OK;
+}
+}  // namespace tw
 
 extern "C" void tw_collected_free(tw_collected *c)
 {

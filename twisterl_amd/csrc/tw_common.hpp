@@ -498,6 +498,14 @@ struct SyncArgs {
 };
 
 int launch_policy_sync(const SyncArgs &a, hipStream_t s);
+
+// tw_api.hip internals the exchange (tw_comm.hip) works on
+int policy_device_image(tw_policy *p, void **image, size_t *bytes);       // the one allocation holding every weight image
+int collected_describe(const tw_collected *c, int *is_ppo, uint32_t *n_cells, uint32_t *n_actions, uint64_t *n_records, uint64_t *n_episodes);
+const void *collected_field(const tw_collected *c, int field);
+// wraps device memory the caller allocated with hipMalloc into a result object (which frees it through the arena pool)
+int collected_adopt(void *arena, size_t arena_bytes, int device, int is_ppo, uint32_t n_cells, uint32_t n_actions, uint64_t n_records,
+                    uint64_t n_episodes, void *const (&field_ptr)[TW_F_COUNT], const size_t (&field_bytes)[TW_F_COUNT], tw_collected **out);
 int launch_policy_eval(const PolicyDev &pol, int mode, const int32_t *obs_d, uint32_t n, uint32_t n_obs,
                        const uint8_t *masks_d, const int32_t *perms_d, float *out_actions_d, float *out_values_d,
                        hipStream_t s);

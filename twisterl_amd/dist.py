@@ -184,6 +184,74 @@ class TrajectoryGather:
         return out
 
 
+class Comm:
+    """RCCL communicator of the C ABI (tw_comm_*, include/twisterl_hip.h): what a non-Python host of the collectors uses for
+    the multi-GPU exchange.  The unique id travels over whatever the host has; here: the torch.distributed group."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        cid = _lib.CommId()
+        if self.rank == 0:
+            _lib.check(L.tw_comm_get_unique_id(C.byref(cid)))
+        box = [C.string_at(C.byref(cid), 128) if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        C.memmove(C.byref(cid), box[0], 128)
+        h = C.c_void_p()
+        _lib.check(L.tw_comm_init(self.rank, self.world, C.byref(cid), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                from . import _lib
+                _lib.lib().tw_comm_destroy(h)
+            except Exception:          # interpreter shutting down
+                pass
+
+    __del__ = close
+
+    def broadcast_policy(self, policy, root: int = 0) -> None:
+        """Policy sync across GPUs: the root's weight images replace everybody's (one ncclBroadcast)."""
+        from . import _lib
+        _lib.check(_lib.lib().tw_comm_broadcast_policy(self._h, policy._handle(), int(root)))
+
+
+class RcclGather:
+    """TrajectoryGather over the C ABI (tw_gather_*): same steps, same placement, RCCL send/recv issued by the library on
+    the communicator's own stream.  submit() takes the CollectedData of this rank's chunk (or None) and the index of its
+    first episode inside the gathered range; finish() returns the merged CollectedData on the root."""
+
+    def __init__(self, comm: Comm, dst: int, steps: int, max_records: int, max_episode_records: int, total_episodes: int,
+                 is_ppo: bool, n_cells: int):
+        import ctypes as C
+        from . import _lib
+        self.comm, self.dst = comm, dst
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tw_gather_begin(comm._h, int(dst), int(steps), int(max_records or 0), int(max_episode_records or 0),
+                                              int(total_episodes), int(bool(is_ppo)), int(n_cells), C.byref(h)))
+        self._h, self.keep = h, []
+
+    def submit(self, data, episode_offset: int) -> None:
+        from . import _lib
+        self.keep.append(data)                    # the chunk's buffers are read by the transfer until finish()
+        _lib.check(_lib.lib().tw_gather_submit(self._h, data._dev.h if data is not None else None, int(episode_offset)))
+
+    def finish(self):
+        import ctypes as C
+        from . import _lib
+        from .collector import CollectedData, _DeviceResult
+        out = C.c_void_p()
+        h, self._h = self._h, None
+        _lib.check(_lib.lib().tw_gather_finish(h, C.byref(out)))
+        self.keep = []
+        return CollectedData._from_device(_DeviceResult(out.value)) if out.value else None
+
+
 def gather_trajectories(fields: Dict[str, torch.Tensor], ep_len: torch.Tensor, dst: int = 0,
                         group=None) -> Optional[Dict[str, torch.Tensor]]:
     """One-step gather: every rank holds the compact trajectories of ITS contiguous episode shard (index order)."""
@@ -216,7 +284,7 @@ def _empty_like_fields(template: Dict[str, torch.Tensor]):
 
 def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None, gather: bool = True, chunks: int = 1,
                     max_episode_records: Optional[int] = None, gatherer: Optional[TrajectoryGather] = None,
-                    reserve_cus: Optional[int] = None, step_episodes: Optional[int] = None):
+                    reserve_cus: Optional[int] = None, step_episodes: Optional[int] = None, comm: Optional[Comm] = None):
     """Run `collector` (a PPOCollector/AZCollector configured with the GLOBAL num_episodes) over all ranks and gather to
     `dst`.  Returns (merged dict of device tensors on `dst` else None, list of this rank's CollectedData, one per non-empty
     chunk).  chunks > 1 collects in that many pipeline steps so that each step's transfer overlaps with the next step's
@@ -224,7 +292,8 @@ def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None,
     reuse its output buffers between calls.  `reserve_cus` compute units stay free of rollout workgroups while a transfer
     can be in flight (default DEFAULT_RESERVE_CUS when pipelining on more than one rank, else 0).  `step_episodes` sets the
     episodes per rank and step instead of `chunks` -- with episodes of equal length a step should be a whole number of
-    rounds of the GPU's resident lanes ((CUs - reserve_cus) x 256)."""
+    rounds of the GPU's resident lanes ((CUs - reserve_cus) x 256).  With `comm` (a Comm) the exchange runs inside the library
+    (tw_gather_*: RCCL issued from C++, the path a non-Python host has) instead of torch.distributed's point-to-point ops."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     E = int(collector.num_episodes)
@@ -242,6 +311,20 @@ def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None,
             local.reserve_cus = int(reserve_cus)
         return local.collect(env, policy, seed=seed)
 
+    if gather and comm is not None:
+        from .env import get_env_desc
+        desc = get_env_desc(env)
+        rg = RcclGather(comm, dst, K, E * int(max_episode_records or 0) if K > 1 else 0, max_episode_records or 0, E,
+                        getattr(collector, "_IS_PPO", True), int(desc.width) * int(desc.height))
+        datas = []
+        for s in range(K):
+            a, b = chunk_range(bounds, s, rank, world)
+            d = run(a, b) if b > a else None
+            if d is not None:
+                datas.append(d)
+            rg.submit(d, a)
+        merged = rg.finish()
+        return (merged.to_torch() if merged is not None else None), datas
     tg = None
     if gather:
         if K > 1 and max_episode_records is None:
