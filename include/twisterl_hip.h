@@ -141,10 +141,12 @@ typedef struct {
 
 typedef struct tw_policy tw_policy;
 
-/* Copies the weights to the device (host pointers in `desc` need not outlive the call).
- * Supported shape: 1-D EmbeddingBag -> ONE common Linear -> ONE action Linear (n_actions
- * outputs) and ONE value Linear (1 output); emb_size % 32 == 0, hidden % 32 == 0 (<= 256),
- * obs_size <= 256.  Anything else: NULL + TW_ERR_UNSUPPORTED. */
+/* Copies the weights to the device (host pointers in `desc` need not outlive the call).  Any stack the reference's
+ * Policy holds is accepted (rust/src/nn/modules.rs:28-34): 1-D EmbeddingBag (emb_size % 4 == 0, <= 512; obs_size <= 256),
+ * up to 8 Linear layers each in `common`, `action` (ending in n_actions outputs) and `value`, widths <= 512.  The shape of
+ * both Puzzle configs -- ONE common Linear of 32 / 64 / 128 / 256 units, emb_size % 32 == 0, linear heads -- runs on the
+ * MFMA engines (and has the f16 modes and tw_policy_update_device); every other stack runs the generic engine (vector ALU,
+ * same arithmetic, f32 only).  NULL + message in tw_last_error() otherwise. */
 tw_policy *tw_policy_create(const tw_policy_desc *desc);
 void       tw_policy_destroy(tw_policy *p);
 /* Device-to-device policy sync (replaces the per-iteration policy.to_rust() round trip through host lists,

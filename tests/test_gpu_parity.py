@@ -259,6 +259,58 @@ def test_rccl_exchange_behind_the_c_abi_single_rank(tw, oracle):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------ any Sequential depth (modules.rs:28-34)
+@pytest.mark.parametrize("n2,emb,common,pl,vl,twists", [
+    (9, 64, (128, 64), (), (), True),          # two common layers
+    (9, 128, (256,), (32,), (16,), False),     # hidden policy / value layers (config keys policy_layers / value_layers)
+    (16, 256, (512,), (), (), True),           # 512 hidden units
+    (9, 64, (96,), (), (), False),             # a width the MFMA tiles do not cover
+    (4, 32, (), (24,), (), False),             # no common layer at all
+    (16, 512, (256, 256, 128), (64, 32), (64,), True),
+])
+def test_policies_of_any_depth(tw, oracle, n2, emb, common, pl, vl, twists):
+    """The reference's Policy holds any Sequential stacks (rust/src/nn/modules.rs:28-34; BasicPolicy builds them from
+    common_layers / policy_layers / value_layers, src/twisterl/nn/policy.py:60-113).  Shapes beyond the one-common-layer
+    BasicPolicy of the Puzzle configs run the generic engine: forward / predict / full_predict, PPO collect, self-play,
+    evaluate and solve are bit-equal to the oracle here too."""
+    from tests.util import make_deep_policy_arrays
+    side = int(round(n2 ** 0.5))
+    arrs = make_deep_policy_arrays(n2, seed=11, emb=emb, common=common, policy_layers=pl, value_layers=vl, scale=2.0)
+    op_, ap_ = puzzle_transpose_twist(side) if twists else ((), ())
+    gp, op = amd_policy(arrs, op_, ap_), oracle_policy(oracle, arrs, op_, ap_)
+    rng = np.random.default_rng(0)
+    n = 24
+    boards = np.stack([rng.permutation(n2) for _ in range(n)])
+    obs = np.arange(n2)[None, :] * n2 + boards
+    masks = rng.integers(0, 2, size=(n, 4)).astype(np.uint8); masks[:, 0] = 1
+    perms = rng.integers(-1, 2 if twists else 0, size=n).astype(np.int32)
+    la, va = gp.evaluate_batch(_lib.TW_EVAL_FORWARD, obs, masks, perms)
+    fa, fv = gp.evaluate_batch(_lib.TW_EVAL_FULL_PREDICT, obs, masks)
+    oracle.set_det_exp(True)
+    try:
+        for i in range(n):
+            lo, vo = op.forward(obs[i].tolist(), masks[i].astype(bool).tolist(), perm=int(perms[i]), arith=oracle.ARITH_CHAIN)
+            assert np.array_equal(f32_bits(lo), f32_bits(la[i])) and f32_bits(vo) == f32_bits(va[i]), i
+            po, pv = op.full_predict(obs[i].tolist(), masks[i].astype(bool).tolist(), arith=oracle.ARITH_CHAIN)
+            assert np.array_equal(f32_bits(po), f32_bits(fa[i])) and f32_bits(pv) == f32_bits(fv[i]), i
+    finally:
+        oracle.set_det_exp(False)
+    genv, oenv = tw.env.Puzzle(side, side, 5, 2, 256), oracle.Puzzle(side, side, 5, 2, 256)
+    for E in (50, 300):
+        g = tw.collector.PPOCollector(E, 0.995, 0.995, 32).collect(genv, gp, seed=41)
+        o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=41, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8)
+        _assert_same_collect(g, o, n2)
+    z = tw.collector.AZCollector(40, 14, 1.41, 1, 32).collect(genv, gp, seed=43)
+    zo = oracle.az_collect(oenv, op, 40, 14, 1.41, 1, seed=43, arith=oracle.ARITH_CHAIN, num_threads=8, det_math=True)
+    _assert_same_az(z, zo, n2)
+    ge = tw.collector.evaluate(genv, gp, num_episodes=60, deterministic=False, num_searches=3, num_mcts_searches=0, seed=7, C=1.41,
+                               max_expand_depth=1, num_cores=32)
+    oe = oracle.evaluate(oenv, op, 60, False, 3, seed=7, arith=oracle.ARITH_CHAIN, det_math=True)
+    assert f32_bits(ge[0]) == f32_bits(oe[0]) and f32_bits(ge[1]) == f32_bits(oe[1])
+    with pytest.raises(RuntimeError, match="f16 modes"):
+        tw.collector.PPOCollector(8, 0.9, 0.9, 1, precision="fp16").collect(genv, gp, seed=1)
+
+
 def test_errors(tw, oracle):
     gp, _ = _pair(oracle, 9, 8, 32, 32)
     with pytest.raises(RuntimeError, match="No data in collected data chunks to merge"):
@@ -269,8 +321,11 @@ def test_errors(tw, oracle):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)
     with pytest.raises(ValueError):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(4, 4, 1, 2, 256), gp)   # obs_size mismatch
-    arrs = make_policy_arrays(9, emb=48, hidden=32)
-    with pytest.raises(RuntimeError, match="unsupported shape"):
+    arrs = make_policy_arrays(9, emb=50, hidden=32)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        amd_policy(arrs)._handle()
+    arrs = make_policy_arrays(9, emb=64, hidden=600)
+    with pytest.raises(RuntimeError, match="widths up to 512"):
         amd_policy(arrs)._handle()
 
 

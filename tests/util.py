@@ -36,6 +36,35 @@ def make_policy_arrays(n2, seed=0, emb=512, hidden=256, n_actions=4, scale=1.0):
             [(np.ascontiguousarray(wv.T).reshape(-1), bv, False)])
 
 
+def make_deep_policy_arrays(n2, seed=0, emb=64, common=(128, 64), policy_layers=(), value_layers=(), n_actions=4, scale=1.0):
+    """Weights of a BasicPolicy with any number of common / policy / value layers (src/twisterl/nn/policy.py:60-113 builds
+    them with make_sequential: every hidden Linear is followed by ReLU, the final action / value Linear is not) in the
+    reference's export layout (src/twisterl/nn/utils.py:17-42)."""
+    rng = np.random.default_rng(seed)
+
+    def lin(i, o, relu):
+        b = scale / np.sqrt(i)
+        w = rng.uniform(-b, b, size=(o, i)).astype(np.float32)
+        bias = rng.uniform(-b, b, size=o).astype(np.float32)
+        return (np.ascontiguousarray(w.T).reshape(-1), bias, relu)
+
+    b0 = scale / np.sqrt(n2 * n2)
+    we = rng.uniform(-b0, b0, size=(emb, n2 * n2)).astype(np.float32)
+    be = rng.uniform(-b0, b0, size=emb).astype(np.float32)
+    cs, w = [], emb
+    for h in common:
+        cs.append(lin(w, h, True)); w = h
+    acts, wa = [], w
+    for h in policy_layers:
+        acts.append(lin(wa, h, True)); wa = h
+    acts.append(lin(wa, n_actions, False))
+    vals, wv = [], w
+    for h in value_layers:
+        vals.append(lin(wv, h, True)); wv = h
+    vals.append(lin(wv, 1, False))
+    return (np.ascontiguousarray(we.T), be, cs, acts, vals)
+
+
 def amd_policy(arrs, obs_perms=(), act_perms=()):
     """twisterl_amd.nn.Policy from make_policy_arrays() output, built through the same
     constructor calls BasicPolicy.to_rust() makes (src/twisterl/nn/policy.py:191-199)."""

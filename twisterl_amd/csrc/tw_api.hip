@@ -368,38 +368,117 @@ namespace {
 int hid_row(int r, int i) { return 32 * r + 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }   // == tw::hid() in tw_rollout.hip
 }
 
+namespace {
+
+// The shape the MFMA engines implement (the BasicPolicy of both Puzzle configs, examples/ppo_puzzle{8,15}_v1.json):
+// embedding -> ONE common Linear of 32..256 units -> linear heads.  Everything else runs the generic engine.
+bool is_mfma_shape(const tw_policy_desc *d)
+{
+    if (d->n_common != 1 || d->n_action != 1 || d->n_value != 1 || !d->common || !d->action || !d->value) return false;
+    const tw_linear_desc &c = d->common[0], &a = d->action[0], &v = d->value[0];
+    const uint32_t E = d->emb_size, H = c.out_features, A = a.out_features;
+    return c.in_features == E && a.in_features == H && v.in_features == H && v.out_features == 1 && A == d->n_actions && A != 0 && A <= 31 &&
+           E != 0 && E % 32 == 0 && H % 32 == 0 && H != 0 && H <= 256 && (H & (H - 1)) == 0 && d->obs_size != 0 && d->obs_size <= 256 &&
+           !a.apply_relu && !v.apply_relu;
+}
+
+// Any Sequential stack (modules.rs:28-34): natural-layout weights + a layer table for EngineV (tw_engine_generic.hpp).
+tw_policy *create_generic_policy(const tw_policy_desc *d)
+{
+    const uint32_t E = d->emb_size, OS = d->obs_size;
+    if (E == 0 || E % 4 != 0 || E > 512 || OS == 0 || OS > 256) {
+        set_error("policy: generic stacks need an embedding size that is a multiple of 4 and <= 512 and obs_size <= 256 (got emb=%u obs_size=%u)", E, OS);
+        return nullptr;
+    }
+    const uint32_t n_layers = d->n_common + d->n_action + d->n_value;
+    if (d->n_common > 8 || d->n_action > 8 || d->n_value > 8) { set_error("policy: at most 8 layers per stack"); return nullptr; }
+    if ((d->n_common && !d->common) || (d->n_action && !d->action) || (d->n_value && !d->value)) { set_error("policy: null layer array"); return nullptr; }
+    auto chain = [&](const tw_linear_desc *ls, uint32_t n, uint32_t in, const char *what, uint32_t *out) -> bool {
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!ls[i].weights || !ls[i].bias || ls[i].in_features != in || ls[i].out_features == 0 || ls[i].out_features > 512) {
+                set_error("policy: %s layer %u has %u -> %u features where %u inputs arrive (widths up to 512)", what, i, ls[i].in_features, ls[i].out_features, in);
+                return false;
+            }
+            in = ls[i].out_features;
+        }
+        *out = in;
+        return true;
+    };
+    uint32_t cw = 0, aw = 0, vw = 0;
+    if (!chain(d->common, d->n_common, E, "common", &cw) || !chain(d->action, d->n_action, cw, "action", &aw) ||
+        !chain(d->value, d->n_value, cw, "value", &vw)) return nullptr;
+    if (aw != d->n_actions || aw < 1 || aw > 31) { set_error("policy: the action head ends in %u outputs, n_actions is %u", aw, d->n_actions); return nullptr; }
+    const uint32_t A = aw;
+    size_t cur = 0;
+    auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    const size_t o_emb = seg((size_t)(OS + 2) * E * 4), o_tab = seg((size_t)(n_layers ? n_layers : 1) * sizeof(LayerDev)),
+                 o_op = seg((size_t)(d->n_perms ? d->n_perms : 1) * OS), o_ap = seg((size_t)(d->n_perms ? d->n_perms : 1) * A);
+    std::vector<size_t> o_w(n_layers), o_b(n_layers);
+    std::vector<const tw_linear_desc *> all;
+    for (uint32_t i = 0; i < d->n_common; ++i) all.push_back(&d->common[i]);
+    for (uint32_t i = 0; i < d->n_action; ++i) all.push_back(&d->action[i]);
+    for (uint32_t i = 0; i < d->n_value; ++i) all.push_back(&d->value[i]);
+    for (uint32_t i = 0; i < n_layers; ++i) { o_w[i] = seg((size_t)all[i]->in_features * all[i]->out_features * 4); o_b[i] = seg((size_t)all[i]->out_features * 4 + 16); }
+    std::vector<uint8_t> img(cur, 0);
+    float *emb = reinterpret_cast<float *>(img.data() + o_emb);
+    memcpy(emb, d->emb_vectors, (size_t)OS * E * 4);
+    memcpy(emb + (size_t)OS * E, d->emb_bias, (size_t)E * 4);
+    for (uint32_t i = 0; i < n_layers; ++i) {
+        memcpy(img.data() + o_w[i], all[i]->weights, (size_t)all[i]->in_features * all[i]->out_features * 4);
+        memcpy(img.data() + o_b[i], all[i]->bias, (size_t)all[i]->out_features * 4);
+    }
+    for (uint32_t p = 0; p < d->n_perms; ++p) {
+        for (uint32_t i = 0; i < OS; ++i) img[o_op + (size_t)p * OS + i] = (uint8_t)d->obs_perms[(size_t)p * OS + i];
+        for (uint32_t i = 0; i < A; ++i) img[o_ap + (size_t)p * A + i] = (uint8_t)d->act_perms[(size_t)p * A + i];
+    }
+    tw_policy *pol = new tw_policy();
+    pol->arena_bytes = img.size();
+    hipError_t e = hipGetDevice(&pol->device);
+    if (e == hipSuccess) e = hipMalloc(&pol->arena, img.size());
+    if (e != hipSuccess) { hip_fail(e, "policy upload", __FILE__, __LINE__); delete pol; return nullptr; }
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(pol->arena);
+    LayerDev *tab = reinterpret_cast<LayerDev *>(img.data() + o_tab);          // device pointers go into the table before the upload
+    for (uint32_t i = 0; i < n_layers; ++i) {
+        tab[i].w = reinterpret_cast<const float *>(base + o_w[i]); tab[i].b = reinterpret_cast<const float *>(base + o_b[i]);
+        tab[i].in = (int32_t)all[i]->in_features; tab[i].out = (int32_t)all[i]->out_features; tab[i].relu = all[i]->apply_relu ? 1 : 0; tab[i].pad = 0;
+    }
+    e = hipMemcpy(pol->arena, img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hip_fail(e, "policy upload", __FILE__, __LINE__); (void)hipFree(pol->arena); delete pol; return nullptr; }
+    PolicyDev &pd = pol->dev;
+    pd.obs_size = (int)OS; pd.emb = (int)E; pd.hidden = 0; pd.n_actions = (int)A; pd.n_perms = (int)d->n_perms;
+    pd.emb_relu = d->emb_apply_relu ? 1 : 0; pd.common_relu = 0;
+    pd.emb_rows = reinterpret_cast<const float *>(base + o_emb);
+    pd.obs_perms = base + o_op; pd.act_perms = base + o_ap;
+    pd.generic = 1; pd.n_common = (int)d->n_common; pd.n_action = (int)d->n_action; pd.n_value = (int)d->n_value; pd.value_out = (int)vw;
+    pd.layers = reinterpret_cast<const LayerDev *>(base + o_tab);
+    return pol;
+}
+
+}  // namespace
+
 extern "C" tw_policy *tw_policy_create(const tw_policy_desc *d)
 {
     if (!d || !d->emb_vectors || !d->emb_bias) { set_error("tw_policy_create: null descriptor"); return nullptr; }
     if (require_device()) return nullptr;
-    // ---- shape validation: the HIP path implements the BasicPolicy of the Puzzle configs
-    //      (examples/ppo_puzzle{8,15}_v1.json: embedding -> one common layer -> two linear heads)
-    if (d->n_common != 1 || d->n_action != 1 || d->n_value != 1 || !d->common || !d->action || !d->value) {
-        set_error("policy: HIP path supports exactly one common, one action and one value Linear (got %u/%u/%u)",
-                  d->n_common, d->n_action, d->n_value);
-        return nullptr;
-    }
-    const tw_linear_desc &c = d->common[0], &a = d->action[0], &v = d->value[0];
-    const uint32_t E = d->emb_size, H = c.out_features, A = a.out_features;
-    if (c.in_features != E || a.in_features != H || v.in_features != H || v.out_features != 1 || A != d->n_actions ||
-        A == 0 || A > 31 || E == 0 || E % 32 != 0 || H % 32 != 0 || H == 0 || H > 256 || d->obs_size == 0 ||
-        d->obs_size > 256 || a.apply_relu || v.apply_relu) {
-        set_error("policy: unsupported shape (obs_size=%u emb=%u hidden=%u actions=%u; need emb%%32==0, hidden%%32==0 "
-                  "and <=256, obs_size<=256, linear heads)", d->obs_size, E, H, A);
-        return nullptr;
-    }
     if (d->n_perms > 0 && (!d->obs_perms || !d->act_perms)) { set_error("policy: n_perms > 0 but perms are null"); return nullptr; }
     if (d->n_perms > 127) { set_error("policy: at most 127 twists"); return nullptr; }
-    for (uint32_t p = 0; p < d->n_perms; ++p) {
-        for (uint32_t i = 0; i < d->obs_size; ++i)
-            if (d->obs_perms[(size_t)p * d->obs_size + i] < 0 || (uint32_t)d->obs_perms[(size_t)p * d->obs_size + i] >= d->obs_size) {
-                set_error("policy: obs_perms[%u][%u] out of range", p, i); return nullptr;
-            }
-        for (uint32_t i = 0; i < A; ++i)
-            if (d->act_perms[(size_t)p * A + i] < 0 || (uint32_t)d->act_perms[(size_t)p * A + i] >= A) {
-                set_error("policy: act_perms[%u][%u] out of range", p, i); return nullptr;
-            }
+    {
+        const uint32_t A0 = d->n_actions;
+        for (uint32_t p = 0; p < d->n_perms; ++p) {
+            for (uint32_t i = 0; i < d->obs_size; ++i)
+                if (d->obs_perms[(size_t)p * d->obs_size + i] < 0 || (uint32_t)d->obs_perms[(size_t)p * d->obs_size + i] >= d->obs_size) {
+                    set_error("policy: obs_perms[%u][%u] out of range", p, i); return nullptr;
+                }
+            for (uint32_t i = 0; i < A0; ++i)
+                if (d->act_perms[(size_t)p * A0 + i] < 0 || (uint32_t)d->act_perms[(size_t)p * A0 + i] >= A0) {
+                    set_error("policy: act_perms[%u][%u] out of range", p, i); return nullptr;
+                }
+        }
     }
+    // ---- the MFMA engines implement the BasicPolicy of the Puzzle configs; any other Sequential stack runs the generic engine
+    if (!is_mfma_shape(d)) return create_generic_policy(d);
+    const tw_linear_desc &c = d->common[0], &a = d->action[0], &v = d->value[0];
+    const uint32_t E = d->emb_size, H = c.out_features, A = a.out_features;
 
     const uint32_t NT = H / 32, OS = d->obs_size;
     // ---- host image ------------------------------------------------------------------------
@@ -622,6 +701,7 @@ extern "C" int tw_policy_update_device(tw_policy *p, const float *emb_w, const f
     if (!p || !emb_w || !emb_b || !w1 || !b1 || !wa || !ba || !wv || !bv) { set_error("tw_policy_update_device: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
     const PolicyDev &d = p->dev;
+    if (d.generic) { set_error("tw_policy_update_device: policies with more than one common layer or non-linear heads are rebuilt with tw_policy_create"); return TW_ERR_UNSUPPORTED; }
     SyncArgs a{};
     a.emb_w = emb_w; a.emb_b = emb_b; a.w1 = w1; a.b1 = b1; a.wa = wa; a.ba = ba; a.wv = wv; a.bv = bv;
     a.OS = d.obs_size; a.E = d.emb; a.H = d.hidden; a.A = d.n_actions; a.NT = d.hidden / 32; a.NQ = (a.NT + 3) / 4;
@@ -881,6 +961,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
         return TW_ERR_INVALID;
     }
     if (ra.pol.n_actions != 4) { set_error("Puzzle has 4 actions, policy has %d", ra.pol.n_actions); return TW_ERR_INVALID; }
+    if (ra.pol.generic && prm->precision != TW_PREC_F32_EXACT) { set_error("tw_ppo_collect: the f16 modes exist for the one-common-layer policy shape only"); return TW_ERR_UNSUPPORTED; }
     const uint64_t E = prm->num_episodes;
     const int t_pad = ra.env.depth0 + 1;
     ra.num_episodes = E; ra.episode_offset = prm->episode_offset; ra.seed = prm->seed;
@@ -896,7 +977,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     ra.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
     const uint64_t resident = prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false, ra.reserve_cus)
                                                                   : rollout_f32_resident_episodes(ra.reserve_cus);
-    const bool persist = E > resident && !launch_options().no_persist;
+    const bool persist = E > resident && !launch_options().no_persist && !ra.pol.generic;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
                  o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     void *wsp = nullptr;
@@ -1010,7 +1091,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     // few, deep searches: the walker-per-wave shape (tw_mcts_deep.hip) -- always persistent, 64-byte nodes, one arena per walker
     const bool deep = mcts_deep_applies(ma);
     const uint64_t resident = deep ? mcts_deep_walkers(E, ma.reserve_cus) : f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
-    const bool persist = deep || (E > resident && !launch_options().no_persist);
+    const bool persist = deep || (E > resident && !launch_options().no_persist && !ma.pol.generic);
     const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(32), o_scan = seg(scan_scratch_bytes(E)),

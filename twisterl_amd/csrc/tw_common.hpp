@@ -287,6 +287,13 @@ __host__ __device__ inline uint32_t puzzle_maskbits(const PuzzleLane &s, const P
     return (s.zx > 0 ? 1u : 0u) | (s.zy > 0 ? 2u : 0u) | (s.zx < c.width - 1 ? 4u : 0u) | (s.zy < c.height - 1 ? 8u : 0u);
 }
 
+// one Linear of a generic policy stack (EngineV, tw_engine_generic.hpp): weights in the reference's export layout
+struct LayerDev {
+    const float *w;      // [in][out] row-major == torch_weight.T.flatten() (layers.rs:26)
+    const float *b;      // [out]
+    int32_t in, out, relu, pad;
+};
+
 // ---- device-side policy image (built once by tw_policy_create) ------------------------------
 struct PolicyDev {
     int32_t obs_size, emb, hidden, n_actions, n_perms;
@@ -318,6 +325,9 @@ struct PolicyDev {
     // split-f16 image (TW_PREC_F16X2, EngineS in tw_engine16x2.hpp): operands x16, hi / lo binary16 terms
     const uint8_t *stageS;    // [2*emb/32 + 1][SP KiB]: stage 2k = [T_hi(k+1) | W1_hi(k)], 2k+1 = lo terms, last = [head_hi | head_lo]
     const uint8_t *t0S;       // [2*f16_nc KiB]: table tile 0, hi chunks then lo chunks
+    // generic stacks (any Sequential depth; EngineV): layers = common | action | value; hidden == 0 marks such a policy
+    int32_t generic, n_common, n_action, n_value, value_out;
+    const LayerDev *layers;
 };
 
 // padded (episode-major) trajectory workspace written by the rollout / MCTS kernels: ONE 48-byte

@@ -3,6 +3,7 @@
 // with both weight streams running through a ring of LDS slots.  See tw_rollout.hip for the design notes.
 #pragma once
 #include "tw_common.hpp"
+#include "tw_engine_generic.hpp"
 #include <cstdlib>
 
 namespace tw {
@@ -825,12 +826,13 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
     }
 };
 
-constexpr int geom_threads(int nw) { return nw == -16 ? 256 : 64 * (nw < 0 ? -nw : nw); }
+constexpr int geom_threads(int nw) { return (nw == -16 || nw == -64) ? 256 : 64 * (nw < 0 ? -nw : nw); }
 // launch geometry code -> engine: NW > 0 = NW independent waves of 32 episodes (Engine3); NW < 0 = -NW waves sharing 32 (Engine3S)
 template <int NT, int NC, int DBG, int NW> struct Geom { using Eng = Engine3<NT, NC, DBG, NW>; static constexpr int WAVES = NW; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -4> { using Eng = Engine3S<NT, NC, 4>; static constexpr int WAVES = 4; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -2> { using Eng = Engine3S<NT, NC, 2>; static constexpr int WAVES = 2; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -16> { using Eng = Engine3T<NT, NC>; static constexpr int WAVES = 4; };   // 16 episodes per workgroup
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -64> { using Eng = EngineV<NC>; static constexpr int WAVES = 4; };        // generic stacks on the vector ALU
 
 // geometry for n episodes: 8 = the throughput shape; below ~3/4 of a chip of 256-episode workgroups the split shape
 template <int NT> inline int geometry_for(uint64_t n)

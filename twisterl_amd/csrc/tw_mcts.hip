@@ -508,6 +508,18 @@ int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t
 {
     // host-side shape checks: everything the kernel indexes with is validated here
     const uint64_t need = 5ull + 4ull * a.num_searches * (a.max_expand_depth ? a.max_expand_depth : 1u);
+    if (a.pol.generic) {          // any Sequential depth: the vector-ALU engine (tw_engine_generic.hpp)
+        if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
+            (!a.solve.on && a.out.t_pad < a.env.depth0 + 1) || a.node_cap < need || !a.arena || !a.eval_count || a.queue || a.init_boards ||
+            (a.solve.on && (!a.solve.success || !a.solve.total || !a.solve.n_steps || a.solve.num_searches == 0))) {
+            set_error("mcts: unsupported shape for a generic policy (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
+            return TW_ERR_UNSUPPORTED;
+        }
+        const int nc = a.env.n_cells;
+        if (nc <= 4) return launch_mcts_geom<0, 4, -64>(a, s, blocks, threads);
+        if (nc <= 9) return launch_mcts_geom<0, 9, -64>(a, s, blocks, threads);
+        return launch_mcts_geom<0, 16, -64>(a, s, blocks, threads);
+    }
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||
         a.pol.obs_size > 256 || a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 ||
         (!a.solve.on && a.out.t_pad < a.env.depth0 + 1) || a.node_cap < need || !a.arena || !a.eval_count ||

@@ -237,6 +237,17 @@ static int launch_nt(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint
 
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
+    if (a.pol.generic) {          // any Sequential depth: the vector-ALU engine (tw_engine_generic.hpp); shapes validated by tw_policy_create
+        if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
+            a.out.t_pad < a.env.depth0 + 1 || a.queue || a.init_boards) {
+            set_error("rollout: unsupported shape for a generic policy (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
+            return TW_ERR_UNSUPPORTED;
+        }
+        const int nc = a.env.n_cells;
+        if (nc <= 4) return launch_geom<0, 4, 0, -64>(a, s, blocks, threads);
+        if (nc <= 9) return launch_geom<0, 9, 0, -64>(a, s, blocks, threads);
+        return launch_geom<0, 16, 0, -64>(a, s, blocks, threads);
+    }
     // host-side shape checks: everything the kernel indexes with is validated here
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||
         a.pol.obs_size > 256 || a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 ||

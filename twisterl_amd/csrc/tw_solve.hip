@@ -119,6 +119,17 @@ static int launch_solve_nt(const SolveArgs &a, hipStream_t s)
 
 int launch_solve_f32(const SolveArgs &a, hipStream_t s)
 {
+    if (a.pol.generic) {          // any Sequential depth: the vector-ALU engine (tw_engine_generic.hpp)
+        if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
+            a.num_searches == 0 || !a.success || !a.total || !a.n_steps || (a.actions && a.t_pad < 1)) {
+            set_error("solve: unsupported shape for a generic policy (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
+            return TW_ERR_UNSUPPORTED;
+        }
+        const int nc = a.env.n_cells;
+        if (nc <= 4) return launch_solve_geom<0, 4, -64>(a, s);
+        if (nc <= 9) return launch_solve_geom<0, 9, -64>(a, s);
+        return launch_solve_geom<0, 16, -64>(a, s);
+    }
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||
         a.pol.obs_size > 256 || a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 || a.num_searches == 0 ||
         !a.success || !a.total || !a.n_steps || (a.actions && a.t_pad < 1)) {
