@@ -201,6 +201,25 @@ typedef struct {
     uint32_t reserve_cus;         /* as in tw_ppo_params                                        */
 } tw_az_params;
 
+/* ---- any environment: `trait Env` (rust/src/rl/env.rs:18-68) as a table of C functions.  The collector clones the
+ * prototype once per episode and never mutates it (rust/src/collector/ppo.rs:59); the environment's code runs on the host,
+ * as in the reference (a Rust crate like examples/grid_world, or a Python class behind PyEnv, python_interface/pyenv.rs),
+ * the policy forward of all live episodes of a time step is one batched launch on the device.  `reset` receives the collect's
+ * seed and the GLOBAL episode index (build extension: the reference's reset draws from thread_rng). */
+typedef struct {
+    void    *prototype;
+    uint32_t num_actions;                 /* Env::num_actions (<= 31)                                   */
+    uint32_t n_obs, obs_size;             /* observe() returns n_obs ids, each < obs_size (<= 65535)    */
+    void  *(*clone)(void *env);
+    void   (*destroy)(void *env);
+    void   (*reset)(void *env, uint64_t seed, uint64_t episode);
+    void   (*step)(void *env, uint32_t action);
+    void   (*observe)(void *env, int32_t *out /* n_obs */);
+    void   (*masks)(void *env, uint8_t *out /* num_actions, 0/1 */);
+    float  (*reward)(void *env);
+    int    (*is_final)(void *env);
+} tw_env_vtable;
+
 /* solve / evaluate (rust/src/rl/solve.rs:73-101, rust/src/rl/evaluate.rs:22-89; PyO3 functions
  * collector.solve / collector.evaluate, rust/src/python_interface/env.rs:180-207) */
 typedef struct {
@@ -219,6 +238,10 @@ int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy,
                    const tw_ppo_params *params, tw_collected **out);
 int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
                   const tw_az_params *params, tw_collected **out);
+/* PPOCollector::collect for any environment (policies: any shape tw_policy_create accepts; f32).  An episode that has not
+ * ended after max_records_per_episode records is an error.  params.reserve_cus is ignored. */
+int tw_ppo_collect_env(const tw_env_vtable *env, const tw_policy *policy, const tw_ppo_params *params,
+                       uint32_t max_records_per_episode, tw_collected **out);
 
 /* evaluate(): reset + best-of-num_searches solve for episodes [episode_offset, +num_episodes);
  * returns the success rate and the mean total reward, accumulated in episode order. */
@@ -250,6 +273,7 @@ uint64_t tw_collected_num_episodes(const tw_collected *c);
 uint32_t tw_collected_num_cells(const tw_collected *c);
 uint32_t tw_collected_num_actions(const tw_collected *c);
 int      tw_collected_is_ppo(const tw_collected *c);
+uint32_t tw_collected_obs_width(const tw_collected *c);   /* bytes per obs id in TW_F_OBS: 1, or 2 for environments with > 256 ids */
 /* device pointer + byte size of a field (NULL/0 when the collector does not produce it) */
 void    *tw_collected_device_ptr(const tw_collected *c, int field, size_t *bytes);
 int      tw_collected_copy_to_host(const tw_collected *c, int field, void *dst, size_t bytes);

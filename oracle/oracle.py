@@ -461,3 +461,50 @@ def replay(env: Puzzle, actions):
                      _fp(rew), fin.ctypes.data_as(C.POINTER(C.c_uint8)),
                      board.ctypes.data_as(C.POINTER(C.c_int64)))
     return obs, masks.astype(bool), rew, fin.astype(bool), board
+
+
+# ------------------------------------------------------------------------------------- any environment
+def ppo_collect_env(proto, policy: Policy, num_episodes, gamma, lam, seed=0, episode_offset=0, difficulty=1, arith=ARITH_CHAIN,
+                    merge_order=True) -> Collected:
+    """PPOCollector::collect (rust/src/collector/ppo.rs:41-126) over ANY environment object with the reference's Python env
+    protocol (python_interface/pyenv.rs: copy, reset(difficulty), next, masks, is_final, value, observe): clone + reset per
+    episode (:59-60), per record observe / masks / reward of the current state, forward_with_perm, sample_from_logits, push,
+    `if is_final break`, step (:69-80), GAE (:82-92), merge (collector.rs:40-46).  Randomness per the build's RNG spec (same
+    streams as two_ppo_collect).  A pure-Python loop: small cases only."""
+    A = policy.n_actions
+    eps = []
+    for i in range(num_episodes):
+        e = proto.copy()
+        ep = episode_offset + i
+        if hasattr(e, "seed_episode"):
+            e.seed_episode(seed, ep)
+        e.reset(difficulty)
+        obs_l, lg_l, perm_l, val_l, rew_l, act_l = [], [], [], [], [], []
+        t = 0
+        while True:
+            obs = [int(x) for x in e.observe()]
+            masks = [bool(m) for m in e.masks()]
+            rew = np.float32(e.value())
+            perm = -1
+            if policy.n_perms > 0:
+                w = philox4x32_10([ep & 0xFFFFFFFF, ep >> 32, t, 2], [seed & 0xFFFFFFFF, seed >> 32])
+                perm = (w[0] * policy.n_perms) >> 32
+            lg, v = policy.forward(obs, masks, perm=perm, arith=arith)
+            u = []
+            for a in range(A):
+                w = philox4x32_10([ep & 0xFFFFFFFF, ep >> 32, t | ((a >> 2) << 24), 1], [seed & 0xFFFFFFFF, seed >> 32])
+                u.append(np.float32(w[a & 3] >> 8) * np.float32(1.0 / 16777216.0))
+            act = sample_from_logits(lg, u, det_log=True)
+            obs_l.append(obs); lg_l.append(lg); perm_l.append(perm); val_l.append(v); rew_l.append(rew); act_l.append(act)
+            if e.is_final():
+                break
+            e.next(act)
+            t += 1
+        advs, rets = gae(rew_l, val_l, gamma, lam)
+        eps.append((obs_l, lg_l, perm_l, val_l, rew_l, act_l, advs, rets))
+    order = ([num_episodes - 1] + list(range(num_episodes - 1))) if merge_order else list(range(num_episodes))
+    cat = lambda k, dt: np.concatenate([np.asarray(eps[i][k], dtype=dt).reshape(len(eps[i][3]), -1) for i in order])
+    return Collected(cat(0, np.int64), cat(1, np.float32), cat(2, np.int32).reshape(-1), cat(3, np.float32).reshape(-1),
+                     cat(4, np.float32).reshape(-1), cat(5, np.int64).reshape(-1),
+                     {"advs": cat(6, np.float32).reshape(-1), "rets": cat(7, np.float32).reshape(-1)},
+                     np.asarray([len(e[3]) for e in eps], dtype=np.uint32))

@@ -311,6 +311,54 @@ def test_policies_of_any_depth(tw, oracle, n2, emb, common, pl, vl, twists):
         tw.collector.PPOCollector(8, 0.9, 0.9, 1, precision="fp16").collect(genv, gp, seed=1)
 
 
+# ------------------------------------------------------------------------------ any environment
+@pytest.mark.parametrize("w,h,steps,emb,common,E", [(3, 3, 8, 64, (64,), 120), (5, 5, 12, 64, (128, 32), 60)])
+def test_ppo_collect_of_a_python_environment(tw, oracle, w, h, steps, emb, common, E):
+    """PPOCollector.collect on an environment the library does not implement (the reference collects any Box<dyn Env>;
+    its example is examples/grid_world): a GridWorld written in Python behind twisterl.env.PyEnv.  The env's code runs on the
+    host, the policy forward of every time step is one batched launch; the whole CollectedData is bit-equal to the oracle's
+    generic restatement of ppo.rs:41-126 running the same env class.  5 x 5: 625 obs ids (two-byte ids in the result)."""
+    from tests.gridworld_env import GridWorld
+    from tests.util import make_deep_policy_arrays
+    n = w * h
+    rng = np.random.default_rng(13)
+    lin = lambda i, o, relu: (np.ascontiguousarray(rng.uniform(-2 / np.sqrt(i), 2 / np.sqrt(i), size=(o, i)).astype(np.float32).T).reshape(-1),
+                              rng.uniform(-1 / np.sqrt(i), 1 / np.sqrt(i), size=o).astype(np.float32), relu)
+    we = rng.uniform(-0.3, 0.3, size=(n * n, emb)).astype(np.float32)
+    be = rng.uniform(-0.1, 0.1, size=emb).astype(np.float32)
+    cs, width = [], emb
+    for hdim in common:
+        cs.append(lin(width, hdim, True)); width = hdim
+    arrs = (we, be, cs, [lin(width, 4, False)], [lin(width, 1, False)])
+    gp, op = amd_policy(arrs), oracle_policy(oracle, arrs)
+    proto = GridWorld(w, h, steps)
+    env = tw.env.PyEnv(proto)
+    env.difficulty = 3
+    assert env.num_actions() == 4 and env.obs_shape() == [n, n]
+    for merge_order in (True, False):
+        g = tw.collector.PPOCollector(E, 0.99, 0.95, 4, merge_order=merge_order).collect(env, gp, seed=77)
+        o = oracle.ppo_collect_env(proto, op, E, 0.99, 0.95, seed=77, difficulty=3, merge_order=merge_order)
+        _assert_same_collect(g, o, n)
+    a = g.to_numpy()
+    assert a["obs"].dtype == (np.uint16 if n * n > 256 else np.uint8)
+    assert (a["ep_len"] <= steps + 1).all() and a["ep_len"].min() >= 1
+    # reference-style access and the consumers' attributes
+    assert len(g.obs) == len(g.actions) == len(g.additional_data["rets"]) and set(g.perms) == {-1}
+    with pytest.raises(TypeError, match="PPOCollector"):
+        tw.collector.AZCollector(4, 4, 1.41, 1, 1).collect(env, gp)
+
+    class Broken(GridWorld):
+        def next(self, action):
+            raise ValueError("boom")
+
+        def copy(self):
+            c = Broken(self.width, self.height, self.max_steps)
+            c.steps_left, c.agent, c.goal, c.trap = self.steps_left, self.agent, self.goal, self.trap
+            return c
+    with pytest.raises(ValueError, match="boom"):           # an exception in the env's code surfaces, the collect is abandoned
+        tw.collector.PPOCollector(4, 0.99, 0.95, 1).collect(tw.env.PyEnv(Broken(w, h, steps)), gp, seed=1)
+
+
 def test_errors(tw, oracle):
     gp, _ = _pair(oracle, 9, 8, 32, 32)
     with pytest.raises(RuntimeError, match="No data in collected data chunks to merge"):

@@ -493,3 +493,28 @@ def test_reference_trained_policy_solves_the_oracle_puzzle(oracle):
     # and with the table rows of (cell, tile) read as (tile, cell): a transposed obs encoding
     T = np.arange(81).reshape(9, 9).T.reshape(-1)
     assert oracle.evaluate(env, oracle.Policy(np.ascontiguousarray(emb[T]), eb, common, action, value), 200, False, 1, seed=1)[0] < 0.5
+
+
+def test_generic_env_collect_dummy_env_known_answer(oracle):
+    """The reference's own collector test (rust/src/collector/ppo.rs:128-183): DummyEnv (final after one step, reward 1.0) and a
+    one-weight policy: 1 episode => 2 records; with gamma 0.9, lambda 0.95, values [1, 1], rewards [1, 1]: rets [1.9, 1.0],
+    advs [0.9, 0.0].  Through the oracle's collector for arbitrary environments (ppo_collect_env)."""
+    class DummyEnv:
+        def __init__(self):
+            self.steps = 0
+        def copy(self):
+            c = DummyEnv(); c.steps = self.steps; return c
+        def num_actions(self): return 1
+        def obs_shape(self): return [1]
+        def reset(self, difficulty): self.steps = 0
+        def next(self, action): self.steps += 1
+        def masks(self): return [True]
+        def is_final(self): return self.steps >= 1
+        def value(self): return 1.0
+        def observe(self): return [0]
+    pol = oracle.Policy(np.zeros((1, 1), np.float32), np.ones(1, np.float32), [], [(np.ones(1, np.float32), np.zeros(1, np.float32), False)],
+                        [(np.ones(1, np.float32), np.zeros(1, np.float32), False)], emb_relu=False)
+    d = oracle.ppo_collect_env(DummyEnv(), pol, 1, 0.9, 0.95, seed=0)
+    assert d.obs.shape[0] == 2 and d.values.tolist() == [1.0, 1.0] and d.rewards.tolist() == [1.0, 1.0]
+    assert np.allclose(d.additional_data["rets"], [1.9, 1.0]) and np.allclose(d.additional_data["advs"], [0.9, 0.0], atol=1e-7)
+    assert d.actions.tolist() == [0, 0] and d.ep_len.tolist() == [2]

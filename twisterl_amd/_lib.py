@@ -77,6 +77,14 @@ class CollectStats(C.Structure):
                 ("rollout_threads", C.c_uint32), ("forward_evals", C.c_uint64), ("speculative_evals", C.c_uint64)]
 
 
+class EnvVTable(C.Structure):
+    _fields_ = [("prototype", C.c_void_p), ("num_actions", C.c_uint32), ("n_obs", C.c_uint32), ("obs_size", C.c_uint32),
+                ("clone", C.CFUNCTYPE(C.c_void_p, C.c_void_p)), ("destroy", C.CFUNCTYPE(None, C.c_void_p)),
+                ("reset", C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)), ("step", C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)),
+                ("observe", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32))), ("masks", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8))),
+                ("reward", C.CFUNCTYPE(C.c_float, C.c_void_p)), ("is_final", C.CFUNCTYPE(C.c_int, C.c_void_p))]
+
+
 class CommId(C.Structure):
     _fields_ = [("bytes", C.c_ubyte * 128)]      # (c_ubyte: a c_char array field would read back truncated at the first NUL)
 
@@ -122,6 +130,7 @@ SYMBOLS = {
                                      C.POINTER(C.c_float)]),
     "tw_ppo_collect": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(PPOParams), C.POINTER(_VP)]),
     "tw_az_collect": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(AZParams), C.POINTER(_VP)]),
+    "tw_ppo_collect_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(PPOParams), C.c_uint32, C.POINTER(_VP)]),
     "tw_evaluate": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(SolveParams), C.c_uint64, C.c_uint64,
                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tw_solve": (C.c_int, [_VP, _VP, C.POINTER(SolveParams), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -131,6 +140,7 @@ SYMBOLS = {
     "tw_collected_num_cells": (C.c_uint32, [_VP]),
     "tw_collected_num_actions": (C.c_uint32, [_VP]),
     "tw_collected_is_ppo": (C.c_int, [_VP]),
+    "tw_collected_obs_width": (C.c_uint32, [_VP]),
     "tw_collected_device_ptr": (_VP, [_VP, C.c_int, C.POINTER(C.c_size_t)]),
     "tw_collected_copy_to_host": (C.c_int, [_VP, C.c_int, _VP, C.c_size_t]),
     "tw_collected_stats": (C.c_int, [_VP, C.POINTER(CollectStats)]),

@@ -14,7 +14,7 @@ import ctypes as _c
 import numpy as np
 
 from . import _lib
-from .env import get_env_desc
+from .env import PyEnv, get_env_desc
 from .nn import Policy
 
 ctypes_u8 = _c.c_uint8
@@ -43,6 +43,7 @@ class _DeviceResult:
         self.n_cells = int(L.tw_collected_num_cells(handle))
         self.n_actions = int(L.tw_collected_num_actions(handle))
         self.is_ppo = bool(L.tw_collected_is_ppo(handle))
+        self.obs_width = int(L.tw_collected_obs_width(handle))      # 2: an environment with more than 256 obs ids
         st = _lib.CollectStats()
         _lib.check(L.tw_collected_stats(handle, C.byref(st)))
         self.stats = {k: getattr(st, k) for k, _ in st._fields_}
@@ -64,6 +65,9 @@ class _DeviceResult:
             return (self.n_episodes,)
         return (self.n,)
 
+    def dtype(self, field):
+        return np.uint16 if (field == _lib.TW_F_OBS and self.obs_width == 2) else _FIELD_DTYPES[field]
+
     def ptr(self, field):
         nbytes = C.c_size_t()
         p = _lib.lib().tw_collected_device_ptr(self.h, field, C.byref(nbytes))
@@ -71,7 +75,7 @@ class _DeviceResult:
 
     def host(self, field) -> np.ndarray:
         p, nbytes = self.ptr(field)
-        dt = np.dtype(_FIELD_DTYPES[field])
+        dt = np.dtype(self.dtype(field))
         if nbytes == 0:
             return np.zeros((0,), dt)
         out = np.empty(self.shape(field), dt)
@@ -88,7 +92,7 @@ class DeviceArray:
         self._owner = owner
         ptr, nbytes = owner.ptr(field)
         self.shape = owner.shape(field)
-        self.dtype = np.dtype(_FIELD_DTYPES[field])
+        self.dtype = np.dtype(owner.dtype(field))
         self.nbytes = nbytes
         self.__cuda_array_interface__ = {"shape": self.shape, "typestr": self.dtype.str, "data": (ptr, False),
                                          "version": 2, "strides": None}
@@ -308,6 +312,8 @@ class PPOCollector(PyBaseCollector):
         return s
 
     def collect(self, py_env, policy: Policy, *, seed=None) -> CollectedData:
+        if isinstance(py_env, PyEnv):
+            return self._collect_foreign(py_env, policy, seed)
         desc = self._check(py_env, policy)
         prm = _lib.PPOParams(self.num_episodes, self.episode_offset, self.gamma, self.lambda_,
                              (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed(),
@@ -315,6 +321,93 @@ class PPOCollector(PyBaseCollector):
         out = C.c_void_p()
         _lib.check(_lib.lib().tw_ppo_collect(C.byref(desc), policy._handle(), C.byref(prm), C.byref(out)))
         return CollectedData._from_device(_DeviceResult(out.value))
+
+
+def _collect_foreign(self, py_env: PyEnv, policy: Policy, seed) -> CollectedData:
+    """PPOCollector.collect for an environment implemented in Python (tw_ppo_collect_env): the object's methods are handed to
+    the library as the C function table of `trait Env`; clones live here, keyed by small integer handles."""
+    if not isinstance(policy, Policy):
+        raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
+    if self.precision not in ("fp32", "f32", "exact"):
+        raise RuntimeError("environments implemented in Python are collected in f32")
+    proto = py_env._env
+    envs, nxt, err = {1: proto}, [2], []
+    V = _lib.EnvVTable
+
+    def guard(default=None):
+        def deco(fn):
+            def wrapped(*a):
+                if err:
+                    return default
+                try:
+                    return fn(*a)
+                except BaseException as e:          # an exception must not unwind through the C frames
+                    err.append(e)
+                    return default
+            return wrapped
+        return deco
+
+    @guard(0)
+    def f_clone(h):
+        envs[nxt[0]] = envs[h].copy()
+        nxt[0] += 1
+        return nxt[0] - 1
+
+    @guard()
+    def f_destroy(h):
+        envs.pop(h, None)
+
+    @guard()
+    def f_reset(h, sd, ep):
+        e = envs[h]
+        if hasattr(e, "seed_episode"):
+            e.seed_episode(int(sd), int(ep))
+        e.reset(py_env.difficulty)                  # PyEnvImpl::reset (pyenv.rs:93-100)
+
+    @guard()
+    def f_step(h, a):
+        envs[h].next(int(a))
+
+    @guard()
+    def f_observe(h, out_p):
+        for i, v in enumerate(envs[h].observe()):
+            out_p[i] = int(v)
+
+    @guard()
+    def f_masks(h, out_p):
+        for i, v in enumerate(envs[h].masks()):
+            out_p[i] = 1 if v else 0
+
+    @guard(0.0)
+    def f_reward(h):
+        return float(envs[h].value())
+
+    @guard(1)
+    def f_final(h):
+        return 1 if envs[h].is_final() else 0
+
+    n_obs = len(proto.observe())
+    obs_size = 1
+    for x in proto.obs_shape():
+        obs_size *= int(x)
+    fields = dict(V._fields_)
+    vt = V(1, int(proto.num_actions()), n_obs, obs_size, fields["clone"](f_clone), fields["destroy"](f_destroy), fields["reset"](f_reset),
+           fields["step"](f_step), fields["observe"](f_observe), fields["masks"](f_masks), fields["reward"](f_reward),
+           fields["is_final"](f_final))
+    prm = _lib.PPOParams(self.num_episodes, self.episode_offset, self.gamma, self.lambda_,
+                         (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed(), _lib.TW_PREC_F32_EXACT,
+                         int(self.merge_order), 0)
+    out = C.c_void_p()
+    rc = _lib.lib().tw_ppo_collect_env(C.byref(vt), policy._handle(), C.byref(prm), int(getattr(proto, "max_records", 1 << 16)), C.byref(out))
+    if err:
+        if out.value:
+            _lib.lib().tw_collected_free(out)
+        raise err[0]
+    _lib.check(rc)
+    return CollectedData._from_device(_DeviceResult(out.value))
+
+
+PPOCollector._collect_foreign = _collect_foreign
 
 
 class AZCollector(PyBaseCollector):

@@ -79,7 +79,7 @@ int ensure_dynamic_lds(const void *kernel, size_t bytes)
     return TW_OK;
 }
 
-static int require_device()
+int require_device()
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -386,8 +386,8 @@ bool is_mfma_shape(const tw_policy_desc *d)
 tw_policy *create_generic_policy(const tw_policy_desc *d)
 {
     const uint32_t E = d->emb_size, OS = d->obs_size;
-    if (E == 0 || E % 4 != 0 || E > 512 || OS == 0 || OS > 256) {
-        set_error("policy: generic stacks need an embedding size that is a multiple of 4 and <= 512 and obs_size <= 256 (got emb=%u obs_size=%u)", E, OS);
+    if (E == 0 || E % 4 != 0 || E > 512 || OS == 0 || OS > 65535) {
+        set_error("policy: generic stacks need an embedding size that is a multiple of 4 and <= 512 and obs_size <= 65535 (got emb=%u obs_size=%u)", E, OS);
         return nullptr;
     }
     const uint32_t n_layers = d->n_common + d->n_action + d->n_value;
@@ -412,7 +412,8 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     const size_t o_emb = seg((size_t)(OS + 2) * E * 4), o_tab = seg((size_t)(n_layers ? n_layers : 1) * sizeof(LayerDev)),
-                 o_op = seg((size_t)(d->n_perms ? d->n_perms : 1) * OS), o_ap = seg((size_t)(d->n_perms ? d->n_perms : 1) * A);
+                 o_op = seg((size_t)(d->n_perms ? d->n_perms : 1) * OS), o_ap = seg((size_t)(d->n_perms ? d->n_perms : 1) * A),
+                 o_op16 = seg(OS > 256 ? (size_t)(d->n_perms ? d->n_perms : 1) * OS * 2 : 0);
     std::vector<size_t> o_w(n_layers), o_b(n_layers);
     std::vector<const tw_linear_desc *> all;
     for (uint32_t i = 0; i < d->n_common; ++i) all.push_back(&d->common[i]);
@@ -428,7 +429,10 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
         memcpy(img.data() + o_b[i], all[i]->bias, (size_t)all[i]->out_features * 4);
     }
     for (uint32_t p = 0; p < d->n_perms; ++p) {
-        for (uint32_t i = 0; i < OS; ++i) img[o_op + (size_t)p * OS + i] = (uint8_t)d->obs_perms[(size_t)p * OS + i];
+        for (uint32_t i = 0; i < OS; ++i) {
+            img[o_op + (size_t)p * OS + i] = (uint8_t)d->obs_perms[(size_t)p * OS + i];
+            if (OS > 256) { const uint16_t v16 = (uint16_t)d->obs_perms[(size_t)p * OS + i]; memcpy(img.data() + o_op16 + ((size_t)p * OS + i) * 2, &v16, 2); }
+        }
         for (uint32_t i = 0; i < A; ++i) img[o_ap + (size_t)p * A + i] = (uint8_t)d->act_perms[(size_t)p * A + i];
     }
     tw_policy *pol = new tw_policy();
@@ -437,6 +441,7 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
     if (e == hipSuccess) e = hipMalloc(&pol->arena, img.size());
     if (e != hipSuccess) { hip_fail(e, "policy upload", __FILE__, __LINE__); delete pol; return nullptr; }
     const uint8_t *base = reinterpret_cast<const uint8_t *>(pol->arena);
+    pol->dev.obs_perms16 = OS > 256 ? reinterpret_cast<const uint16_t *>(base + o_op16) : nullptr;
     LayerDev *tab = reinterpret_cast<LayerDev *>(img.data() + o_tab);          // device pointers go into the table before the upload
     for (uint32_t i = 0; i < n_layers; ++i) {
         tab[i].w = reinterpret_cast<const float *>(base + o_w[i]); tab[i].b = reinterpret_cast<const float *>(base + o_b[i]);
@@ -779,6 +784,7 @@ extern "C" int tw_policy_evaluate(const tw_policy *p, int mode, uint32_t precisi
 struct tw_collected {
     void *arena = nullptr;                  // one allocation holding every compact field (from the arena pool)
     size_t arena_cap = 0; int device = -1;
+    uint32_t obs_width = 1;                 // bytes per obs id (2: an environment with more than 256 ids, tw_ppo_collect_env)
     void *field_ptr[TW_F_COUNT] = {};
     size_t field_bytes[TW_F_COUNT] = {};
     uint64_t n_records = 0, n_episodes = 0;
@@ -792,6 +798,7 @@ extern "C" uint64_t tw_collected_num_episodes(const tw_collected *c) { return c 
 extern "C" uint32_t tw_collected_num_cells(const tw_collected *c) { return c ? c->n_cells : 0; }
 extern "C" uint32_t tw_collected_num_actions(const tw_collected *c) { return c ? c->n_actions : 0; }
 extern "C" int tw_collected_is_ppo(const tw_collected *c) { return c ? c->is_ppo : 0; }
+extern "C" uint32_t tw_collected_obs_width(const tw_collected *c) { return c ? c->obs_width : 0; }
 
 extern "C" void *tw_collected_device_ptr(const tw_collected *c, int field, size_t *bytes)
 {
@@ -853,6 +860,7 @@ extern "C" int tw_collected_pack_trainer(const tw_collected *c, uint32_t obs_siz
                   (unsigned long long)row_count, (unsigned long long)c->n_records);
         return TW_ERR_INVALID;
     }
+    if (obs_onehot && c->obs_width != 1) { set_error("tw_collected_pack_trainer: one-hot packing exists for one-byte obs ids (obs_size <= 256)"); return TW_ERR_UNSUPPORTED; }
     if (obs_onehot && (obs_size == 0 || obs_size > 256 || obs_size < c->n_cells)) { set_error("tw_collected_pack_trainer: obs_size %u", obs_size); return TW_ERR_INVALID; }
     if ((log_probs || actions || advs) && !c->is_ppo) { set_error("tw_collected_pack_trainer: log_probs / actions / advs exist for PPO data only"); return TW_ERR_INVALID; }
     hipStream_t s = current_stream();
@@ -875,6 +883,8 @@ extern "C" int tw_collected_pack_trainer(const tw_collected *c, uint32_t obs_siz
 }
 
 namespace tw {
+const PolicyDev *policy_dev(const tw_policy *p) { return &p->dev; }
+void collected_adopt_obs_width(tw_collected *c, uint32_t obs_width) { c->obs_width = obs_width; }
 int policy_device_image(tw_policy *p, void **image, size_t *bytes)
 {
     if (!p || !p->arena) { set_error("policy: no device image"); return TW_ERR_INVALID; }

@@ -328,6 +328,7 @@ struct PolicyDev {
     // generic stacks (any Sequential depth; EngineV): layers = common | action | value; hidden == 0 marks such a policy
     int32_t generic, n_common, n_action, n_value, value_out;
     const LayerDev *layers;
+    const uint16_t *obs_perms16;   // [n_perms][obs_size] for obs_size > 256 (environments other than Puzzle; the evaluate kernels)
 };
 
 // padded (episode-major) trajectory workspace written by the rollout / MCTS kernels: ONE 48-byte
@@ -509,7 +510,10 @@ struct SyncArgs {
 
 int launch_policy_sync(const SyncArgs &a, hipStream_t s);
 
-// tw_api.hip internals the exchange (tw_comm.hip) works on
+// tw_api.hip internals the exchange (tw_comm.hip) and the generic-env collector (tw_env_generic.hip) work on
+int require_device();
+const PolicyDev *policy_dev(const tw_policy *p);
+void collected_adopt_obs_width(tw_collected *c, uint32_t obs_width);
 int policy_device_image(tw_policy *p, void **image, size_t *bytes);       // the one allocation holding every weight image
 int collected_describe(const tw_collected *c, int *is_ppo, uint32_t *n_cells, uint32_t *n_actions, uint64_t *n_records, uint64_t *n_episodes);
 const void *collected_field(const tw_collected *c, int field);

@@ -1,0 +1,171 @@
+// tw_env_generic.hip -- PPO collection for ANY environment: the reference's `Collector::collect(&Box<dyn Env>, &Policy)`
+// (rust/src/collector/collector.rs:92-95, ppo.rs:41-126) takes any implementor of `trait Env` (rust/src/rl/env.rs:18-68) --
+// the GridWorld crate of examples/grid_world, Python classes behind PyEnv (python_interface/pyenv.rs) -- not only Puzzle.
+//
+// An environment whose dynamics this library does not implement on the GPU is user code: it arrives as a table of C
+// function pointers (tw_env_vtable = the trait's methods the collector calls) and steps on the host, exactly as the
+// reference runs it.  Everything else of the path stays on the device: the policy forward of ALL live episodes of a
+// time step is ONE batched launch (policy_eval kernels: MFMA-shape or generic stacks, any obs_size), the result is an
+// ordinary tw_collected in HBM.  Per record, as ppo.rs:69-80: observe / masks / reward of the CURRENT state, forward_with_perm
+// (twist index from the RNG spec of tw_common.hpp), Gumbel arg-max with the spec's uniforms and deterministic log, push,
+// `if is_final break`, step.  Then GAE (ppo.rs:82-92, un-fused) and merge order (collector.rs:40-46).
+#include "tw_common.hpp"
+
+#include <cstring>
+#include <vector>
+
+using namespace tw;
+
+extern "C" int tw_ppo_collect_env(const tw_env_vtable *env, const tw_policy *policy, const tw_ppo_params *prm,
+                                  uint32_t max_records_per_episode, tw_collected **out)
+{
+    if (!env || !policy || !prm || !out) { set_error("tw_ppo_collect_env: null argument"); return TW_ERR_INVALID; }
+    *out = nullptr;
+    if (!env->prototype || !env->clone || !env->destroy || !env->reset || !env->step || !env->observe || !env->masks || !env->reward || !env->is_final) {
+        set_error("tw_ppo_collect_env: the environment table lacks a method"); return TW_ERR_INVALID;
+    }
+    if (prm->num_episodes == 0) { set_error("Something went wrong. No data in collected data chunks to merge. "); return TW_ERR_EMPTY; }   // collector.rs:41
+    if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_ppo_collect_env: f32 only"); return TW_ERR_UNSUPPORTED; }
+    const PolicyDev *pd = policy_dev(policy);
+    const uint32_t A = env->num_actions, NO = env->n_obs;
+    if (A == 0 || A > 31 || (int)A != pd->n_actions) { set_error("environment has %u actions, policy has %d (at most 31)", A, pd->n_actions); return TW_ERR_INVALID; }
+    if (NO == 0 || NO > 64) { set_error("tw_ppo_collect_env: observations of %u ids (1..64 supported)", NO); return TW_ERR_UNSUPPORTED; }
+    if ((int)env->obs_size != pd->obs_size) { set_error("index out of bounds: policy obs_size %d != environment obs ids %u", pd->obs_size, env->obs_size); return TW_ERR_INVALID; }
+    if (max_records_per_episode == 0) { set_error("tw_ppo_collect_env: max_records_per_episode must be positive"); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+
+    const uint64_t E = prm->num_episodes;
+    const uint32_t OW = pd->obs_size > 256 ? 2u : 1u;                      // bytes per obs id in the result
+    hipStream_t s = current_stream();
+    struct Ep {
+        void *env = nullptr; bool alive = true;
+        std::vector<int32_t> obs; std::vector<float> logits, values, rewards; std::vector<int32_t> actions, perms;
+    };
+    std::vector<Ep> eps(E);
+    auto cleanup = [&]() { for (auto &e : eps) if (e.env) { env->destroy(e.env); e.env = nullptr; } };
+    for (uint64_t i = 0; i < E; ++i) {                                     // ppo.rs:59-60: clone + reset per episode
+        eps[i].env = env->clone(env->prototype);
+        if (!eps[i].env) { cleanup(); set_error("tw_ppo_collect_env: clone() returned null"); return TW_ERR_INVALID; }
+        env->reset(eps[i].env, prm->seed, prm->episode_offset + i);
+    }
+    // device staging for one time step of all live episodes
+    const size_t b_obs = (size_t)E * NO * 4, b_m = (size_t)E * A, b_p = (size_t)E * 4, b_la = (size_t)E * A * 4, b_v = (size_t)E * 4;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_obs = 0, o_m = up(b_obs), o_p = o_m + up(b_m), o_la = o_p + up(b_p), o_v = o_la + up(b_la), tot = o_v + up(b_v);
+    uint8_t *dev = nullptr;
+    hipError_t he = hipMalloc((void **)&dev, tot);
+    if (he != hipSuccess) { cleanup(); return hip_fail(he, "hipMalloc(step staging)", __FILE__, __LINE__); }
+    std::vector<int32_t> h_obs((size_t)E * NO), h_perm(E); std::vector<uint8_t> h_m((size_t)E * A); std::vector<float> h_la((size_t)E * A), h_v(E);
+    std::vector<uint64_t> live; live.reserve(E);
+#define TW_HIP_E(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); (void)hipFree(dev); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
+    for (uint32_t t = 0;; ++t) {
+        live.clear();
+        for (uint64_t i = 0; i < E; ++i) if (eps[i].alive) live.push_back(i);
+        if (live.empty()) break;
+        if (t >= max_records_per_episode) { cleanup(); (void)hipFree(dev); set_error("tw_ppo_collect_env: an episode did not end within %u records", max_records_per_episode); return TW_ERR_INVALID; }
+        const uint32_t n = (uint32_t)live.size();
+        for (uint32_t r = 0; r < n; ++r) {                                  // get_step_data (ppo.rs:46-48)
+            Ep &e = eps[live[r]];
+            env->observe(e.env, &h_obs[(size_t)r * NO]);
+            for (uint32_t c = 0; c < NO; ++c) {
+                const int32_t id = h_obs[(size_t)r * NO + c];
+                if (id < 0 || id >= pd->obs_size) { cleanup(); (void)hipFree(dev); set_error("index out of bounds: obs id %d, obs_size %d", id, pd->obs_size); return TW_ERR_INVALID; }
+            }
+            env->masks(e.env, &h_m[(size_t)r * A]);
+            e.rewards.push_back(env->reward(e.env));
+            int32_t perm = -1;                                               // get_perm_id (policy.rs:67-77)
+            if (pd->n_perms > 0) perm = (int32_t)u32_below(rng_draw(prm->seed, prm->episode_offset + live[r], t, STREAM_PERM).x, (uint32_t)pd->n_perms);
+            h_perm[r] = perm;
+            e.obs.insert(e.obs.end(), &h_obs[(size_t)r * NO], &h_obs[(size_t)r * NO] + NO);
+            e.perms.push_back(perm);
+        }
+        TW_HIP_E(hipMemcpyAsync(dev + o_obs, h_obs.data(), (size_t)n * NO * 4, hipMemcpyHostToDevice, s));
+        TW_HIP_E(hipMemcpyAsync(dev + o_m, h_m.data(), (size_t)n * A, hipMemcpyHostToDevice, s));
+        TW_HIP_E(hipMemcpyAsync(dev + o_p, h_perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        rc = launch_policy_eval(*pd, TW_EVAL_FORWARD, reinterpret_cast<const int32_t *>(dev + o_obs), n, NO, dev + o_m,
+                                reinterpret_cast<const int32_t *>(dev + o_p), reinterpret_cast<float *>(dev + o_la), reinterpret_cast<float *>(dev + o_v), s);
+        if (rc) { cleanup(); (void)hipFree(dev); return rc; }
+        TW_HIP_E(hipMemcpyAsync(h_la.data(), dev + o_la, (size_t)n * A * 4, hipMemcpyDeviceToHost, s));
+        TW_HIP_E(hipMemcpyAsync(h_v.data(), dev + o_v, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        TW_HIP_E(hipStreamSynchronize(s));
+        for (uint32_t r = 0; r < n; ++r) {
+            Ep &e = eps[live[r]];
+            const float *l = &h_la[(size_t)r * A];
+            // sample_from_logits (policy.rs:169-172) + argmax (:130-151): one uniform per element, first maximum wins, NaN never
+            int best = 0; float bv = 0.0f;
+            for (uint32_t i = 0; i < A; ++i) {
+                const u32x4 w = rng_draw(prm->seed, prm->episode_offset + live[r], t | ((i >> 2) << 24), STREAM_GUMBEL);
+                const uint32_t word = (i & 3u) == 0 ? w.x : ((i & 3u) == 1 ? w.y : ((i & 3u) == 2 ? w.z : w.w));
+                const float a1 = tw_logf(u32_to_unit(word));
+                const float gi = l[i] - tw_logf(__builtin_fabsf(a1));
+                if (i == 0) { bv = gi; best = 0; } else if (gi > bv) { bv = gi; best = (int)i; }
+            }
+            e.logits.insert(e.logits.end(), l, l + A);
+            e.values.push_back(h_v[r]);
+            e.actions.push_back(best);
+            if (env->is_final(e.env)) e.alive = false;                      // ppo.rs:78
+            else env->step(e.env, (uint32_t)best);                           // ppo.rs:79
+        }
+    }
+#undef TW_HIP_E
+    (void)hipFree(dev);
+    cleanup();
+
+    // ---- GAE (ppo.rs:82-92) + merge (collector.rs:40-46) into host images of the compact fields ----------------------
+    uint64_t total = 0;
+    for (auto &e : eps) total += e.values.size();
+    std::vector<uint64_t> order(E);
+    for (uint64_t p = 0; p < E; ++p) order[p] = prm->merge_order ? (p == 0 ? E - 1 : p - 1) : p;
+    std::vector<uint8_t> f_obs((size_t)total * NO * OW), f_act(total); std::vector<int8_t> f_perm(total);
+    std::vector<float> f_lg((size_t)total * A), f_val(total), f_rew(total), f_adv(total), f_ret(total);
+    std::vector<uint32_t> f_len(E); std::vector<uint64_t> f_start(E);
+    uint64_t pos = 0;
+    for (uint64_t p = 0; p < E; ++p) {
+        const Ep &e = eps[order[p]];
+        const size_t nrec = e.values.size();
+        f_len[order[p]] = (uint32_t)nrec; f_start[order[p]] = pos;
+        std::vector<float> adv(nrec), ret(nrec);
+        adv[nrec - 1] = e.rewards[nrec - 1] - e.values[nrec - 1];
+        ret[nrec - 1] = e.rewards[nrec - 1];
+        for (size_t tt = nrec - 1; tt-- > 0;) {
+            float inner = prm->lambda * adv[tt + 1];
+            inner = e.values[tt + 1] + inner;
+            inner = prm->gamma * inner;
+            ret[tt] = e.rewards[tt] + inner;
+            adv[tt] = ret[tt] - e.values[tt];
+        }
+        for (size_t tt = 0; tt < nrec; ++tt) {
+            for (uint32_t c = 0; c < NO; ++c) {
+                const int32_t id = e.obs[tt * NO + c];
+                if (OW == 1) f_obs[(pos + tt) * NO + c] = (uint8_t)id;
+                else { const uint16_t v = (uint16_t)id; memcpy(&f_obs[((pos + tt) * NO + c) * 2], &v, 2); }
+            }
+            memcpy(&f_lg[(pos + tt) * A], &e.logits[tt * A], A * 4);
+            f_perm[pos + tt] = (int8_t)e.perms[tt]; f_val[pos + tt] = e.values[tt]; f_rew[pos + tt] = e.rewards[tt];
+            f_act[pos + tt] = (uint8_t)e.actions[tt]; f_adv[pos + tt] = adv[tt]; f_ret[pos + tt] = ret[tt];
+        }
+        pos += nrec;
+    }
+    // ---- the result object: one device allocation ---------------------------------------------------------------------
+    size_t cur = 0, off[TW_F_COUNT] = {}, bytes[TW_F_COUNT] = {};
+    const void *src[TW_F_COUNT] = {};
+    auto put = [&](int f, const void *p, size_t b) { src[f] = p; bytes[f] = b; off[f] = cur; cur = (cur + b + 255) / 256 * 256; };
+    put(TW_F_OBS, f_obs.data(), f_obs.size()); put(TW_F_LOGITS, f_lg.data(), f_lg.size() * 4); put(TW_F_PERMS, f_perm.data(), f_perm.size());
+    put(TW_F_VALUES, f_val.data(), total * 4); put(TW_F_REWARDS, f_rew.data(), total * 4); put(TW_F_ACTIONS, f_act.data(), total);
+    put(TW_F_ADVS, f_adv.data(), total * 4); put(TW_F_RETS, f_ret.data(), total * 4); put(TW_F_EP_LEN, f_len.data(), E * 4); put(TW_F_EP_START, f_start.data(), E * 8);
+    void *arena = nullptr;
+    TW_HIP(hipMalloc(&arena, cur ? cur : 256));
+    void *fp[TW_F_COUNT] = {};
+    for (int f = 0; f < TW_F_COUNT; ++f) if (bytes[f]) {
+        fp[f] = reinterpret_cast<uint8_t *>(arena) + off[f];
+        he = hipMemcpyAsync(fp[f], src[f], bytes[f], hipMemcpyHostToDevice, s);
+        if (he != hipSuccess) { (void)hipFree(arena); return hip_fail(he, "upload of the collected fields", __FILE__, __LINE__); }
+    }
+    he = hipStreamSynchronize(s);
+    if (he != hipSuccess) { (void)hipFree(arena); return hip_fail(he, "upload of the collected fields", __FILE__, __LINE__); }
+    int dev_id = 0; (void)hipGetDevice(&dev_id);
+    rc = collected_adopt(arena, cur ? cur : 256, dev_id, 1, NO, A, total, E, fp, bytes, out);
+    if (rc) { (void)hipFree(arena); return rc; }
+    collected_adopt_obs_width(*out, OW);
+    return TW_OK;
+}

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) policy_eval_generic_kernel(const
             float v = pol.emb_rows[(size_t)pol.obs_size * pol.emb + k];
             for (uint32_t i = 0; i < n_obs; ++i) {
                 int id = obs[(size_t)sample * n_obs + i];
-                if (perm >= 0) id = pol.obs_perms[perm * pol.obs_size + id];
+                if (perm >= 0) id = pol.obs_perms16 ? (int)pol.obs_perms16[(size_t)perm * pol.obs_size + id] : (int)pol.obs_perms[perm * pol.obs_size + id];
                 v = v + pol.emb_rows[(size_t)id * pol.emb + k];
             }
             if (pol.emb_relu) v = v > 0.0f ? v : 0.0f;

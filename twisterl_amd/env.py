@@ -135,12 +135,66 @@ class Puzzle(PyBaseEnv):
         return int(_lib.lib().tw_puzzle_depth(self._h))
 
 
+class PyEnv:
+    """PyEnv(pyenv): an environment implemented in Python (reference rust/src/python_interface/pyenv.rs:41-160,
+    src/twisterl/envs/__init__.py:20-25).  `pyenv` provides the methods the reference calls on it: copy(), num_actions(),
+    obs_shape(), reset(difficulty), next(action), masks(), is_final(), value(), success(), observe(), set_state(state).
+    Its code runs on the host -- as in the reference -- while the policy forward of all live episodes of a time step is one
+    batched launch on the GPU (tw_ppo_collect_env).  Build extension: if `pyenv` has seed_episode(seed, episode) it is
+    called before every reset(), so that a collect is reproducible (the reference's envs draw from OS entropy)."""
+
+    def __init__(self, pyenv):
+        for m in ("copy", "num_actions", "obs_shape", "reset", "next", "masks", "is_final", "value", "observe"):
+            if not callable(getattr(pyenv, m, None)):
+                raise TypeError(f"PyEnv: the environment object has no method {m}()")
+        self._env = pyenv
+        self._difficulty = 1                                   # PyEnvImpl::new (pyenv.rs:41-45)
+
+    def __extract_env__(self) -> int:
+        return id(self)
+
+    difficulty = property(lambda self: self._difficulty, lambda self, d: setattr(self, "_difficulty", int(d)))
+
+    def num_actions(self) -> int:
+        return int(self._env.num_actions())
+
+    def obs_shape(self) -> list:
+        return [int(x) for x in self._env.obs_shape()]
+
+    def set_state(self, state) -> None:
+        self._env.set_state([int(x) for x in state])
+
+    def reset(self) -> None:
+        self._env.reset(self._difficulty)
+
+    def step(self, action: int) -> None:
+        self._env.next(int(action))
+
+    def masks(self) -> list:
+        return [bool(m) for m in self._env.masks()]
+
+    def is_final(self) -> bool:
+        return bool(self._env.is_final())
+
+    def reward(self) -> float:
+        return float(self._env.value())
+
+    def observe(self) -> list:
+        return [int(x) for x in self._env.observe()]
+
+    def twists(self):
+        return ([], [])                                        # Env::twists default (rl/env.rs:59)
+
+
 def get_env_desc(py_env) -> "_lib.PuzzleDesc":
     """Counterpart of get_env() (env.rs:163-177).  The reference turns the integer returned by
     `__extract_env__` back into a Rust Box<dyn Env>; this library can only run envs whose
     dynamics it implements on the GPU, so the object must be one of ours."""
     if not hasattr(py_env, "__extract_env__"):
         raise TypeError("Object must implement __extract_env__ method")
+    if isinstance(py_env, PyEnv):
+        raise TypeError("environments implemented in Python are collected by PPOCollector (tw_ppo_collect_env); self-play, "
+                        "evaluate and solve run environments whose dynamics the library implements on the GPU (Puzzle)")
     if not isinstance(py_env, PyBaseEnv):
         raise TypeError("Expected environment of type twisterl_amd.env.Puzzle "
                         "(the HIP collectors cannot run a foreign Box<dyn Env>)")
