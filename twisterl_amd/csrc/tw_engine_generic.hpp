@@ -27,6 +27,9 @@ struct EngineV {
     int tid, lane, wave, j, h, g;
     float *lds0, *lds_out, *lds_user;
     const uint8_t *perm_obs, *perm_act;
+#ifdef TW_ABLATE
+    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};      // (cycle stamps of the diagnostic build: none inside this engine)
+#endif
 
     // three activation buffers (the common output stays put while the two heads run) | head outputs [16][8] | kernel use
     __host__ __device__ static size_t lds_floats(int) { return (size_t)3 * GEN_MAX_WIDTH * GEN_COLS + GEN_COLS * 8 + 256; }

@@ -63,31 +63,22 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32
 
     const PuzzleConsts env = a.env;
     const int j = eng.j, h = eng.h;
-    uint64_t e_local  = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)eng.ep_lane();
-    const bool valid  = e_local < a.num_episodes;
+    // Loop-carried per-episode state is kept to five registers (board, depth, episode, t): everything derivable (blank position,
+    // global episode index, record address, obs-id constants) is recomputed after the forward -- held across it, those were the
+    // registers the 8-wave x 256-accumulator shape spilled to scratch.
+    const uint64_t e_first = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)eng.ep_lane();
+    const bool valid  = e_first < a.num_episodes;
     const bool writer = h == 0 && eng.primary();          // the lane that stores the episode's records
-    uint64_t e_global = a.episode_offset + e_local;
-
-    PuzzleLane st;
-    st.board = env.ident; st.zx = 0; st.zy = 0; st.depth = 0;
-    auto take = [&](uint64_t e) {                         // persistent mode: start board of episode e from the pre-pass
-        st.board = a.init_boards[e];
-        const int z = blank_cell(st.board);
-        st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
-    };
+    uint32_t e_local = (uint32_t)e_first;                 // (launch_geom bounds the episode count of a launch to 2^31)
+    uint64_t board = env.ident; int depth = 0;
     if (valid) {
-        if constexpr (PERSIST) take(e_local);
-        else puzzle_reset(st, env, a.seed, e_global);
+        if constexpr (PERSIST) { board = a.init_boards[e_local]; depth = env.depth0; }      // start boards from the pre-pass
+        else { PuzzleLane s0; puzzle_reset(s0, env, a.seed, a.episode_offset + e_first); board = s0.board; depth = s0.depth; }
     }
 
     bool     alive = valid;
     bool     more  = PERSIST;                             // the queue may still hold episodes
-    int      t = 0;
-    uint32_t len = 0;
-    uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
-
-    uint32_t obs_base[4];
-    obs_base_words(env.n_cells, obs_base);
+    int      t = 0;                                       // (stays at the last record once the episode is over: records = t + 1)
 
     eng.begin2();
     // (the barrier inside __syncthreads_or publishes the first two ring slots and the LDS constants)
@@ -96,15 +87,17 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32
         // ---- observe (puzzle.rs:183-185) + twist of the obs ids (policy.rs:67-83) -------------
         int perm = -1;
         if (eng.pol.n_perms > 0) {
-            const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_PERM);
+            const u32x4 w = rng_draw(a.seed, a.episode_offset + (uint64_t)e_local, (uint32_t)t, STREAM_PERM);
             perm = (int)u32_below(w.x, (uint32_t)eng.pol.n_perms);
         }
         int rowoff[NC];
-        eng.rows_of(st.board, env.n_cells, perm, rowoff);
+        eng.rows_of(board, env.n_cells, perm, rowoff);
 
         float lg[4]; float value;
         eng.forward(rowoff, lg, value);
 
+        PuzzleLane st; st.board = board; st.depth = depth;
+        { const int z = blank_cell(board); st.zx = z % env.width; st.zy = z / env.width; }
         float rew = 0.0f; int action = t & 3;
         if constexpr (!(DBG & 8)) {
             eng.act_perm(perm, lg);
@@ -112,21 +105,22 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32
 #pragma unroll
             for (int i = 0; i < 4; ++i) lg[i] = ((mb >> i) & 1u) ? lg[i] : -1e10f;   // policy.rs:62
             rew = puzzle_reward(st, env);
-            const u32x4 gw = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_GUMBEL);
+            const u32x4 gw = rng_draw(a.seed, a.episode_offset + (uint64_t)e_local, (uint32_t)t, STREAM_GUMBEL);
             action = gumbel_argmax4(lg, gw);
         }
         // ---- push the record (ppo.rs:71-76), then is_final / step (ppo.rs:78-79) --------------
         if (alive) {
             if (writer) {
-                const uint64_t rec = rec_base + (uint64_t)t;
-                uint32_t pk[4];
-                obs_bytes(st.board, obs_base, pk);
+                const uint64_t rec = (uint64_t)e_local * (uint64_t)a.out.t_pad + (uint64_t)t;
+                uint32_t obs_base[4], pk[4];
+                obs_base_words(env.n_cells, obs_base);
+                obs_bytes(board, obs_base, pk);
                 store_rec(a.out.rec + rec, pk, lg, value, rew, action, perm);
             }
             if (puzzle_final(st, env)) {
-                alive = false; len = (uint32_t)t + 1u;
-                if constexpr (PERSIST) { if (writer) a.out.ep_len[e_local] = len; }
-            } else { puzzle_step(st, env, action); ++t; }
+                alive = false;
+                if constexpr (PERSIST) { if (writer) a.out.ep_len[e_local] = (uint32_t)t + 1u; }
+            } else { puzzle_step(st, env, action); board = st.board; depth = st.depth; ++t; }
         }
         if constexpr (PERSIST) {
             const bool want = !alive && more;             // take the next episode off the queue (every lane of the episode the same one)
@@ -140,14 +134,14 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32
             } else got = (unsigned)__shfl((int)got, j, 64);
             if (want) {
                 if ((uint64_t)got < a.num_episodes) {
-                    e_local = got; e_global = a.episode_offset + e_local; rec_base = e_local * (uint64_t)a.out.t_pad;
-                    take(e_local);
+                    e_local = got;
+                    board = a.init_boards[e_local]; depth = env.depth0;
                     alive = true; t = 0;
                 } else more = false;
             }
         }
     }
-    if constexpr (!PERSIST) { if (valid && writer) a.out.ep_len[e_local] = len; }
+    if constexpr (!PERSIST) { if (valid && writer) a.out.ep_len[e_local] = (uint32_t)t + 1u; }
     eng.end();
 }
 
