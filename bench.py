@@ -173,6 +173,11 @@ def main():
         # started plainly (`python bench.py --gpus N`): become the launcher of N ranks BEFORE anything touches torch or HIP
         raise SystemExit(self_launch(args, argv))
 
+    # stdout carries ONE line (rank 0's JSON); libraries that print there (RCCL's version banner) go to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import twisterl_amd
     from twisterl_amd import _lib, twisterl
@@ -335,7 +340,10 @@ def main():
             out["f16_input_mode"] = side_mode("fp16")
         if not args.no_cpu_baseline and world == 1 and not use_dist:     # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds, args.cpu_threads)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -121,7 +121,7 @@ def _worker(rank, world, port, E, chunks, q):
             ok2 = ok2 and (_same(merged, full) if rank == 0 else merged is None)
         # every rank issued K steps; its collects cover exactly its chunk-major ranges; CUs are reserved only while pipelining
         mine = [chunk_range(bounds, s, rank, world) for s in range(K)]
-        want = [(a, b - a, 8 if (world > 1 and K > 1) else 0) for (a, b) in mine if b > a]
+        want = [(a, b - a, 8 if (world > 1 and K > 1 and s < K - 1) else 0) for s, (a, b) in enumerate(mine) if b > a]
         ok3 = coll.calls == want + want
         covered = sorted(chunk_range(bounds, s, r, world) for s in range(K) for r in range(world))
         ok3 = ok3 and covered[0][0] == 0 and covered[-1][1] == E and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))

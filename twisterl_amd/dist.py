@@ -302,13 +302,14 @@ def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None,
     if reserve_cus is None:
         reserve_cus = DEFAULT_RESERVE_CUS if (world > 1 and K > 1 and gather) else 0
 
-    def run(a, b):
+    def run(a, b, last_step=False):
         local = copy.copy(collector)
         local.num_episodes = b - a
         local.episode_offset = collector.episode_offset + a
         local.merge_order = False
         if hasattr(local, "reserve_cus"):
-            local.reserve_cus = int(reserve_cus)
+            # nothing is collected after the last step, so it has no later transfer to make room for: it runs on every CU
+            local.reserve_cus = 0 if last_step else int(reserve_cus)
         return local.collect(env, policy, seed=seed)
 
     if gather and comm is not None:
@@ -319,7 +320,7 @@ def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None,
         datas = []
         for s in range(K):
             a, b = chunk_range(bounds, s, rank, world)
-            d = run(a, b) if b > a else None
+            d = run(a, b, s == K - 1) if b > a else None
             if d is not None:
                 datas.append(d)
             rg.submit(d, a)
@@ -339,7 +340,7 @@ def collect_sharded(collector, env, policy, seed: int, dst: int = 0, group=None,
     for s in range(K):
         a, b = chunk_range(bounds, s, rank, world)
         if b > a:
-            d = run(a, b)
+            d = run(a, b, s == K - 1)
             datas.append(d)
             if tg is not None:
                 template, ep_len = _split_fields(d)
