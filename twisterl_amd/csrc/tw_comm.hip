@@ -270,33 +270,40 @@ extern "C" int tw_gather_submit(tw_gather *g, const tw_collected *local, uint64_
         return 1;
     };
 
-    TW_NCCL(g_rccl.GroupStart());
-    if (rank == g->root) {
-        for (int r = 0; r < world; ++r) {
-            Piece pc[2]; const int np = pieces(r, pc);
-            const uint64_t er = all[(size_t)r * 4 + 2], eo = all[(size_t)r * 4 + 3];
-            if (r == rank) {
-                for (int i = 0; i < np; ++i)
-                    for (int f = 0; f < TW_F_COUNT; ++f) if (g->width[f])
-                        TW_HIP(hipMemcpyAsync(g->base[f] + pc[i].dst * g->width[f], reinterpret_cast<const uint8_t *>(collected_field(local, f)) + pc[i].lo * g->width[f],
-                                              (pc[i].hi - pc[i].lo) * g->width[f], hipMemcpyDeviceToDevice, s));
-                if (er) TW_HIP(hipMemcpyAsync(g->ep_len + eo, collected_field(local, TW_F_EP_LEN), er * 4, hipMemcpyDeviceToDevice, s));
-            } else {
-                for (int i = 0; i < np; ++i)
-                    for (int f = 0; f < TW_F_COUNT; ++f) if (g->width[f])
-                        TW_NCCL(g_rccl.Recv(g->base[f] + pc[i].dst * g->width[f], (pc[i].hi - pc[i].lo) * g->width[f], ncclChar, r, c->comm, s));
-                if (er) TW_NCCL(g_rccl.Recv(g->ep_len + eo, er, ncclUint32, r, c->comm, s));
+    // (a failure inside the group still closes it: RCCL keeps a thread-local group depth)
+    auto transfers = [&]() -> int {
+        if (rank == g->root) {
+            for (int r = 0; r < world; ++r) {
+                Piece pc[2]; const int np = pieces(r, pc);
+                const uint64_t er = all[(size_t)r * 4 + 2], eo = all[(size_t)r * 4 + 3];
+                if (r == rank) {
+                    for (int i = 0; i < np; ++i)
+                        for (int f = 0; f < TW_F_COUNT; ++f) if (g->width[f])
+                            TW_HIP(hipMemcpyAsync(g->base[f] + pc[i].dst * g->width[f], reinterpret_cast<const uint8_t *>(collected_field(local, f)) + pc[i].lo * g->width[f],
+                                                  (pc[i].hi - pc[i].lo) * g->width[f], hipMemcpyDeviceToDevice, s));
+                    if (er) TW_HIP(hipMemcpyAsync(g->ep_len + eo, collected_field(local, TW_F_EP_LEN), er * 4, hipMemcpyDeviceToDevice, s));
+                } else {
+                    for (int i = 0; i < np; ++i)
+                        for (int f = 0; f < TW_F_COUNT; ++f) if (g->width[f])
+                            TW_NCCL(g_rccl.Recv(g->base[f] + pc[i].dst * g->width[f], (pc[i].hi - pc[i].lo) * g->width[f], ncclChar, r, c->comm, s));
+                    if (er) TW_NCCL(g_rccl.Recv(g->ep_len + eo, er, ncclUint32, r, c->comm, s));
+                }
             }
+        } else {
+            Piece pc[2]; const int np = pieces(rank, pc);
+            for (int i = 0; i < np; ++i)
+                for (int f = 0; f < TW_F_COUNT; ++f) if (g->width[f])
+                    TW_NCCL(g_rccl.Send(reinterpret_cast<const uint8_t *>(collected_field(local, f)) + pc[i].lo * g->width[f], (pc[i].hi - pc[i].lo) * g->width[f],
+                                        ncclChar, g->root, c->comm, s));
+            if (e_local) TW_NCCL(g_rccl.Send(collected_field(local, TW_F_EP_LEN), e_local, ncclUint32, g->root, c->comm, s));
         }
-    } else {
-        Piece pc[2]; const int np = pieces(rank, pc);
-        for (int i = 0; i < np; ++i)
-            for (int f = 0; f < TW_F_COUNT; ++f) if (g->width[f])
-                TW_NCCL(g_rccl.Send(reinterpret_cast<const uint8_t *>(collected_field(local, f)) + pc[i].lo * g->width[f], (pc[i].hi - pc[i].lo) * g->width[f],
-                                    ncclChar, g->root, c->comm, s));
-        if (e_local) TW_NCCL(g_rccl.Send(collected_field(local, TW_F_EP_LEN), e_local, ncclUint32, g->root, c->comm, s));
-    }
-    TW_NCCL(g_rccl.GroupEnd());
+        return TW_OK;
+    };
+    TW_NCCL(g_rccl.GroupStart());
+    const int trc = transfers();
+    const ncclResult_t gend = g_rccl.GroupEnd();
+    if (trc) return trc;
+    if (gend != ncclSuccess) return nccl_fail(gend, "ncclGroupEnd", __LINE__);
     g->pos = p;
     g->step += 1;
     return TW_OK;
