@@ -1,0 +1,6 @@
+#!/bin/bash
+# cycle stamps of the generic engine's forward (diagnostic TW_ABLATE build).  Run on the GPU box from the repo root.
+set -e
+out=$PWD/gpurun_out/genst; mkdir -p $out
+TW_ABLATE=1 python3 -m twisterl_amd.build --force > $out/build.log 2>&1
+TW_STAMPS=1 python3 scripts/bench_generic_engine.py 2>&1 | grep -v amdgpu.ids | tee $out/stamps.log

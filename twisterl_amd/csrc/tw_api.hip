@@ -419,14 +419,18 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
     for (uint32_t i = 0; i < d->n_common; ++i) all.push_back(&d->common[i]);
     for (uint32_t i = 0; i < d->n_action; ++i) all.push_back(&d->action[i]);
     for (uint32_t i = 0; i < d->n_value; ++i) all.push_back(&d->value[i]);
-    for (uint32_t i = 0; i < n_layers; ++i) { o_w[i] = seg((size_t)all[i]->in_features * all[i]->out_features * 4); o_b[i] = seg((size_t)all[i]->out_features * 4 + 16); }
+    // every layer's outputs are padded to a multiple of four (zero weight columns, zero bias): the engine works on output quads
+    auto pad4 = [](uint32_t x) { return (x + 3u) & ~3u; };
+    for (uint32_t i = 0; i < n_layers; ++i) { o_w[i] = seg((size_t)all[i]->in_features * pad4(all[i]->out_features) * 4); o_b[i] = seg((size_t)pad4(all[i]->out_features) * 4 + 16); }
     std::vector<uint8_t> img(cur, 0);
     float *emb = reinterpret_cast<float *>(img.data() + o_emb);
     memcpy(emb, d->emb_vectors, (size_t)OS * E * 4);
     memcpy(emb + (size_t)OS * E, d->emb_bias, (size_t)E * 4);
     for (uint32_t i = 0; i < n_layers; ++i) {
-        memcpy(img.data() + o_w[i], all[i]->weights, (size_t)all[i]->in_features * all[i]->out_features * 4);
-        memcpy(img.data() + o_b[i], all[i]->bias, (size_t)all[i]->out_features * 4);
+        const uint32_t in = all[i]->in_features, out = all[i]->out_features, outp = pad4(out);
+        float *wd = reinterpret_cast<float *>(img.data() + o_w[i]);
+        for (uint32_t k = 0; k < in; ++k) memcpy(wd + (size_t)k * outp, all[i]->weights + (size_t)k * out, (size_t)out * 4);
+        memcpy(img.data() + o_b[i], all[i]->bias, (size_t)out * 4);
     }
     for (uint32_t p = 0; p < d->n_perms; ++p) {
         for (uint32_t i = 0; i < OS; ++i) {
@@ -445,7 +449,7 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
     LayerDev *tab = reinterpret_cast<LayerDev *>(img.data() + o_tab);          // device pointers go into the table before the upload
     for (uint32_t i = 0; i < n_layers; ++i) {
         tab[i].w = reinterpret_cast<const float *>(base + o_w[i]); tab[i].b = reinterpret_cast<const float *>(base + o_b[i]);
-        tab[i].in = (int32_t)all[i]->in_features; tab[i].out = (int32_t)all[i]->out_features; tab[i].relu = all[i]->apply_relu ? 1 : 0; tab[i].pad = 0;
+        tab[i].in = (int32_t)all[i]->in_features; tab[i].out = (int32_t)pad4(all[i]->out_features); tab[i].relu = all[i]->apply_relu ? 1 : 0; tab[i].pad = 0;
     }
     e = hipMemcpy(pol->arena, img.data(), img.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hip_fail(e, "policy upload", __FILE__, __LINE__); (void)hipFree(pol->arena); delete pol; return nullptr; }
