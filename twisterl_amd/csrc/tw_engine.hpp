@@ -2,6 +2,7 @@
 // (AlphaZero) and solve/evaluate kernels: EmbeddingBag gather + common Linear on f32 MFMA + both heads,
 // with both weight streams running through a ring of LDS slots.  See tw_rollout.hip for the design notes.
 #pragma once
+#include <type_traits>
 #include "tw_common.hpp"
 #include "tw_engine_generic.hpp"
 #include <cstdlib>
@@ -55,6 +56,10 @@ __device__ __forceinline__ float relu_lim_v(float x, float lim)
     asm("v_max_f32 %0, %1, %2" : "=v"(y) : "s"(lim), "v"(x));
     return y;
 }
+
+#ifdef TW_ABLATE   // timing-only switches of the diagnostic build, per translation unit (TW_ENG_DBG: 4 = no weight / table streams)
+static __device__ int g_eng_dbg;
+#endif
 
 template <int NT> struct Tiles { static constexpr int NQ = (NT + 3) / 4; };
 
@@ -124,11 +129,17 @@ struct Engine3 {
     // everything wave-dependent is folded into dsrc_* / ddst_* at begin1: an op costs two 64-bit scalar adds, one 32-bit add
     // and the M0 write (the generic form spent 9 scalar instructions per op, which a lone wave per SIMD cannot hide).
     static_assert(WPIECE % NW == 0, "W1 pieces per chunk must be a multiple of the wave count");
+#ifdef TW_ABLATE
+    int eng_dbg = 0;
+#endif
     const uint8_t *dsrc_w, *dsrc_t;        // image bases (+ this wave's first W1 piece)
     uint32_t ddst_w, ddst_t;               // LDS byte addresses of ring slot 0 (+ this wave's first W1 piece)
     __device__ __forceinline__ void stream_op(int chunk, int slot, int op)
     {
         if constexpr (DBG & 4) return;
+#ifdef TW_ABLATE
+        if (eng_dbg & 4) return;
+#endif
         if (NW * op < WPIECE) {
             const uint8_t *src = dsrc_w + (size_t)chunk * (WSLOT * 4) + (size_t)op * (NW * 1024);
             const uint32_t dst = ddst_w + (uint32_t)slot * (WSLOT * 4) + (uint32_t)op * (NW * 1024);
@@ -146,6 +157,9 @@ struct Engine3 {
     __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
     {
         pol = p;
+#ifdef TW_ABLATE
+        eng_dbg = __builtin_amdgcn_readfirstlane(g_eng_dbg);
+#endif
         tid  = threadIdx.x;
         lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -659,13 +673,26 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int NT, int NC>
 struct Engine3T : Engine3<NT, NC, 0, 4> {
     using B = Engine3<NT, NC, 0, 4>;
-    static constexpr int NS = 4, EPB = 16, TPW = NT / 2, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, NOPS = B::NOPS, H = NT * 32;
+    static constexpr int NS = 4, EPB = 16, TPW = NT / 2, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, H = NT * 32;
+    static constexpr int WOPS = B::WPIECE / 4, TOPS = (B::TPIECE + 3) / 4, NOPS = WOPS + TOPS;   // DMA ops per wave and chunk: W1 pieces, table pieces
     static constexpr bool SPLIT = true;
     static_assert(NT == 8 || NT == 4, "Engine3T: 128 or 256 hidden units");
 
     float *lds_x, *lds_user;
+    // The weight / table streams of this engine.  A lone wave per SIMD issues one instruction every 4..5 cycles whatever its kind
+    // (measured: the chunk loop with 16 MFMAs and ~150 other instructions ran 970 cycles per chunk against 512 of matrix time;
+    // the same forward on 16 waves, four per SIMD, ran SLOWER -- the SIMD issues ~one instruction per 4 cycles for all its waves
+    // together), so the instruction count is the bound.  A stream op is therefore: M0 = this wave's piece address + a literal
+    // (slot and piece), the DMA instruction with a per-op lane offset kept in a VGPR, and nothing else; the source is a running
+    // pointer to the chunk streamed next (the ring runs on from one forward into the next).
+    // The ring position is a compile-time fact: a forward always starts in slot 0 -- its chunk sequence is padded to a multiple
+    // of three steps (0..2 "bubble" steps that only stream; 1 of 33 for a 512-wide embedding), so the slot offsets of all LDS
+    // reads are immediates and the loop body is three straight-line steps.
+    const uint8_t *swp, *stp;
+    int sv, n3;                            // virtual step whose data is streamed next (sv == step + 2); steps per forward (multiple of 3)
+    uint32_t voffW[WOPS], voffT[TOPS], mT[TOPS];
 #ifdef TW_ABLATE
-    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk compute | vmcnt wait | barrier wait | heads | -
+    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk loop | - | - | heads | -
 #endif
 
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
@@ -675,10 +702,26 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
 
     __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
     {
-        B::begin1(p, lds);
+        B::begin1(p, lds);                 // (streams chunks 0 and 1 into slots 0 and 1)
         this->j = this->lane & 15; this->h = this->lane >> 4;
         lds_x = lds + engine3_lds_floats<NT>(p.obs_size);
         lds_user = lds_x + R3S_XCHG;
+        n3 = (this->n_chunks + 2) / 3 * 3;
+        sv = 2;                            // (B::begin1 streamed steps 0 and 1)
+        {
+            const int first = 2 < this->n_chunks ? 2 : 0;                        // a bubble step gets chunk 0's data (never read)
+            swp = this->dsrc_w + (size_t)first * (WSLOT * 4);
+            stp = this->dsrc_t + (size_t)first * (R3_TSLOT * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < WOPS; ++k) voffW[k] = this->voff + (uint32_t)k * 4096u;            // piece wave + 4k (dsrc_w / ddst_w carry the wave)
+#pragma unroll
+        for (int k = 0; k < TOPS; ++k) {
+            int tp = this->wave + 4 * k;
+            tp = tp < B::TPIECE ? tp : B::TPIECE - 1;                                           // past the end: repeat the last piece
+            mT[k] = this->ddst_t + (uint32_t)tp * 1024u;
+            voffT[k] = this->voff + (uint32_t)tp * 1024u;
+        }
     }
 
     __device__ __forceinline__ void rows_of(uint64_t board, int n_cells, int perm, int (&rowoff)[NC]) const
@@ -694,6 +737,17 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         }
     }
 
+    template <int S, int OP>   // DMA op OP of this wave: a piece of chunk sc_next into ring slot S
+    __device__ __forceinline__ void stream() const
+    {
+        if constexpr (OP < WOPS)
+            asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                         :: "v"(voffW[OP]), "s"(this->ddst_w), "i"(S * WSLOT * 4 + OP * 4096), "s"(swp) : "memory", "m0", "scc");
+        else
+            asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                         :: "v"(voffT[OP - WOPS]), "s"(mT[OP - WOPS]), "i"(S * R3_TSLOT * 4), "s"(stp) : "memory", "m0", "scc");
+    }
+
     __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
     {
         typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
@@ -707,30 +761,24 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         const int half = wave >> 1;
         const int q    = NT == 8 ? (wave & 1) : 0;
         const int cc0  = NT == 8 ? 0 : 2 * (wave & 1);
-        const int a_off = (kq * NQ + q) * 128 + (16 * half + jj) * 4 + cc0;      // + g * 4*NQ*128 for k-group g
-        // gather: k-group `wave`, this lane's k = 4*wave + kq of the chunk -> position in the [even k | odd k] row image
-        const int gpos = (kq & 1) * 8 + 2 * wave + (kq >> 1);
+        lds_cfloat *abase = (lds_cfloat *)this->lds_w + (kq * NQ + q) * 128 + (16 * half + jj) * 4 + cc0;   // + slot, + g * 4*NQ*128 for k-group g
+        // gather: k-group `wave`, this lane's k = 4*wave + kq of the chunk -> position in the [even k | odd k] row image.
+        // One LDS address per row for the whole forward: the ring slot is an immediate offset of the read.
+        lds_cfloat *gb = (lds_cfloat *)this->lds_t + ((kq & 1) * 8 + 2 * wave + (kq >> 1));
         lds_cfloat *ga[NC + 1];
-        ga[0] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT + this->bias_row * R3_LSTR) + gpos;
+        ga[0] = gb + this->bias_row * R3_LSTR;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) ga[c + 1] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT) + rowoff[c] + gpos;
+        for (int c = 0; c < NC; ++c) ga[c + 1] = gb + rowoff[c];
 
         float *xb = lds_x + 256;                                                  // [2 buffers][64 lanes][4 k-groups]
         float gr[NC + 1];
-        auto gather_read = [&](int c) { gr[c] = *ga[c]; };
         auto gather_finish = [&](int buf) {
             float sm = gr[0];                                                     // bias row, then the cells in order
 #pragma unroll
             for (int c = 1; c <= NC; ++c) sm = sm + gr[c];
             xb[(buf * 64 + this->lane) * 4 + wave] = relu_lim_v(sm, this->emb_lim);
         };
-        auto advance = [&](int from, int to) {
-            const int delta = (to - from) * R3_TSLOT;
-#pragma unroll
-            for (int c = 0; c <= NC; ++c) ga[c] += delta;
-        };
-        auto read_a = [&](lds_cfloat *base, int g, float (&a)[TPW]) {
-            lds_cfloat *ap = base + g * (4 * NQ * 128);
+        auto read_a = [&](lds_cfloat *ap, float (&a)[TPW]) {
             if constexpr (TPW == 4) {
                 const f32x4 v = *reinterpret_cast<lds_cf4 *>(ap);
                 a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
@@ -740,60 +788,70 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             }
         };
 
-        int s0 = this->rp;
         float aw[TPW];
-        TW_S3(q_in);
-        read_a((lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off), 0, aw);
-        {
-            const int s1 = s0 == 2 ? 0 : s0 + 1;
+        int par = 0;                                                              // B-operand buffer of the current chunk
+        // the data of virtual step sv has been requested: move on (chunk sv, or chunk 0 again for a bubble, or the next forward's)
+        auto stream_advance = [&]() {
+            ++sv; swp += WSLOT * 4; stp += R3_TSLOT * 4;
+            if (sv == this->n_chunks || sv == n3) { swp = this->dsrc_w; stp = this->dsrc_t; }
+            if (sv == n3) sv = 0;
+        };
+        // One step with the ring slots as compile-time facts (S0: this chunk, S1: the next one -- complete, S2: streamed now)
+        auto step = [&](auto s0c, int c) {
+            constexpr int S0 = decltype(s0c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
+            constexpr int M = 4 * TPW;
+            if (c < this->n_chunks) {
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(xb + (par * 64 + this->lane) * 4);
 #pragma unroll
-            for (int c = 0; c <= NC; ++c) gather_read(c);
+                for (int m = 0; m < M; ++m) {
+                    constexpr_for_ops<S2>(m, M);
+                    const int g = m / TPW, t = m % TPW;
+                    // (inline asm, accumulators pinned to VGPRs: with the intrinsic the register allocator keeps the loop-carried
+                    //  accumulators in VGPRs and the MFMA results in AGPRs and copies all 16 both ways every chunk.  Operands come
+                    //  from LDS reads (waitcnt is the compiler's); the same accumulator is TPW MFMAs apart, which the matrix pipe
+                    //  interlocks; results are read long after the last MFMA, see below.)
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(aw[t]), "v"(bq[g]));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int cq = m * (NC + 1) / M; cq < (m + 1) * (NC + 1) / M; ++cq) gr[cq] = ga[cq][S1 * R3_TSLOT];   // step c+1, complete in slot S1
+                    if (t == TPW - 1) {
+                        if (g < 3) read_a(abase + S0 * WSLOT + (g + 1) * (4 * NQ * 128), aw); else read_a(abase + S1 * WSLOT, aw);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                gather_finish(par ^ 1);
+                par ^= 1;
+            } else {                                                              // bubble: only the streams
+                constexpr_for_ops<S2>(0, 1);
+            }
+            stream_advance();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+
+        TW_S3(q_in);
+        {
+            read_a(abase, aw);                                                    // slot 0
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) gr[c] = ga[c][0];
             gather_finish(0);
-            advance(s0, s1);
             __syncthreads();
         }
         TW_S3(q_pro);
         TW_A3(0, q_in, q_pro);
-        for (int c = 0; c < this->n_chunks; ++c) {
-            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-            int sc = c + 2; if (sc >= this->n_chunks) sc -= this->n_chunks;       // chunk streamed now (wraps into the next forward)
-            if (this->n_chunks == 1) sc = 0;
-            TW_S3(q_c0);
-            const f32x4 bq = *reinterpret_cast<const f32x4 *>(xb + ((c & 1) * 64 + this->lane) * 4);
-            lds_cfloat *wb = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
-            lds_cfloat *wn = (lds_cfloat *)(this->lds_w + s1 * WSLOT + a_off);
-            constexpr int M = 4 * TPW;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const int g = m / TPW, t = m % TPW;
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t], bq[g], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int op = m * NOPS / M; op < (m + 1) * NOPS / M; ++op) this->stream_op(sc, s2, op);
-#pragma unroll
-                for (int cq = m * (NC + 1) / M; cq < (m + 1) * (NC + 1) / M; ++cq) gather_read(cq);   // chunk c+1, complete in slot s1
-                if (t == TPW - 1) {
-                    if (g < 3) read_a(wb, g + 1, aw); else read_a(wn, 0, aw);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            gather_finish((c + 1) & 1);
-            advance(s1, s2);
-            TW_S3(q_c1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TW_S3(q_c2);
-            __syncthreads();
-            TW_S3(q_c3);
-            TW_A3(1, q_c0, q_c1); TW_A3(2, q_c1, q_c2); TW_A3(3, q_c2, q_c3);
-            s0 = s1;
+        for (int c = 0; c < n3; c += 3) {
+            step(std::integral_constant<int, 0>{}, c);
+            step(std::integral_constant<int, 1>{}, c + 1);
+            step(std::integral_constant<int, 2>{}, c + 2);
         }
-        this->rp = s0;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> vector ALU: the wait states the compiler would count for the intrinsic
+        TW_S3(q_lp);
+        TW_A3(1, q_pro, q_lp);
 
         // heads: hidden units -> freed table slot as [unit/4][16 episodes][4], then one v_fma_f32 chain per (episode, output)
         TW_S3(q_h0);
         {
-            const int fs = s0 == 0 ? 2 : s0 - 1;
-            float *hid = this->lds_t + fs * R3_TSLOT;
+            float *hid = this->lds_t + 2 * R3_TSLOT;                              // the last step's table slot: free until step 0 of the next forward streams into it
             // D row 4*kq + r of local tile t is hidden unit 32*(4q + cc0 + t) + 2*(r + 8*half + 4*(kq>>1)) + (kq&1)
             const int ublk = 8 * half + 4 * (kq >> 1);                            // the lane-dependent part of g'
             float *dst = hid + (8 * (4 * q + cc0) + 2 * (2 * half + (kq >> 1))) * 64 + jj * 4 + (kq & 1);
@@ -824,9 +882,18 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         TW_S3(q_h1);
         TW_A3(4, q_h0, q_h1);
     }
+
+    // the DMA ops of MFMA slot m of M: ops [m*NOPS/M, (m+1)*NOPS/M) of this wave, into ring slot S
+    template <int S, int OP = 0>
+    __device__ __forceinline__ void constexpr_for_ops(int m, int M) const
+    {
+        if constexpr (OP < NOPS) {
+            if (OP >= m * NOPS / M && OP < (m + 1) * NOPS / M) stream<S, OP>();     // (m is a constant after unrolling: one op survives)
+            constexpr_for_ops<S, OP + 1>(m, M);
+        }
+    }
 };
 
-constexpr int geom_threads(int nw) { return (nw == -16 || nw == -64) ? 256 : 64 * (nw < 0 ? -nw : nw); }
 // launch geometry code -> engine: NW > 0 = NW independent waves of 32 episodes (Engine3); NW < 0 = -NW waves sharing 32 (Engine3S)
 template <int NT, int NC, int DBG, int NW> struct Geom { using Eng = Engine3<NT, NC, DBG, NW>; static constexpr int WAVES = NW; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -4> { using Eng = Engine3S<NT, NC, 4>; static constexpr int WAVES = 4; };

@@ -48,7 +48,7 @@ __device__ inline PuzzleLane lane_of(const MctsNode &n, const PuzzleConsts &c)
 }
 
 template <int NT, int NC, int NW, bool PERSIST = false>
-__global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) mcts_f32_kernel(const MctsArgs a)
+__global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 2 : 1)) mcts_f32_kernel(const MctsArgs a)
 {
     using Eng = typename Geom<NT, NC, 0, NW>::Eng;
     extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -53,8 +53,12 @@ int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_
     return TW_OK;
 }
 
+#ifdef TW_ABLATE   // diagnostic build: cycle stamps of the generic engine (TW_STAMPS=1 prints them per launch)
+__device__ unsigned long long g_gen_stamps[8];
+#endif
+
 template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
-__global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32_kernel(const RolloutArgs a)
+__global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), (NW == 8 ? 2 : 1)) rollout_f32_kernel(const RolloutArgs a)
 {
     using Eng = typename Geom<NT, NC, DBG, NW>::Eng;       // NW < 0: -NW waves share 32 episodes (Engine3S); all carry the same state
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,6 +147,15 @@ __global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) rollout_f32
     }
     if constexpr (!PERSIST) { if (valid && writer) a.out.ep_len[e_local] = (uint32_t)t + 1u; }
     eng.end();
+#ifdef TW_ABLATE
+    if constexpr (NW == -64) {
+        if (eng.lane == 0 && (eng.wave == 0 || eng.wave == 3)) for (int i = 0; i < 4; ++i) atomicAdd(&g_gen_stamps[(eng.wave ? 4 : 0) + i], eng.stq[i]);
+    }
+    if constexpr (NW == -16) {      // wave 0: prologue | chunk compute | vmcnt wait | barrier wait | heads
+        if (eng.lane == 0 && eng.wave == 0) for (int i = 0; i < 5; ++i) atomicAdd(&g_gen_stamps[i], eng.stq[i]);
+        if (eng.lane == 0 && eng.wave == 0) atomicAdd(&g_gen_stamps[5], (unsigned long long)t + 1ull);
+    }
+#endif
 }
 
 // persistent mode: one 256-episode workgroup per CU of the current device (256 on an MI355X; every rollout kernel needs
@@ -181,7 +194,25 @@ static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
     const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>), lds_bytes)) return rc;
+#ifdef TW_ABLATE
+    const bool stamps = (NW == -64 || NW == -16) && getenv("TW_STAMPS");
+    if (stamps) { unsigned long long z[8] = {0}; TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_stamps), z, sizeof(z))); }
+    { const char *d = getenv("TW_ENG_DBG"); const int v = d ? atoi(d) : 0; TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eng_dbg), &v, sizeof(v))); }
+#endif
     hipLaunchKernelGGL((rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, a);
+#ifdef TW_ABLATE
+    if (stamps) {
+        unsigned long long g[8];
+        TW_HIP(hipStreamSynchronize(s));
+        TW_HIP(hipMemcpyFromSymbol(g, HIP_SYMBOL(g_gen_stamps), sizeof(g)));
+        if (NW == -64)
+            fprintf(stderr, "[generic engine stamps, cycles summed over %llu workgroups] wave0: embed %llu common %llu value %llu action %llu | wave3: %llu %llu %llu %llu\n",
+                    (unsigned long long)nb, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+        else
+            fprintf(stderr, "[16-column engine on %d waves, wave 0, cycles per forward] prologue %.0f chunk loop %.0f heads %.0f\n",
+                    G::WAVES, (double)g[0] / g[5], (double)g[1] / g[5], (double)g[4] / g[5]);
+    }
+#endif
     TW_HIP(hipGetLastError());
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = THREADS;

@@ -11,7 +11,7 @@
 namespace tw {
 
 template <int NT, int NC, int NW>
-__global__ void __launch_bounds__(geom_threads(NW), NW == 8 ? 2 : 1) solve_f32_kernel(const SolveArgs a)
+__global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 2 : 1)) solve_f32_kernel(const SolveArgs a)
 {
     using Eng = typename Geom<NT, NC, 0, NW>::Eng;
     extern __shared__ __attribute__((aligned(16))) float lds[];
