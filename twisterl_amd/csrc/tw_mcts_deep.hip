@@ -42,7 +42,7 @@ constexpr int DEEP_WALKERS = 4;          // walkers (= waves) per workgroup
 constexpr int DEEP_POOL = 40;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
 constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
-constexpr unsigned long long DEEP_TREE_BUDGET = 24000;   // cycles of tree walk per trip after which a walker stops at the next search
+constexpr unsigned long long DEEP_TREE_BUDGET = 48000;   // cycles of tree walk per trip after which a walker stops at the next search
                                                           // boundary (all its columns then carry frontier nodes): the other three
                                                           // walkers and the engine do not wait for one long streak of stored outputs
 
