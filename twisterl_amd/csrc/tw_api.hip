@@ -421,7 +421,15 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
     for (uint32_t i = 0; i < d->n_value; ++i) all.push_back(&d->value[i]);
     // every layer's outputs are padded to a multiple of four (zero weight columns, zero bias): the engine works on output quads
     auto pad4 = [](uint32_t x) { return (x + 3u) & ~3u; };
-    for (uint32_t i = 0; i < n_layers; ++i) { o_w[i] = seg((size_t)all[i]->in_features * pad4(all[i]->out_features) * 4); o_b[i] = seg((size_t)pad4(all[i]->out_features) * 4 + 16); }
+    // matrix-core image of a layer (LayerDev::wm): tiles of 16 outputs, tb tiles per block, nb blocks, kg groups of four inputs
+    auto tiles_per_block = [](uint32_t out) { const uint32_t tiles = (out + 15u) / 16u; return tiles >= 4u ? 4u : tiles; };
+    auto blocks_of = [&](uint32_t out) { const uint32_t tiles = (out + 15u) / 16u, tb = tiles_per_block(out); return (tiles + tb - 1u) / tb; };
+    std::vector<size_t> o_wm(n_layers);
+    for (uint32_t i = 0; i < n_layers; ++i) {
+        const uint32_t in = all[i]->in_features, out = all[i]->out_features, tb = tiles_per_block(out), nb = blocks_of(out), kg = (in + 3u) / 4u;
+        o_w[i] = seg((size_t)in * pad4(out) * 4); o_b[i] = seg((size_t)nb * tb * 16 * 4 + 16);
+        o_wm[i] = seg((size_t)(kg + 8) * 4 * nb * 16 * tb * 4 + 64);          // (+ 8 k-groups of read slack: EngineV loads that far ahead)
+    }
     std::vector<uint8_t> img(cur, 0);
     float *emb = reinterpret_cast<float *>(img.data() + o_emb);
     memcpy(emb, d->emb_vectors, (size_t)OS * E * 4);
@@ -431,6 +439,15 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
         float *wd = reinterpret_cast<float *>(img.data() + o_w[i]);
         for (uint32_t k = 0; k < in; ++k) memcpy(wd + (size_t)k * outp, all[i]->weights + (size_t)k * out, (size_t)out * 4);
         memcpy(img.data() + o_b[i], all[i]->bias, (size_t)out * 4);
+        const uint32_t tb = tiles_per_block(out), nb = blocks_of(out), kg = (in + 3u) / 4u;
+        float *wm = reinterpret_cast<float *>(img.data() + o_wm[i]);
+        for (uint32_t k = 0; k < kg * 4; ++k)
+            for (uint32_t b = 0; b < nb; ++b)
+                for (uint32_t r = 0; r < 16; ++r)
+                    for (uint32_t t = 0; t < tb; ++t) {
+                        const uint32_t o = (b * tb + t) * 16 + r;
+                        wm[(((size_t)k * nb + b) * 16 + r) * tb + t] = (k < in && o < out) ? all[i]->weights[(size_t)k * out + o] : -0.0f;
+                    }
     }
     for (uint32_t p = 0; p < d->n_perms; ++p) {
         for (uint32_t i = 0; i < OS; ++i) {
@@ -450,6 +467,8 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
     for (uint32_t i = 0; i < n_layers; ++i) {
         tab[i].w = reinterpret_cast<const float *>(base + o_w[i]); tab[i].b = reinterpret_cast<const float *>(base + o_b[i]);
         tab[i].in = (int32_t)all[i]->in_features; tab[i].out = (int32_t)pad4(all[i]->out_features); tab[i].relu = all[i]->apply_relu ? 1 : 0; tab[i].pad = 0;
+        tab[i].wm = reinterpret_cast<const float *>(base + o_wm[i]);
+        tab[i].kg = (int32_t)((all[i]->in_features + 3u) / 4u); tab[i].nb = (int32_t)blocks_of(all[i]->out_features); tab[i].tb = (int32_t)tiles_per_block(all[i]->out_features); tab[i].pad2 = 0;
     }
     e = hipMemcpy(pol->arena, img.data(), img.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hip_fail(e, "policy upload", __FILE__, __LINE__); (void)hipFree(pol->arena); delete pol; return nullptr; }

@@ -289,9 +289,13 @@ __host__ __device__ inline uint32_t puzzle_maskbits(const PuzzleLane &s, const P
 
 // one Linear of a generic policy stack (EngineV, tw_engine_generic.hpp): weights in the reference's export layout
 struct LayerDev {
-    const float *w;      // [in][out] row-major == torch_weight.T.flatten() (layers.rs:26)
-    const float *b;      // [out]
+    const float *w;      // [in][out] row-major == torch_weight.T.flatten() (layers.rs:26); out padded to a multiple of 4 (policy_eval kernels)
+    const float *b;      // [nb * tb * 16]: bias, 0 beyond the layer's outputs
     int32_t in, out, relu, pad;
+    // matrix-core image (EngineV): [kg * 4][nb][16][tb] floats, element (k, b, i, t) = W[k][(b * tb + t) * 16 + i], -0.0 where
+    // k >= in or the output does not exist (fma(-0.0, x, acc) == acc for every finite x: padding is an exact identity)
+    const float *wm;
+    int32_t kg, nb, tb, pad2;     // k-groups of four inputs; blocks of tb 16-output tiles (tb = 4 from 64 outputs up, else all tiles in one block)
 };
 
 // ---- device-side policy image (built once by tw_policy_create) ------------------------------

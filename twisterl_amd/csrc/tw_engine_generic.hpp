@@ -6,10 +6,9 @@
 // Same interface as Engine3T (16 episode columns per 256-thread workgroup, lane = (h = lane >> 4, j = lane & 15), all four
 // waves carry every column's state), so the rollout / self-play / solve kernels instantiate it unchanged.  Arithmetic = the
 // numeric spec of DESIGN.md: EmbeddingBag = bias + rows in cell order (plain adds), every Linear a k-ordered fma chain from
-// 0 with the bias added last -- on the vector ALU, which on gfx950 has the same f32 rate as the f32 MFMA (both use the
-// SIMD's FMA lanes): thread (column c, group g of 16) computes output quads g, g+16, .. of a layer for its column with one
-// float4 weight load (wave-broadcast, L1/L2 resident) and four v_fma_f32 per k.  Activations ping-pong through LDS as
-// [unit][column].  Bit-equal to the oracle's TWO_ARITH_CHAIN forward.
+// 0 with the bias added last -- v_mfma_f32_16x16x4_f32 per group of four inputs and tile of 16 outputs, weights read from a
+// per-layer image in global memory (L2-resident), activations ping-pong through LDS as [unit][column].  Bit-equal to the
+// oracle's TWO_ARITH_CHAIN forward.
 #pragma once
 #include "tw_common.hpp"
 
@@ -17,7 +16,6 @@ namespace tw {
 
 constexpr int GEN_MAX_WIDTH = 512;        // widest layer (and embedding) the engine's LDS buffers hold
 constexpr int GEN_COLS = 16;
-constexpr int GEN_PF = 16;                // weight quads a lane keeps in flight inside a layer
 
 typedef float fx4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) fx4 gfx4;
@@ -36,7 +34,7 @@ struct EngineV {
 #endif
 
     // three activation buffers (the common output stays put while the two heads run) | head outputs [16][8] | kernel use
-    __host__ __device__ static size_t lds_floats(int) { return (size_t)3 * GEN_MAX_WIDTH * GEN_COLS + GEN_COLS * 8 + 256; }
+    __host__ __device__ static size_t lds_floats(int) { return (size_t)3 * GEN_MAX_WIDTH * GEN_COLS + GEN_COLS * 8 + 256 + 512; }   // (+ 2 KiB of read slack, see layer_tb)
     __device__ __forceinline__ bool primary() const { return wave == 0; }
     __device__ __forceinline__ int  ep_lane() const { return j; }
     __device__ __forceinline__ bool owns_lane() const { return wave == j / (EPB / NS); }
@@ -82,67 +80,90 @@ struct EngineV {
         }
     }
 
-    // one Linear (layers.rs:31-37) for the 16 columns: x [in][16] -> y [out][16].  Inside a layer lane = (column group cg =
-    // lane >> 4, quad ql = lane & 15): a lane owns output quad 16*wave + ql (+64 per pass) for the FOUR columns 4cg..4cg+3 --
-    // 16 independent k-ordered fma chains, two per v_pk_fma_f32, fed per k by ONE float4 weight load (the wave reads 256
-    // contiguous bytes of the weight row) and ONE ds_read_b128 of the four columns' activations: the vector ALU, not the
-    // memory pipe, is the limit.
-    __device__ __forceinline__ void layer(const LayerDev &L, const float *x, float *y) const
+    // one Linear (layers.rs:31-37) for the 16 columns: x [in][16] -> y [out][16], on the matrix cores.  v_mfma_f32_16x16x4_f32
+    // is a k-ordered fma chain per output element (scripts/mfma_probe/probe_f32_16x16x4.hip), so one MFMA per group of four
+    // inputs and 16-output tile continues the layer's chains exactly as the reference's dot product runs; the padding of the
+    // image (inputs up to a multiple of four, outputs up to whole tiles) multiplies -0.0 into the chain, an exact identity.
+    // Lane = (kq = lane >> 4, jj = lane & 15): A = W[4g + kq][tile row jj] (ONE load of tb floats per lane and k-group: the
+    // image interleaves the block's tiles), B = x[4g + kq][column jj] (one LDS read), D rows 4kq .. 4kq+3 of each tile.
+    // A wave works on blocks wave, wave + 4, ..; per k-group: one weight load, one LDS read, tb MFMAs -- the matrix pipe is the
+    // limit (the vector-ALU form of this loop spent 10 instructions per 128 fmas and ran at a quarter of this rate).
+    template <int TB>
+    __device__ __forceinline__ void layer_tb(const LayerDev &L, const float *x, float *y) const
     {
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const int in = L.in, out = L.out;       // (out: padded to a multiple of four by tw_policy_create, zero weights / bias)
-        {
-            const int nq = out >> 2, cg = lane >> 4, ql = lane & 15;
-            for (int q = 16 * wave + ql; q < nq; q += 64) {           // (no barrier inside this loop)
-                f2 acc[4][2];
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const int kq = lane >> 4, jj = lane & 15;
+        const int NB = L.nb, KG = L.kg;
+        constexpr int PF = 8;                                                       // k-groups of weights in flight
+        for (int b = wave; b < NB; b += NW) {                                        // (wave-uniform; no barrier inside)
+            f4v acc[TB];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { acc[c][0] = f2{0.0f, 0.0f}; acc[c][1] = f2{0.0f, 0.0f}; }
-                // the weight pointer comes out of the layer table in memory: say it is global, or the loads are flat_load, which
-                // count on lgkmcnt as well and every LDS wait then drains the whole weight prefetch
-                const gfx4 *wp = (const gfx4 *)(L.w + 4 * q);
-                const size_t wstride = (size_t)(out >> 2);      // (one k = out floats = out / 4 quads)
-                const float *xp = x + 4 * cg;
-                auto fma4 = [&](const fx4 w, const float4 xv) {
-                    const f2 w01 = f2{w.x, w.y}, w23 = f2{w.z, w.w};
-                    acc[0][0] = __builtin_elementwise_fma(w01, f2{xv.x, xv.x}, acc[0][0]); acc[0][1] = __builtin_elementwise_fma(w23, f2{xv.x, xv.x}, acc[0][1]);
-                    acc[1][0] = __builtin_elementwise_fma(w01, f2{xv.y, xv.y}, acc[1][0]); acc[1][1] = __builtin_elementwise_fma(w23, f2{xv.y, xv.y}, acc[1][1]);
-                    acc[2][0] = __builtin_elementwise_fma(w01, f2{xv.z, xv.z}, acc[2][0]); acc[2][1] = __builtin_elementwise_fma(w23, f2{xv.z, xv.z}, acc[2][1]);
-                    acc[3][0] = __builtin_elementwise_fma(w01, f2{xv.w, xv.w}, acc[3][0]); acc[3][1] = __builtin_elementwise_fma(w23, f2{xv.w, xv.w}, acc[3][1]);
-                };
-                // GEN_PF weight quads in flight per lane (one wave per SIMD: nothing else hides the L2 latency); a slot is
-                // refilled for k + GEN_PF right after its fma group, clamped to the last row so every address is valid
-                fx4 w[GEN_PF];
+            for (int t = 0; t < TB; ++t) acc[t] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+            const size_t gstride = (size_t)4 * NB * 16 * TB;                         // floats per k-group
+            // running pointers, PF groups ahead of the MFMAs: the image carries PF k-groups of slack behind the last one and the
+            // LDS buffers 2 KiB, so nothing is clamped; the slack is loaded and never used
+            const float *wq = L.wm + (((size_t)kq * NB + b) * 16 + jj) * TB;
+            const float *xq = x + kq * GEN_COLS + jj;
+            auto ldw = [&](float (&w)[TB]) {
+                if constexpr (TB == 4) { const fx4 v = *(const gfx4 *)wq; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+                else {
+                    typedef const __attribute__((address_space(1))) float gf1;
 #pragma unroll
-                for (int i = 0; i < GEN_PF; ++i) w[i] = wp[(size_t)(i < in ? i : in - 1) * wstride];
-                int k0 = 0;
-                for (; k0 + GEN_PF <= in; k0 += GEN_PF) {
+                    for (int t = 0; t < TB; ++t) w[t] = ((gf1 *)wq)[t];
+                }
+                wq += gstride;
+            };
+            float w[PF][TB], xv[PF];                                                 // weights AND activations PF k-groups ahead: no LDS
+#pragma unroll                                                                       // or L2 round trip between two MFMAs
+            for (int i = 0; i < PF; ++i) { ldw(w[i]); xv[i] = xq[i * (4 * GEN_COLS)]; }
+            xq += PF * (4 * GEN_COLS);
+            int g0 = 0;
+            for (; g0 + PF <= KG; g0 += PF) {
 #pragma unroll
-                    for (int i = 0; i < GEN_PF; ++i) {
-                        fma4(w[i], *reinterpret_cast<const float4 *>(xp + (k0 + i) * GEN_COLS));
-                        const int kn = k0 + i + GEN_PF;
-                        w[i] = wp[(size_t)(kn < in ? kn : in - 1) * wstride];
+                for (int i = 0; i < PF; ++i) {
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(w[i][t]), "v"(xv[i]));
+                        if (t == TB - 1) xv[i] = xq[i * (4 * GEN_COLS)];             // (after the last MFMA that reads it was issued)
                     }
+                    ldw(w[i]);
                 }
+                xq += PF * (4 * GEN_COLS);
+            }
 #pragma unroll
-                for (int i = 0; i < GEN_PF; ++i)
-                    if (k0 + i < in) fma4(w[i], *reinterpret_cast<const float4 *>(xp + (k0 + i) * GEN_COLS));
-                const fx4 bb = *(const gfx4 *)(L.b + 4 * q);
-                float r[4][4];          // [output e][column c]
+            for (int i = 0; i < PF; ++i) {
+                if (g0 + i < KG) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    r[0][c] = acc[c][0][0] + bb.x; r[1][c] = acc[c][0][1] + bb.y; r[2][c] = acc[c][1][0] + bb.z; r[3][c] = acc[c][1][1] + bb.w;
+                    for (int t = 0; t < TB; ++t) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(w[i][t]), "v"(xv[i]));
                 }
+            }
+            // (the MFMAs are inline asm with the accumulators pinned to VGPRs -- with the intrinsic the allocator shuttles them
+            //  between VGPRs and AGPRs around every group; the wait states between the last MFMA and the reads below are ours)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            // D row 4kq + r of tile t is output (b * TB + t) * 16 + 4kq + r
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int o0 = (b * TB + t) * 16 + 4 * kq;
+                const fx4 bb = *(const gfx4 *)(L.b + o0);
+                float r[4] = {acc[t][0] + bb.x, acc[t][1] + bb.y, acc[t][2] + bb.z, acc[t][3] + bb.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (L.relu) {         // layers.rs:89-91: `if x > 0.0 { x } else { 0.0 }`
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) r[e][c] = r[e][c] > 0.0f ? r[e][c] : 0.0f;
-                    }
-                    *reinterpret_cast<float4 *>(y + (4 * q + e) * GEN_COLS + 4 * cg) = make_float4(r[e][0], r[e][1], r[e][2], r[e][3]);
+                    if (L.relu) r[e] = r[e] > 0.0f ? r[e] : 0.0f;                   // layers.rs:89-91: `if x > 0.0 { x } else { 0.0 }`
+                    y[(o0 + e) * GEN_COLS + jj] = r[e];
                 }
             }
         }
         __syncthreads();
+    }
+
+    __device__ __forceinline__ void layer(const LayerDev &L, const float *x, float *y) const
+    {
+        switch (L.tb) {                                                              // (wave-uniform)
+            case 1: layer_tb<1>(L, x, y); break;
+            case 2: layer_tb<2>(L, x, y); break;
+            case 3: layer_tb<3>(L, x, y); break;
+            default: layer_tb<4>(L, x, y); break;
+        }
     }
 
     // runs a stack from buffer `src`; returns the buffer holding its output (never `keep`)
@@ -167,22 +188,35 @@ struct EngineV {
         const int E = pol.emb;
         const float *tab = pol.emb_rows;
         const float *bias = tab + (size_t)pol.obs_size * E;
-        for (int q = g; q < E / 4; q += 16) {
-            // every row's load is issued before the first add (a missing cell loads row 0 and is not added): one latency per
-            // quad, not one per cell
-            fx4 r[NC];
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                r[i] = *(const gfx4 *)(tab + (size_t)(rowoff[i] >= 0 ? rowoff[i] : 0) * E + 4 * q);
-            fx4 a = *(const gfx4 *)(bias + 4 * q);
+        // thread (column j, group g of 16) sums output quads g, g+16, ..; TWO quads per trip: all 2 x (NC+1) row loads are requested
+        // before the first add (a missing cell loads row 0 and is not added), so a trip costs one L2 round trip
+        const int nq = E / 4;
+        for (int q0 = g; q0 < nq; q0 += 32) {
+            const int q1 = q0 + 16 < nq ? q0 + 16 : q0;                              // (second quad of the trip; a repeat of the first at the end)
+            fx4 r0[NC], r1[NC];
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                if (rowoff[i] >= 0) { a.x = a.x + r[i].x; a.y = a.y + r[i].y; a.z = a.z + r[i].z; a.w = a.w + r[i].w; }
+                const float *row = tab + (size_t)(rowoff[i] >= 0 ? rowoff[i] : 0) * E;
+                r0[i] = *(const gfx4 *)(row + 4 * q0);
+                r1[i] = *(const gfx4 *)(row + 4 * q1);
             }
-            if (pol.emb_relu) { a.x = a.x > 0.0f ? a.x : 0.0f; a.y = a.y > 0.0f ? a.y : 0.0f; a.z = a.z > 0.0f ? a.z : 0.0f; a.w = a.w > 0.0f ? a.w : 0.0f; }
+            fx4 a0 = *(const gfx4 *)(bias + 4 * q0), a1 = *(const gfx4 *)(bias + 4 * q1);
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                if (rowoff[i] >= 0) {
+                    a0.x = a0.x + r0[i].x; a0.y = a0.y + r0[i].y; a0.z = a0.z + r0[i].z; a0.w = a0.w + r0[i].w;
+                    a1.x = a1.x + r1[i].x; a1.y = a1.y + r1[i].y; a1.z = a1.z + r1[i].z; a1.w = a1.w + r1[i].w;
+                }
+            }
+            if (pol.emb_relu) {
+                a0.x = a0.x > 0.0f ? a0.x : 0.0f; a0.y = a0.y > 0.0f ? a0.y : 0.0f; a0.z = a0.z > 0.0f ? a0.z : 0.0f; a0.w = a0.w > 0.0f ? a0.w : 0.0f;
+                a1.x = a1.x > 0.0f ? a1.x : 0.0f; a1.y = a1.y > 0.0f ? a1.y : 0.0f; a1.z = a1.z > 0.0f ? a1.z : 0.0f; a1.w = a1.w > 0.0f ? a1.w : 0.0f;
+            }
             float *y = bufp(0);
-            y[(4 * q + 0) * GEN_COLS + j] = a.x; y[(4 * q + 1) * GEN_COLS + j] = a.y;
-            y[(4 * q + 2) * GEN_COLS + j] = a.z; y[(4 * q + 3) * GEN_COLS + j] = a.w;
+            y[(4 * q0 + 0) * GEN_COLS + j] = a0.x; y[(4 * q0 + 1) * GEN_COLS + j] = a0.y;
+            y[(4 * q0 + 2) * GEN_COLS + j] = a0.z; y[(4 * q0 + 3) * GEN_COLS + j] = a0.w;
+            y[(4 * q1 + 0) * GEN_COLS + j] = a1.x; y[(4 * q1 + 1) * GEN_COLS + j] = a1.y;
+            y[(4 * q1 + 2) * GEN_COLS + j] = a1.z; y[(4 * q1 + 3) * GEN_COLS + j] = a1.w;
         }
         __syncthreads();
 #ifdef TW_ABLATE
