@@ -674,7 +674,7 @@ template <int NT, int NC>
 struct Engine3T : Engine3<NT, NC, 0, 4> {
     using B = Engine3<NT, NC, 0, 4>;
     static constexpr int NS = 4, EPB = 16, TPW = NT / 2, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, H = NT * 32;
-    static constexpr int WOPS = B::WPIECE / 4, TOPS = (B::TPIECE + 3) / 4, NOPS = WOPS + TOPS;   // DMA ops per wave and chunk: W1 pieces, table pieces
+    static constexpr int TOPS = (B::TPIECE + 3) / 4, NOPS = TOPS;          // DMA ops per wave and chunk: table pieces (W1 does not go through LDS here)
     static constexpr bool SPLIT = true;
     static_assert(NT == 8 || NT == 4, "Engine3T: 128 or 256 hidden units");
 
@@ -688,9 +688,15 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
     // The ring position is a compile-time fact: a forward always starts in slot 0 -- its chunk sequence is padded to a multiple
     // of three steps (0..2 "bubble" steps that only stream; 1 of 33 for a 512-wide embedding), so the slot offsets of all LDS
     // reads are immediates and the loop body is three straight-line steps.
-    const uint8_t *swp, *stp;
+    // W1 never enters LDS in this shape: a lane's A operands of a step (4 k-groups x its TPW tiles) are ONE contiguous read per
+    // k-group of the same image the other shapes stream (the LDS slot is a verbatim copy of it), requested two steps ahead into
+    // a register ring indexed like the table ring -- 16 KB less LDS-DMA and 16 KB fewer LDS reads per step.
+    const uint8_t *stp;
+    const float *agl;                      // this lane's A operands of k-group 0 in the image
+    int aoff;                              // floats from there to the step whose operands are requested next
     int sv, n3;                            // virtual step whose data is streamed next (sv == step + 2); steps per forward (multiple of 3)
-    uint32_t voffW[WOPS], voffT[TOPS], mT[TOPS];
+    uint32_t voffT[TOPS], mT[TOPS];
+    float areg[3][4][TPW];
 #ifdef TW_ABLATE
     unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk loop | - | - | heads | -
 #endif
@@ -709,12 +715,15 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         n3 = (this->n_chunks + 2) / 3 * 3;
         sv = 2;                            // (B::begin1 streamed steps 0 and 1)
         {
-            const int first = 2 < this->n_chunks ? 2 : 0;                        // a bubble step gets chunk 0's data (never read)
-            swp = this->dsrc_w + (size_t)first * (WSLOT * 4);
+            const int kq = this->h, jj = this->j, wave = this->wave;
+            const int half = wave >> 1, q = NT == 8 ? (wave & 1) : 0, cc0 = NT == 8 ? 0 : 2 * (wave & 1);
+            agl = p.w1p + (kq * NQ + q) * 128 + (16 * half + jj) * 4 + cc0;
+            const int second = 1 < this->n_chunks ? 1 : 0, first = 2 < this->n_chunks ? 2 : 0;   // a bubble step gets chunk 0's data (never read)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { load_a(agl + g * (4 * NQ * 128), areg[0][g]); load_a(agl + second * WSLOT + g * (4 * NQ * 128), areg[1][g]); }
+            aoff = first * WSLOT;
             stp = this->dsrc_t + (size_t)first * (R3_TSLOT * 4);
         }
-#pragma unroll
-        for (int k = 0; k < WOPS; ++k) voffW[k] = this->voff + (uint32_t)k * 4096u;            // piece wave + 4k (dsrc_w / ddst_w carry the wave)
 #pragma unroll
         for (int k = 0; k < TOPS; ++k) {
             int tp = this->wave + 4 * k;
@@ -737,15 +746,19 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         }
     }
 
-    template <int S, int OP>   // DMA op OP of this wave: a piece of chunk sc_next into ring slot S
+    __device__ __forceinline__ static void load_a(const float *p, float (&a)[TPW])
+    {
+        typedef const __attribute__((address_space(1))) f32x4 gl4;
+        typedef const __attribute__((address_space(1))) f32x2 gl2;
+        if constexpr (TPW == 4) { const f32x4 v = *(gl4 *)p; a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3]; }
+        else { const f32x2 v = *(gl2 *)p; a[0] = v[0]; a[1] = v[1]; }
+    }
+
+    template <int S, int OP>   // DMA op OP of this wave: a table piece of the step streamed next into ring slot S
     __device__ __forceinline__ void stream() const
     {
-        if constexpr (OP < WOPS)
-            asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
-                         :: "v"(voffW[OP]), "s"(this->ddst_w), "i"(S * WSLOT * 4 + OP * 4096), "s"(swp) : "memory", "m0", "scc");
-        else
-            asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
-                         :: "v"(voffT[OP - WOPS]), "s"(mT[OP - WOPS]), "i"(S * R3_TSLOT * 4), "s"(stp) : "memory", "m0", "scc");
+        asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                     :: "v"(voffT[OP]), "s"(mT[OP]), "i"(S * R3_TSLOT * 4), "s"(stp) : "memory", "m0", "scc");
     }
 
     __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
@@ -761,7 +774,6 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         const int half = wave >> 1;
         const int q    = NT == 8 ? (wave & 1) : 0;
         const int cc0  = NT == 8 ? 0 : 2 * (wave & 1);
-        lds_cfloat *abase = (lds_cfloat *)this->lds_w + (kq * NQ + q) * 128 + (16 * half + jj) * 4 + cc0;   // + slot, + g * 4*NQ*128 for k-group g
         // gather: k-group `wave`, this lane's k = 4*wave + kq of the chunk -> position in the [even k | odd k] row image.
         // One LDS address per row for the whole forward: the ring slot is an immediate offset of the read.
         lds_cfloat *gb = (lds_cfloat *)this->lds_t + ((kq & 1) * 8 + 2 * wave + (kq >> 1));
@@ -778,22 +790,11 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             for (int c = 1; c <= NC; ++c) sm = sm + gr[c];
             xb[(buf * 64 + this->lane) * 4 + wave] = relu_lim_v(sm, this->emb_lim);
         };
-        auto read_a = [&](lds_cfloat *ap, float (&a)[TPW]) {
-            if constexpr (TPW == 4) {
-                const f32x4 v = *reinterpret_cast<lds_cf4 *>(ap);
-                a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
-            } else {
-                const f32x2 v = *reinterpret_cast<lds_cf2 *>(ap);
-                a[0] = v[0]; a[1] = v[1];
-            }
-        };
-
-        float aw[TPW];
         int par = 0;                                                              // B-operand buffer of the current chunk
         // the data of virtual step sv has been requested: move on (chunk sv, or chunk 0 again for a bubble, or the next forward's)
         auto stream_advance = [&]() {
-            ++sv; swp += WSLOT * 4; stp += R3_TSLOT * 4;
-            if (sv == this->n_chunks || sv == n3) { swp = this->dsrc_w; stp = this->dsrc_t; }
+            ++sv; aoff += WSLOT; stp += R3_TSLOT * 4;
+            if (sv == this->n_chunks || sv == n3) { aoff = 0; stp = this->dsrc_t; }
             if (sv == n3) sv = 0;
         };
         // One step with the ring slots as compile-time facts (S0: this chunk, S1: the next one -- complete, S2: streamed now)
@@ -802,6 +803,10 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             constexpr int M = 4 * TPW;
             if (c < this->n_chunks) {
                 const f32x4 bq = *reinterpret_cast<const f32x4 *>(xb + (par * 64 + this->lane) * 4);
+                // (one visible use of the LAST of this step's operand loads, before any of this step's DMA ops exist: the compiler
+                //  waits here once, with only the four younger loads of the next step's operands in flight, instead of once per
+                //  k-group with counts that -- not knowing the inline-asm streams -- would wait for those as well)
+                asm volatile("" :: "v"(areg[S0][3][TPW - 1]));
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     constexpr_for_ops<S2>(m, M);
@@ -810,13 +815,10 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
                     //  accumulators in VGPRs and the MFMA results in AGPRs and copies all 16 both ways every chunk.  Operands come
                     //  from LDS reads (waitcnt is the compiler's); the same accumulator is TPW MFMAs apart, which the matrix pipe
                     //  interlocks; results are read long after the last MFMA, see below.)
-                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(aw[t]), "v"(bq[g]));
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(areg[S0][g][t]), "v"(bq[g]));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int cq = m * (NC + 1) / M; cq < (m + 1) * (NC + 1) / M; ++cq) gr[cq] = ga[cq][S1 * R3_TSLOT];   // step c+1, complete in slot S1
-                    if (t == TPW - 1) {
-                        if (g < 3) read_a(abase + S0 * WSLOT + (g + 1) * (4 * NQ * 128), aw); else read_a(abase + S1 * WSLOT, aw);
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 gather_finish(par ^ 1);
@@ -824,14 +826,20 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             } else {                                                              // bubble: only the streams
                 constexpr_for_ops<S2>(0, 1);
             }
+            // A operands of step c+2 (register ring slot S2, last read one step ago), requested AFTER the step's last DMA op: the
+            // wait below then covers the streams (and the operands requested a step ago) but not these four loads
+            {
+                const float *ap = agl + aoff;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) load_a(ap + g * (4 * NQ * 128), areg[S2][g]);
+            }
             stream_advance();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
         };
 
         TW_S3(q_in);
         {
-            read_a(abase, aw);                                                    // slot 0
 #pragma unroll
             for (int c = 0; c <= NC; ++c) gr[c] = ga[c][0];
             gather_finish(0);
