@@ -674,63 +674,125 @@ template <int NT, int NC>
 struct Engine3T : Engine3<NT, NC, 0, 4> {
     using B = Engine3<NT, NC, 0, 4>;
     static constexpr int NS = 4, EPB = 16, TPW = NT / 2, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, H = NT * 32;
-    static constexpr int TOPS = (B::TPIECE + 3) / 4, NOPS = TOPS;          // DMA ops per wave and chunk: table pieces (W1 does not go through LDS here)
+    static constexpr int TOPS = (B::TPIECE + 3) / 4;                       // table DMA ops per wave and 16-column chunk
+    static constexpr int NOPS = 2 * TOPS;                                  // ... per step (a step is a PAIR of chunks)
+    static constexpr int GS = 4 * NQ * 128;                                // floats of the W1 image per k-group of four
     static constexpr bool SPLIT = true;
     static_assert(NT == 8 || NT == 4, "Engine3T: 128 or 256 hidden units");
+    // the head buffer (hidden units of the 16 columns) sits behind the table ring when the ring area of Engine3's LDS map has
+    // room for both (256 hidden units), else behind the engine's own areas
+    static constexpr bool HID_IN_RING = 4 * R3_TSLOT + NT * 32 * 16 <= 3 * WSLOT + 3 * R3_TSLOT;
+    static_assert(4 * R3_TSLOT <= 3 * WSLOT + 3 * R3_TSLOT, "table ring must fit the ring area of Engine3's LDS map");
 
     float *lds_x, *lds_user;
-    // The weight / table streams of this engine.  A lone wave per SIMD issues one instruction every 4..5 cycles whatever its kind
-    // (measured: the chunk loop with 16 MFMAs and ~150 other instructions ran 970 cycles per chunk against 512 of matrix time;
-    // the same forward on 16 waves, four per SIMD, ran SLOWER -- the SIMD issues ~one instruction per 4 cycles for all its waves
-    // together), so the instruction count is the bound.  A stream op is therefore: M0 = this wave's piece address + a literal
-    // (slot and piece), the DMA instruction with a per-op lane offset kept in a VGPR, and nothing else; the source is a running
-    // pointer to the chunk streamed next (the ring runs on from one forward into the next).
-    // The ring position is a compile-time fact: a forward always starts in slot 0 -- its chunk sequence is padded to a multiple
-    // of three steps (0..2 "bubble" steps that only stream; 1 of 33 for a 512-wide embedding), so the slot offsets of all LDS
-    // reads are immediates and the loop body is three straight-line steps.
-    // W1 never enters LDS in this shape: a lane's A operands of a step (4 k-groups x its TPW tiles) are ONE contiguous read per
-    // k-group of the same image the other shapes stream (the LDS slot is a verbatim copy of it), requested two steps ahead into
-    // a register ring indexed like the table ring -- 16 KB less LDS-DMA and 16 KB fewer LDS reads per step.
-    const uint8_t *stp;
-    const float *agl;                      // this lane's A operands of k-group 0 in the image
-    int aoff;                              // floats from there to the step whose operands are requested next
-    int sv, n3;                            // virtual step whose data is streamed next (sv == step + 2); steps per forward (multiple of 3)
+    // What this shape does differently from the throughput shapes, and why.  A lone wave per SIMD issues one
+    // instruction every 4..5 cycles whatever its kind and cannot overlap its own stalls, so a step costs its instruction count
+    // plus every round trip on its critical path (barrier -> B operands -> MFMAs -> gather adds -> exchange -> barrier):
+    //   * a step is a PAIR of 16-wide chunks (32 MFMA slots between two barriers): half the barriers and B-operand round trips;
+    //   * W1 never enters LDS: a lane's A operands of a k-group (its TPW tiles) are one contiguous read of the image the other
+    //     shapes stream (an LDS slot is a verbatim copy of it), requested a whole step ahead into a two-deep register ring;
+    //   * the table ring therefore has room for two pair-slots of two chunks (the pair being gathered, the pair being streamed;
+    //     a step never touches the table of its own chunks -- they were gathered a step earlier) in the ring area of Engine3's
+    //     LDS map, the head buffer behind them;
+    //   * ring positions are compile-time facts: a forward starts in pair-slot 0 and has an even number of steps (a "bubble"
+    //     step that only streams if the chunk-pair count is odd), so slot offsets are immediates of the LDS reads and the loop
+    //     body is two straight-line steps; the gather keeps one LDS address per row for the whole forward;
+    //   * a stream op is `s_add_u32 m0, piece, literal` + the DMA instruction with a per-op lane offset in a VGPR and a running
+    //     source pointer (the ring runs on from one forward into the next);
+    //   * the accumulators are pinned to VGPRs (inline-asm MFMA).
+    const uint8_t *stp;                    // table image of the pair streamed next
+    const float *agl;                      // this lane's A operands of k-group 0 in the W1 image
+    int aoff;                              // floats from there to the pair whose operands are requested next
+    int sv, av, np, n2;                    // virtual pair streamed next (step + 2) / loaded next (step + 1); chunk pairs per forward; steps (even)
     uint32_t voffT[TOPS], mT[TOPS];
-    float areg[3][4][TPW];
+    float areg[2][8][TPW];
+    float *tbase;                          // table ring: pair-slot s, chunk h at tbase + (2 s + h) * R3_TSLOT
 #ifdef TW_ABLATE
-    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk loop | - | - | heads | -
+    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | step loop | - | - | heads | -
 #endif
 
-    __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
+    __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER + (HID_IN_RING ? 0 : NT * 32 * 16); }
     __device__ __forceinline__ bool primary() const { return this->wave == 0; }
     __device__ __forceinline__ int  ep_lane() const { return this->j; }
     __device__ __forceinline__ bool owns_lane() const { return this->wave == this->j / (EPB / NS); }
 
+    __device__ __forceinline__ static void load_a(const float *p, float (&a)[TPW])
+    {
+        typedef const __attribute__((address_space(1))) f32x4 gl4;
+        typedef const __attribute__((address_space(1))) f32x2 gl2;
+        if constexpr (TPW == 4) { const f32x4 v = *(gl4 *)p; a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3]; }
+        else { const f32x2 v = *(gl2 *)p; a[0] = v[0]; a[1] = v[1]; }
+    }
+
+    template <int SLOT, int OP>   // DMA op OP of this wave: a table piece of the pair streamed next into pair-slot SLOT (OP >= TOPS: its second chunk)
+    __device__ __forceinline__ void stream() const
+    {
+        constexpr int HALF = OP / TOPS, K = OP % TOPS;
+        asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                     :: "v"(voffT[K] + (uint32_t)(HALF * R3_TSLOT * 4)), "s"(mT[K]), "i"((2 * SLOT + HALF) * R3_TSLOT * 4), "s"(stp) : "memory", "m0", "scc");
+    }
+    // the DMA ops of MFMA slot m of M: ops [m*NOPS/M, (m+1)*NOPS/M) of this wave
+    template <int SLOT, int OP = 0>
+    __device__ __forceinline__ void ops_of_slot(int m, int M) const
+    {
+        if constexpr (OP < NOPS) {
+            if (OP >= m * NOPS / M && OP < (m + 1) * NOPS / M) stream<SLOT, OP>();     // (m is a constant after unrolling: one op survives)
+            ops_of_slot<SLOT, OP + 1>(m, M);
+        }
+    }
+
     __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
     {
-        B::begin1(p, lds);                 // (streams chunks 0 and 1 into slots 0 and 1)
+        B::begin1(p, lds);                 // (LDS constants; its first streams land in the ring area and are overwritten below)
         this->j = this->lane & 15; this->h = this->lane >> 4;
         lds_x = lds + engine3_lds_floats<NT>(p.obs_size);
         lds_user = lds_x + R3S_XCHG;
-        n3 = (this->n_chunks + 2) / 3 * 3;
-        sv = 2;                            // (B::begin1 streamed steps 0 and 1)
-        {
-            const int kq = this->h, jj = this->j, wave = this->wave;
-            const int half = wave >> 1, q = NT == 8 ? (wave & 1) : 0, cc0 = NT == 8 ? 0 : 2 * (wave & 1);
-            agl = p.w1p + (kq * NQ + q) * 128 + (16 * half + jj) * 4 + cc0;
-            const int second = 1 < this->n_chunks ? 1 : 0, first = 2 < this->n_chunks ? 2 : 0;   // a bubble step gets chunk 0's data (never read)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { load_a(agl + g * (4 * NQ * 128), areg[0][g]); load_a(agl + second * WSLOT + g * (4 * NQ * 128), areg[1][g]); }
-            aoff = first * WSLOT;
-            stp = this->dsrc_t + (size_t)first * (R3_TSLOT * 4);
-        }
+        tbase = this->lds_w;
+        np = (this->n_chunks + 1) / 2;     // (tw_policy_create: the embedding is a multiple of 32, so chunks come in pairs)
+        n2 = (np + 1) / 2 * 2;
+        const int kq = this->h, jj = this->j, wave = this->wave;
+        const int half = wave >> 1, q = NT == 8 ? (wave & 1) : 0, cc0 = NT == 8 ? 0 : 2 * (wave & 1);
+        agl = p.w1p + (kq * NQ + q) * 128 + (16 * half + jj) * 4 + cc0;
+        const uint32_t dt = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)tbase);
 #pragma unroll
         for (int k = 0; k < TOPS; ++k) {
-            int tp = this->wave + 4 * k;
+            int tp = wave + 4 * k;
             tp = tp < B::TPIECE ? tp : B::TPIECE - 1;                                           // past the end: repeat the last piece
-            mT[k] = this->ddst_t + (uint32_t)tp * 1024u;
+            mT[k] = dt + (uint32_t)tp * 1024u;
             voffT[k] = this->voff + (uint32_t)tp * 1024u;
         }
+        // pairs 0 and 1 of the first forward into pair-slots 0 and 1 (after B's own first streams have landed: same LDS area),
+        // the A operands of pair 0 into register slot 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stp = this->dsrc_t;
+        stream_pair<0>();
+        stp = this->dsrc_t + (size_t)(np > 1 ? 1 : 0) * (2 * R3_TSLOT * 4);
+        stream_pair<1>();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) load_a(agl + g * GS, areg[0][g]);
+        sv = 2 < n2 ? 2 : 0; av = 1;       // (virtual pair n2 + k is pair k of the next forward)
+        set_pointers();
+    }
+    template <int SLOT, int OP = 0>
+    __device__ __forceinline__ void stream_pair() const
+    {
+        if constexpr (OP < NOPS) { stream<SLOT, OP>(); stream_pair<SLOT, OP + 1>(); }
+    }
+    // virtual pair v: a real pair of this forward (v < np), a bubble (np <= v < n2: pair 0's data, never read), or pair v - n2 of the next forward
+    __device__ __forceinline__ int real_pair(int v) const { return v < np ? v : (v < n2 ? 0 : v - n2); }
+    __device__ __forceinline__ void set_pointers()
+    {
+        stp  = this->dsrc_t + (size_t)real_pair(sv) * (2 * R3_TSLOT * 4);
+        aoff = real_pair(av) * (2 * WSLOT);
+    }
+    __device__ __forceinline__ void advance()
+    {
+        ++sv; ++av; stp += 2 * R3_TSLOT * 4; aoff += 2 * WSLOT;
+        if (sv == np || sv == n2) stp = this->dsrc_t;
+        if (av == np || av == n2) aoff = 0;
+        if (sv == n2) sv = 0;
+        if (av == n2) av = 0;
     }
 
     __device__ __forceinline__ void rows_of(uint64_t board, int n_cells, int perm, int (&rowoff)[NC]) const
@@ -746,120 +808,99 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         }
     }
 
-    __device__ __forceinline__ static void load_a(const float *p, float (&a)[TPW])
-    {
-        typedef const __attribute__((address_space(1))) f32x4 gl4;
-        typedef const __attribute__((address_space(1))) f32x2 gl2;
-        if constexpr (TPW == 4) { const f32x4 v = *(gl4 *)p; a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3]; }
-        else { const f32x2 v = *(gl2 *)p; a[0] = v[0]; a[1] = v[1]; }
-    }
-
-    template <int S, int OP>   // DMA op OP of this wave: a table piece of the step streamed next into ring slot S
-    __device__ __forceinline__ void stream() const
-    {
-        asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
-                     :: "v"(voffT[OP]), "s"(mT[OP]), "i"(S * R3_TSLOT * 4), "s"(stp) : "memory", "m0", "scc");
-    }
-
     __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
     {
         typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
-        typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
         const int jj = this->j, kq = this->h, wave = this->wave;
         f32x4v acc[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
 
-        // this wave's row tiles inside the W1 image: 32-row block 4*q + cc, rows 16*half .. 16*half+15 of it
-        const int half = wave >> 1;
-        const int q    = NT == 8 ? (wave & 1) : 0;
-        const int cc0  = NT == 8 ? 0 : 2 * (wave & 1);
-        // gather: k-group `wave`, this lane's k = 4*wave + kq of the chunk -> position in the [even k | odd k] row image.
-        // One LDS address per row for the whole forward: the ring slot is an immediate offset of the read.
-        lds_cfloat *gb = (lds_cfloat *)this->lds_t + ((kq & 1) * 8 + 2 * wave + (kq >> 1));
+        // gather: k-group `wave` of a chunk, this lane's k = 4*wave + kq of it -> position in the [even k | odd k] row image.
+        // One LDS address per row for the whole forward: pair-slot and chunk are immediate offsets of the read.
+        lds_cfloat *gb = (lds_cfloat *)tbase + ((kq & 1) * 8 + 2 * wave + (kq >> 1));
         lds_cfloat *ga[NC + 1];
         ga[0] = gb + this->bias_row * R3_LSTR;
 #pragma unroll
         for (int c = 0; c < NC; ++c) ga[c + 1] = gb + rowoff[c];
 
-        float *xb = lds_x + 256;                                                  // [2 buffers][64 lanes][4 k-groups]
-        float gr[NC + 1];
+        float *xb = lds_x + 256;                                                  // [2 buffers][64 lanes][8 k-groups of a pair]
+        float gr[2][NC + 1];
         auto gather_finish = [&](int buf) {
-            float sm = gr[0];                                                     // bias row, then the cells in order
 #pragma unroll
-            for (int c = 1; c <= NC; ++c) sm = sm + gr[c];
-            xb[(buf * 64 + this->lane) * 4 + wave] = relu_lim_v(sm, this->emb_lim);
+            for (int hf = 0; hf < 2; ++hf) {
+                float sm = gr[hf][0];                                             // bias row, then the cells in order
+#pragma unroll
+                for (int c = 1; c <= NC; ++c) sm = sm + gr[hf][c];
+                xb[(buf * 64 + this->lane) * 8 + hf * 4 + wave] = relu_lim_v(sm, this->emb_lim);
+            }
         };
-        int par = 0;                                                              // B-operand buffer of the current chunk
-        // the data of virtual step sv has been requested: move on (chunk sv, or chunk 0 again for a bubble, or the next forward's)
-        auto stream_advance = [&]() {
-            ++sv; aoff += WSLOT; stp += R3_TSLOT * 4;
-            if (sv == this->n_chunks || sv == n3) { aoff = 0; stp = this->dsrc_t; }
-            if (sv == n3) sv = 0;
-        };
-        // One step with the ring slots as compile-time facts (S0: this chunk, S1: the next one -- complete, S2: streamed now)
-        auto step = [&](auto s0c, int c) {
-            constexpr int S0 = decltype(s0c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
-            constexpr int M = 4 * TPW;
-            if (c < this->n_chunks) {
-                const f32x4 bq = *reinterpret_cast<const f32x4 *>(xb + (par * 64 + this->lane) * 4);
-                // (one visible use of the LAST of this step's operand loads, before any of this step's DMA ops exist: the compiler
-                //  waits here once, with only the four younger loads of the next step's operands in flight, instead of once per
-                //  k-group with counts that -- not knowing the inline-asm streams -- would wait for those as well)
-                asm volatile("" :: "v"(areg[S0][3][TPW - 1]));
+
+        int par = 0;                                                              // B-operand buffer of the current pair
+        // One step = one pair of chunks; P: register slot of its A operands = pair-slot streamed into; P^1: pair-slot gathered from
+        auto step = [&](auto pc, int p) {
+            constexpr int P = decltype(pc)::value, Q = P ^ 1;
+            constexpr int M = 8 * TPW;
+            // A operands of the NEXT pair, requested first: they land during this step (the closing wait covers them)
+            {
+                const float *ap = agl + aoff;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) load_a(ap + g * GS, areg[Q][g]);
+            }
+            if (p < np) {
+                const f32x4 bq0 = *reinterpret_cast<const f32x4 *>(xb + (par * 64 + this->lane) * 8);
+                const f32x4 bq1 = *reinterpret_cast<const f32x4 *>(xb + (par * 64 + this->lane) * 8 + 4);
+                // (one visible use of the LAST of this step's operand loads before any of this step's DMA ops exist: the compiler
+                //  waits here once, with only the eight loads issued a moment ago in flight, instead of once per k-group with
+                //  counts that -- not knowing the inline-asm streams -- would wait for those as well)
+                asm volatile("" :: "v"(areg[P][7][TPW - 1]));
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    constexpr_for_ops<S2>(m, M);
+                    ops_of_slot<P>(m, M);
                     const int g = m / TPW, t = m % TPW;
-                    // (inline asm, accumulators pinned to VGPRs: with the intrinsic the register allocator keeps the loop-carried
-                    //  accumulators in VGPRs and the MFMA results in AGPRs and copies all 16 both ways every chunk.  Operands come
-                    //  from LDS reads (waitcnt is the compiler's); the same accumulator is TPW MFMAs apart, which the matrix pipe
-                    //  interlocks; results are read long after the last MFMA, see below.)
-                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(areg[S0][g][t]), "v"(bq[g]));
+                    // (operands: LDS / global reads whose waits are the compiler's; the same accumulator is TPW MFMAs apart, which
+                    //  the matrix pipe interlocks; results are read long after the last MFMA, see below)
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(areg[P][g][t]), "v"(g < 4 ? bq0[g & 3] : bq1[g & 3]));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int cq = m * (NC + 1) / M; cq < (m + 1) * (NC + 1) / M; ++cq) gr[cq] = ga[cq][S1 * R3_TSLOT];   // step c+1, complete in slot S1
+                    for (int r = m * 2 * (NC + 1) / M; r < (m + 1) * 2 * (NC + 1) / M; ++r)         // the next pair, complete in pair-slot Q
+                        gr[r / (NC + 1)][r % (NC + 1)] = ga[r % (NC + 1)][(2 * Q + r / (NC + 1)) * R3_TSLOT];
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 gather_finish(par ^ 1);
                 par ^= 1;
             } else {                                                              // bubble: only the streams
-                constexpr_for_ops<S2>(0, 1);
+                stream_pair<P>();
             }
-            // A operands of step c+2 (register ring slot S2, last read one step ago), requested AFTER the step's last DMA op: the
-            // wait below then covers the streams (and the operands requested a step ago) but not these four loads
-            {
-                const float *ap = agl + aoff;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) load_a(ap + g * (4 * NQ * 128), areg[S2][g]);
-            }
-            stream_advance();
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            advance();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         };
 
         TW_S3(q_in);
         {
 #pragma unroll
-            for (int c = 0; c <= NC; ++c) gr[c] = ga[c][0];
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int c = 0; c <= NC; ++c) gr[hf][c] = ga[c][hf * R3_TSLOT];   // pair 0 in pair-slot 0
             gather_finish(0);
             __syncthreads();
         }
         TW_S3(q_pro);
         TW_A3(0, q_in, q_pro);
-        for (int c = 0; c < n3; c += 3) {
-            step(std::integral_constant<int, 0>{}, c);
-            step(std::integral_constant<int, 1>{}, c + 1);
-            step(std::integral_constant<int, 2>{}, c + 2);
+        for (int p = 0; p < n2; p += 2) {
+            step(std::integral_constant<int, 0>{}, p);
+            step(std::integral_constant<int, 1>{}, p + 1);
         }
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> vector ALU: the wait states the compiler would count for the intrinsic
         TW_S3(q_lp);
         TW_A3(1, q_pro, q_lp);
 
-        // heads: hidden units -> freed table slot as [unit/4][16 episodes][4], then one v_fma_f32 chain per (episode, output)
+        // heads: hidden units -> the buffer behind the table ring as [unit/4][16 episodes][4], then one v_fma_f32 chain per (episode, output)
         TW_S3(q_h0);
         {
-            float *hid = this->lds_t + 2 * R3_TSLOT;                              // the last step's table slot: free until step 0 of the next forward streams into it
+            const int half = wave >> 1, q = NT == 8 ? (wave & 1) : 0, cc0 = NT == 8 ? 0 : 2 * (wave & 1);
+            float *hid = HID_IN_RING ? tbase + 4 * R3_TSLOT : lds_user + R3S_USER;
             // D row 4*kq + r of local tile t is hidden unit 32*(4q + cc0 + t) + 2*(r + 8*half + 4*(kq>>1)) + (kq&1)
             const int ublk = 8 * half + 4 * (kq >> 1);                            // the lane-dependent part of g'
             float *dst = hid + (8 * (4 * q + cc0) + 2 * (2 * half + (kq >> 1))) * 64 + jj * 4 + (kq & 1);
@@ -889,16 +930,6 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         }
         TW_S3(q_h1);
         TW_A3(4, q_h0, q_h1);
-    }
-
-    // the DMA ops of MFMA slot m of M: ops [m*NOPS/M, (m+1)*NOPS/M) of this wave, into ring slot S
-    template <int S, int OP = 0>
-    __device__ __forceinline__ void constexpr_for_ops(int m, int M) const
-    {
-        if constexpr (OP < NOPS) {
-            if (OP >= m * NOPS / M && OP < (m + 1) * NOPS / M) stream<S, OP>();     // (m is a constant after unrolling: one op survives)
-            constexpr_for_ops<S, OP + 1>(m, M);
-        }
     }
 };
 
