@@ -90,6 +90,8 @@ def test_policy_evaluate_matches_oracle(tw, oracle, n2, emb, hidden):
     (3, 2, 4, 32, 128, 70, False),      # non-square board (6 cells -> padded to the 9-cell kernel)
     (4, 4, 6, 512, 256, 256, True),     # Puzzle-15 at the benchmark's network size, with twists
     (3, 3, 3, 32, 32, 12800, False),    # 200 workgroups of two waves (the mid-size launch geometry)
+    (3, 3, 6, 96, 256, 100, True),      # 16-column engine: three chunk pairs -> one bubble step per forward
+    (4, 4, 5, 160, 128, 90, False),     # 16-column engine, hidden 128 (head buffer outside the ring area), five chunk pairs
 ])
 def test_ppo_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, twists):
     n2 = w * h
