@@ -51,3 +51,16 @@ for E, S, rep in ((1024, 50, n), (4096, 30, n), (20000, 16, n), (70000, 8, max(2
         if ref is None: ref = dg
         elif dg != ref: bad += 1
     print("self-play E", E, "searches", S, "repeats", rep, "mismatching repeats", bad, flush=True)
+# policies of any depth (EngineV: inline-asm MFMA chains, weights and activations prefetched through running pointers)
+from tests.util import amd_policy, make_deep_policy_arrays
+for kw, E, rep in ((dict(emb=508, common=(256,)), 65536, n), (dict(emb=512, common=(256, 256), policy_layers=(64,), value_layers=(64,)), 20000, n),
+                   (dict(emb=96, common=(96, 32)), 4096, 4 * n)):
+    polg = amd_policy(make_deep_policy_arrays(16, seed=0, **kw))
+    env = twisterl.env.Puzzle(4, 4, 16, 2, 256)
+    coll = twisterl.collector.PPOCollector(E, 0.995, 0.995, 1)
+    ref = None; bad = 0
+    for i in range(rep):
+        dg = digest(coll.collect(env, polg, seed=5))
+        if ref is None: ref = dg
+        elif dg != ref: bad += 1
+    print("generic policy", kw, "E", E, "repeats", rep, "mismatching repeats", bad, flush=True)
