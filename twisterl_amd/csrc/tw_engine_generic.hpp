@@ -16,6 +16,7 @@ namespace tw {
 
 constexpr int GEN_MAX_WIDTH = 512;        // widest layer (and embedding) the engine's LDS buffers hold
 constexpr int GEN_COLS = 16;
+constexpr int GEN_STRIDE = 17;             // floats per unit row of an activation buffer: 16 columns + 1 (the embedding's writes -- 16 lanes, 4 units apart -- then hit 16 different banks)
 
 typedef float fx4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) fx4 gfx4;
@@ -28,13 +29,14 @@ struct EngineV {
     PolicyDev pol;
     int tid, lane, wave, j, h, g;
     float *lds0, *lds_out, *lds_user;
+    int *lds_rows;                         // [16 columns][NC] obs ids of the forward (the embedding gather works on other columns than its lane's)
     const uint8_t *perm_obs, *perm_act;
 #ifdef TW_ABLATE
     unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};      // diagnostic build: cycles in embedding | common | value head | action head
 #endif
 
     // three activation buffers (the common output stays put while the two heads run) | head outputs [16][8] | kernel use
-    __host__ __device__ static size_t lds_floats(int) { return (size_t)3 * GEN_MAX_WIDTH * GEN_COLS + GEN_COLS * 8 + 256 + 512; }   // (+ 2 KiB of read slack, see layer_tb)
+    __host__ __device__ static size_t lds_floats(int) { return (size_t)3 * GEN_MAX_WIDTH * GEN_STRIDE + GEN_COLS * 8 + 256 + GEN_COLS * NC + 544; }   // (+ 2 KiB of read slack, see layer_tb)
     __device__ __forceinline__ bool primary() const { return wave == 0; }
     __device__ __forceinline__ int  ep_lane() const { return j; }
     __device__ __forceinline__ bool owns_lane() const { return wave == j / (EPB / NS); }
@@ -46,14 +48,15 @@ struct EngineV {
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         j = lane & 15; h = lane >> 4; g = tid >> 4;
         lds0 = lds;
-        lds_out = lds + (size_t)3 * GEN_MAX_WIDTH * GEN_COLS;
+        lds_out = lds + (size_t)3 * GEN_MAX_WIDTH * GEN_STRIDE;
         lds_user = lds_out + GEN_COLS * 8;
+        lds_rows = reinterpret_cast<int *>(lds_user + 256);
         perm_obs = pol.obs_perms; perm_act = pol.act_perms;
     }
     __device__ __forceinline__ void begin2() {}
     __device__ __forceinline__ void end() {}
 
-    __device__ __forceinline__ float *bufp(int i) const { return lds0 + (size_t)i * (GEN_MAX_WIDTH * GEN_COLS); }
+    __device__ __forceinline__ float *bufp(int i) const { return lds0 + (size_t)i * (GEN_MAX_WIDTH * GEN_STRIDE); }
 
     // obs ids of the board's cells (after the twist); -1 for cells the board does not have
     __device__ __forceinline__ void rows_of(uint64_t board, int n_cells, int perm, int (&rowoff)[NC]) const
@@ -89,13 +92,13 @@ struct EngineV {
     // A wave works on blocks wave, wave + 4, ..; per k-group: one weight load, one LDS read, tb MFMAs -- the matrix pipe is the
     // limit (the vector-ALU form of this loop spent 10 instructions per 128 fmas and ran at a quarter of this rate).
     template <int TB>
-    __device__ __forceinline__ void layer_tb(const LayerDev &L, const float *x, float *y) const
+    __device__ __forceinline__ void layer_tb(const LayerDev &L, const float *x, float *y, int w0, int nwv) const      // waves w0 .. w0+nwv-1 work
     {
         typedef float f4v __attribute__((ext_vector_type(4)));
         const int kq = lane >> 4, jj = lane & 15;
         const int NB = L.nb, KG = L.kg;
         constexpr int PF = 8;                                                       // k-groups of weights in flight
-        for (int b = wave; b < NB; b += NW) {                                        // (wave-uniform; no barrier inside)
+        for (int b = wave - w0; b >= 0 && wave < w0 + nwv && b < NB; b += nwv) {     // (wave-uniform; no barrier inside)
             f4v acc[TB];
 #pragma unroll
             for (int t = 0; t < TB; ++t) acc[t] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
@@ -103,7 +106,7 @@ struct EngineV {
             // running pointers, PF groups ahead of the MFMAs: the image carries PF k-groups of slack behind the last one and the
             // LDS buffers 2 KiB, so nothing is clamped; the slack is loaded and never used
             const float *wq = L.wm + (((size_t)kq * NB + b) * 16 + jj) * TB;
-            const float *xq = x + kq * GEN_COLS + jj;
+            const float *xq = x + kq * GEN_STRIDE + jj;
             auto ldw = [&](float (&w)[TB]) {
                 if constexpr (TB == 4) { const fx4 v = *(const gfx4 *)wq; w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
                 else {
@@ -115,8 +118,8 @@ struct EngineV {
             };
             float w[PF][TB], xv[PF];                                                 // weights AND activations PF k-groups ahead: no LDS
 #pragma unroll                                                                       // or L2 round trip between two MFMAs
-            for (int i = 0; i < PF; ++i) { ldw(w[i]); xv[i] = xq[i * (4 * GEN_COLS)]; }
-            xq += PF * (4 * GEN_COLS);
+            for (int i = 0; i < PF; ++i) { ldw(w[i]); xv[i] = xq[i * (4 * GEN_STRIDE)]; }
+            xq += PF * (4 * GEN_STRIDE);
             int g0 = 0;
             for (; g0 + PF <= KG; g0 += PF) {
 #pragma unroll
@@ -124,11 +127,11 @@ struct EngineV {
 #pragma unroll
                     for (int t = 0; t < TB; ++t) {
                         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(w[i][t]), "v"(xv[i]));
-                        if (t == TB - 1) xv[i] = xq[i * (4 * GEN_COLS)];             // (after the last MFMA that reads it was issued)
+                        if (t == TB - 1) xv[i] = xq[i * (4 * GEN_STRIDE)];            // (after the last MFMA that reads it was issued)
                     }
                     ldw(w[i]);
                 }
-                xq += PF * (4 * GEN_COLS);
+                xq += PF * (4 * GEN_STRIDE);
             }
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
@@ -149,21 +152,26 @@ struct EngineV {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (L.relu) r[e] = r[e] > 0.0f ? r[e] : 0.0f;                   // layers.rs:89-91: `if x > 0.0 { x } else { 0.0 }`
-                    y[(o0 + e) * GEN_COLS + jj] = r[e];
+                    y[(o0 + e) * GEN_STRIDE + jj] = r[e];
                 }
             }
         }
-        __syncthreads();
     }
 
-    __device__ __forceinline__ void layer(const LayerDev &L, const float *x, float *y) const
+    // (no barrier: the caller publishes y)
+    __device__ __forceinline__ void layer_on(const LayerDev &L, const float *x, float *y, int w0, int nwv) const
     {
         switch (L.tb) {                                                              // (wave-uniform)
-            case 1: layer_tb<1>(L, x, y); break;
-            case 2: layer_tb<2>(L, x, y); break;
-            case 3: layer_tb<3>(L, x, y); break;
-            default: layer_tb<4>(L, x, y); break;
+            case 1: layer_tb<1>(L, x, y, w0, nwv); break;
+            case 2: layer_tb<2>(L, x, y, w0, nwv); break;
+            case 3: layer_tb<3>(L, x, y, w0, nwv); break;
+            default: layer_tb<4>(L, x, y, w0, nwv); break;
         }
+    }
+    __device__ __forceinline__ void layer(const LayerDev &L, const float *x, float *y) const
+    {
+        layer_on(L, x, y, 0, NW);
+        __syncthreads();
     }
 
     // runs a stack from buffer `src`; returns the buffer holding its output (never `keep`)
@@ -188,35 +196,49 @@ struct EngineV {
         const int E = pol.emb;
         const float *tab = pol.emb_rows;
         const float *bias = tab + (size_t)pol.obs_size * E;
-        // thread (column j, group g of 16) sums output quads g, g+16, ..; TWO quads per trip: all 2 x (NC+1) row loads are requested
-        // before the first add (a missing cell loads row 0 and is not added), so a trip costs one L2 round trip
+        // Thread t gathers for column t >> 4 (not its lane's: the ids go round through LDS) the output quads t & 15, + 16, ..: the 16
+        // lanes of a column read 256 contiguous bytes of a row per load instruction -- half the cache lines of a mapping with one
+        // column per lane.  QT quads per trip: all QT x NC row loads are requested before the first add (a missing cell loads
+        // row 0 and is not added), so a trip costs one L2 round trip.
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) lds_rows[j * NC + i] = rowoff[i];
+        }
+        __syncthreads();
+        const int col = tid >> 4, ql = tid & 15;
+        int ro[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) ro[i] = lds_rows[col * NC + i];
+        constexpr int QT = 4;
         const int nq = E / 4;
-        for (int q0 = g; q0 < nq; q0 += 32) {
-            const int q1 = q0 + 16 < nq ? q0 + 16 : q0;                              // (second quad of the trip; a repeat of the first at the end)
-            fx4 r0[NC], r1[NC];
+        for (int q0 = ql; q0 < nq; q0 += 16 * QT) {
+            int qs[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) qs[u] = q0 + 16 * u < nq ? q0 + 16 * u : q0;  // (past the end: a repeat of the trip's first quad)
+            fx4 r[QT][NC];
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                const float *row = tab + (size_t)(rowoff[i] >= 0 ? rowoff[i] : 0) * E;
-                r0[i] = *(const gfx4 *)(row + 4 * q0);
-                r1[i] = *(const gfx4 *)(row + 4 * q1);
+                const float *row = tab + (size_t)(ro[i] >= 0 ? ro[i] : 0) * E;
+#pragma unroll
+                for (int u = 0; u < QT; ++u) r[u][i] = *(const gfx4 *)(row + 4 * qs[u]);
             }
-            fx4 a0 = *(const gfx4 *)(bias + 4 * q0), a1 = *(const gfx4 *)(bias + 4 * q1);
+            fx4 a[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) a[u] = *(const gfx4 *)(bias + 4 * qs[u]);
 #pragma unroll
             for (int i = 0; i < NC; ++i) {
-                if (rowoff[i] >= 0) {
-                    a0.x = a0.x + r0[i].x; a0.y = a0.y + r0[i].y; a0.z = a0.z + r0[i].z; a0.w = a0.w + r0[i].w;
-                    a1.x = a1.x + r1[i].x; a1.y = a1.y + r1[i].y; a1.z = a1.z + r1[i].z; a1.w = a1.w + r1[i].w;
+                if (ro[i] >= 0) {
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) { a[u].x = a[u].x + r[u][i].x; a[u].y = a[u].y + r[u][i].y; a[u].z = a[u].z + r[u][i].z; a[u].w = a[u].w + r[u][i].w; }
                 }
             }
-            if (pol.emb_relu) {
-                a0.x = a0.x > 0.0f ? a0.x : 0.0f; a0.y = a0.y > 0.0f ? a0.y : 0.0f; a0.z = a0.z > 0.0f ? a0.z : 0.0f; a0.w = a0.w > 0.0f ? a0.w : 0.0f;
-                a1.x = a1.x > 0.0f ? a1.x : 0.0f; a1.y = a1.y > 0.0f ? a1.y : 0.0f; a1.z = a1.z > 0.0f ? a1.z : 0.0f; a1.w = a1.w > 0.0f ? a1.w : 0.0f;
-            }
             float *y = bufp(0);
-            y[(4 * q0 + 0) * GEN_COLS + j] = a0.x; y[(4 * q0 + 1) * GEN_COLS + j] = a0.y;
-            y[(4 * q0 + 2) * GEN_COLS + j] = a0.z; y[(4 * q0 + 3) * GEN_COLS + j] = a0.w;
-            y[(4 * q1 + 0) * GEN_COLS + j] = a1.x; y[(4 * q1 + 1) * GEN_COLS + j] = a1.y;
-            y[(4 * q1 + 2) * GEN_COLS + j] = a1.z; y[(4 * q1 + 3) * GEN_COLS + j] = a1.w;
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                if (pol.emb_relu) { a[u].x = a[u].x > 0.0f ? a[u].x : 0.0f; a[u].y = a[u].y > 0.0f ? a[u].y : 0.0f; a[u].z = a[u].z > 0.0f ? a[u].z : 0.0f; a[u].w = a[u].w > 0.0f ? a[u].w : 0.0f; }
+                y[(4 * qs[u] + 0) * GEN_STRIDE + col] = a[u].x; y[(4 * qs[u] + 1) * GEN_STRIDE + col] = a[u].y;
+                y[(4 * qs[u] + 2) * GEN_STRIDE + col] = a[u].z; y[(4 * qs[u] + 3) * GEN_STRIDE + col] = a[u].w;
+            }
         }
         __syncthreads();
 #ifdef TW_ABLATE
@@ -227,20 +249,31 @@ struct EngineV {
 #ifdef TW_ABLATE
         const unsigned long long c2 = __builtin_readcyclecounter();
 #endif
-        const int vo = stack(ls + pol.n_common + pol.n_action, pol.n_value, co, co);           // policy.rs:89
+        int vo, ao;
+        if (pol.n_value == 1 && pol.n_action == 1) {
+            // single-Linear heads (BasicPolicy's default): both at once, the value head on waves 2..3, the action head on waves
+            // 0..1 (a head is one or two blocks of tiles: one after the other they keep one wave busy each)
+            vo = co == 0 ? 1 : 0; ao = 3 - co - vo;
+            layer_on(ls[pol.n_common + pol.n_action], bufp(co), bufp(vo), 2, 2);               // policy.rs:89
+            layer_on(ls[pol.n_common], bufp(co), bufp(ao), 0, 2);                              // policy.rs:92
+            __syncthreads();
+        } else {
+            vo = stack(ls + pol.n_common + pol.n_action, pol.n_value, co, co);                 // policy.rs:89
+            ao = -1;
+        }
         if (g == 0) {                                                                          // .sum() of the value head's outputs
             float s = 0.0f;
-            for (int i = 0; i < pol.value_out; ++i) s = s + bufp(vo)[i * GEN_COLS + j];
+            for (int i = 0; i < pol.value_out; ++i) s = s + bufp(vo)[i * GEN_STRIDE + j];
             lds_out[j * 8 + 4] = s;
         }
         __syncthreads();
 #ifdef TW_ABLATE
         const unsigned long long c3 = __builtin_readcyclecounter();
 #endif
-        const int ao = stack(ls + pol.n_common, pol.n_action, co, co);                         // policy.rs:92
+        if (ao < 0) ao = stack(ls + pol.n_common, pol.n_action, co, co);                       // policy.rs:92
         if (g == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds_out[j * 8 + i] = bufp(ao)[i * GEN_COLS + j];
+            for (int i = 0; i < 4; ++i) lds_out[j * 8 + i] = bufp(ao)[i * GEN_STRIDE + j];
         }
         __syncthreads();
 #pragma unroll
