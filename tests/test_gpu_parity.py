@@ -261,6 +261,29 @@ def test_rccl_exchange_behind_the_c_abi_single_rank(tw, oracle):
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------ boards above 16 cells (puzzle.rs:34-42)
+@pytest.mark.parametrize("w,h,diff,emb,common,E,twists", [(5, 5, 6, 64, (64,), 60, True), (6, 4, 5, 32, (48, 32), 33, False), (8, 8, 3, 32, (32,), 12, False)])
+def test_ppo_collect_of_boards_above_16_cells(tw, oracle, w, h, diff, emb, common, E, twists):
+    """The reference's Puzzle takes any width x height (rust/src/envs/puzzle.rs:34-42); the kernels pack a board as 16 nibbles.
+    Larger boards collect through the any-environment path (the Puzzle steps on the host, one batched policy launch per time
+    step, obs ids beyond 255 as two bytes): every field bit-equal to the oracle's native collector.  Self-play and evaluate of
+    such boards are not implemented and say so."""
+    from tests.util import make_deep_policy_arrays
+    n2 = w * h
+    arrs = make_deep_policy_arrays(n2, seed=5, emb=emb, common=common, scale=2.0)
+    op_, ap_ = puzzle_transpose_twist(w) if twists else ((), ())
+    gp, op = amd_policy(arrs, op_, ap_), oracle_policy(oracle, arrs, op_, ap_)
+    genv, oenv = tw.env.Puzzle(w, h, diff, 2, 256), oracle.Puzzle(w, h, diff, 2, 256)
+    for merge_order in (True, False):
+        coll = tw.collector.PPOCollector(E, 0.995, 0.995, 32)
+        coll.merge_order = merge_order
+        g = coll.collect(genv, gp, seed=17)
+        o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=17, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8, merge_order=merge_order)
+        _assert_same_collect(g, o, n2)
+    with pytest.raises(RuntimeError, match="16"):
+        tw.collector.AZCollector(4, 3, 1.41, 1, 1).collect(genv, gp, seed=1)
+
+
 # ------------------------------------------------------------------------------ any Sequential depth (modules.rs:28-34)
 @pytest.mark.parametrize("n2,emb,common,pl,vl,twists", [
     (9, 64, (128, 64), (), (), True),          # two common layers
@@ -367,8 +390,10 @@ def test_errors(tw, oracle):
         tw.collector.PPOCollector(0, 0.9, 0.9, 1).collect(tw.env.Puzzle(3, 3, 1, 2, 256), gp)
     with pytest.raises(TypeError, match="__extract_env__"):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(object(), gp)
+    with pytest.raises(ValueError):
+        tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)   # (a 25-cell board collects; this policy is a 9-cell one)
     with pytest.raises(RuntimeError, match="width\\*height <= 16"):
-        tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)
+        tw.collector.AZCollector(4, 2, 1.41, 1, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)   # self-play: 16 cells at most
     with pytest.raises(ValueError):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(4, 4, 1, 2, 256), gp)   # obs_size mismatch
     arrs = make_policy_arrays(9, emb=50, hidden=32)

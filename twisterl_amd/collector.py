@@ -240,7 +240,7 @@ class PyBaseCollector:
         desc = get_env_desc(py_env)
         nc = int(desc.width) * int(desc.height)
         z = lambda shape, dt: torch.empty(shape, dtype=dt, device="cuda")
-        out = {"obs": z((0, nc), torch.uint8), "logits": z((0, 4), torch.float32), "perms": z((0,), torch.int8)}
+        out = {"obs": z((0, nc), torch.uint8 if nc * nc <= 256 else torch.int16), "logits": z((0, 4), torch.float32), "perms": z((0,), torch.int8)}
         if self._IS_PPO:
             out.update(values=z((0,), torch.float32), rewards=z((0,), torch.float32), actions=z((0,), torch.uint8),
                        advs=z((0,), torch.float32), rets=z((0,), torch.float32))
