@@ -242,6 +242,11 @@ int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
  * ended after max_records_per_episode records is an error.  params.reserve_cus is ignored. */
 int tw_ppo_collect_env(const tw_env_vtable *env, const tw_policy *policy, const tw_ppo_params *params,
                        uint32_t max_records_per_episode, tw_collected **out);
+/* AZCollector::collect for any environment (rust/src/collector/az.rs:51-109): the search trees live on the host (a node owns
+ * a clone of the environment, as rust/src/rl/search.rs:20-26), every Policy::full_predict the searches of all episodes want at
+ * a moment is one batched launch.  Same rules as tw_ppo_collect_env. */
+int tw_az_collect_env(const tw_env_vtable *env, const tw_policy *policy, const tw_az_params *params,
+                      uint32_t max_records_per_episode, tw_collected **out);
 
 /* evaluate(): reset + best-of-num_searches solve for episodes [episode_offset, +num_episodes);
  * returns the success rate and the mean total reward, accumulated in episode order. */

@@ -508,3 +508,98 @@ def ppo_collect_env(proto, policy: Policy, num_episodes, gamma, lam, seed=0, epi
                      cat(4, np.float32).reshape(-1), cat(5, np.int64).reshape(-1),
                      {"advs": cat(6, np.float32).reshape(-1), "rets": cat(7, np.float32).reshape(-1)},
                      np.asarray([len(e[3]) for e in eps], dtype=np.uint32))
+
+
+def az_collect_env(proto, policy: Policy, num_episodes, num_mcts_searches, C_, max_expand_depth, seed=0, episode_offset=0,
+                   difficulty=1, arith=ARITH_CHAIN, merge_order=True) -> Collected:
+    """AZCollector::collect (rust/src/collector/az.rs:51-109) with predict_probs_mcts (rust/src/rl/search.rs:104-189) over ANY
+    environment object with the reference's Python env protocol: per move root full_predict, expand (a child per action with
+    prior > 0: copy + next), `num_mcts_searches` times: descend by UCB (:29-39, first maximum), up to `max_expand_depth` times
+    reward / is_final / full_predict / expand / next_sample, backpropagate; visit counts -> probs; sample the action; record.
+    Randomness per the build's RNG spec (streams of two_az_collect), exp of the soft-max deterministic (set_det_exp).  A pure-
+    Python loop: small cases only.  Caller: set_det_exp(True) around the call."""
+    f32 = np.float32
+    A = policy.n_actions
+    eps = []
+    for i in range(num_episodes):
+        env = proto.copy()
+        ep = episode_offset + i
+        if hasattr(env, "seed_episode"):
+            env.seed_episode(seed, ep)
+        env.reset(difficulty)
+        obs_l, prob_l, val_l = [], [], []
+        t = 0
+        while True:
+            # predict_probs_mcts (search.rs:104-189)
+            root_state = env.copy()
+            probs, _ = policy.full_predict([int(x) for x in root_state.observe()], [bool(m) for m in root_state.masks()], arith=arith)
+            nodes = [dict(state=root_state, parent=-1, action=-1, prior=f32(0), visit=1, vsum=f32(0), children=[])]
+
+            def expand(idx, pri):
+                for a in range(A):
+                    if not (pri[a] > 0):
+                        continue
+                    st = nodes[idx]["state"].copy()
+                    st.next(a)
+                    nodes.append(dict(state=st, parent=idx, action=a, prior=f32(pri[a]), visit=0, vsum=f32(0), children=[]))
+                    nodes[idx]["children"].append(len(nodes) - 1)
+            expand(0, probs)
+            for it in range(num_mcts_searches):
+                idx = 0
+                while nodes[idx]["children"]:
+                    par, best, best_ucb = nodes[idx], None, f32(-np.inf)
+                    for c in par["children"]:
+                        ch = nodes[c]
+                        q = f32(0) if ch["visit"] == 0 else f32(ch["vsum"] / f32(ch["visit"]))
+                        d = f32(np.sqrt(f32(par["visit"])) / f32(f32(ch["visit"]) + f32(1)))
+                        d = f32(f32(C_) * d)
+                        d = f32(d * ch["prior"])
+                        ucb = f32(q + d)
+                        if ucb > best_ucb:
+                            best, best_ucb = c, ucb
+                    idx = best
+                value, expanded = f32(0), 0
+                while expanded < max_expand_depth:
+                    st = nodes[idx]["state"]
+                    value = f32(st.value())
+                    if st.is_final():
+                        break
+                    pr, nv = policy.full_predict([int(x) for x in st.observe()], [bool(m) for m in st.masks()], arith=arith)
+                    expand(idx, pr)
+                    ch = nodes[idx]["children"]
+                    w = philox4x32_10([ep & 0xFFFFFFFF, ep >> 32, it * max_expand_depth + expanded, 4 | (t << 8)], [seed & 0xFFFFFFFF, seed >> 32])
+                    u = float(f32(w[0] >> 8) * f32(1.0 / 16777216.0))
+                    idx = ch[sample_weighted([nodes[c]["prior"] for c in ch], u)]
+                    value = f32(nv)
+                    expanded += 1
+                j = idx
+                while j >= 0:
+                    nodes[j]["vsum"] = f32(nodes[j]["vsum"] + value)
+                    nodes[j]["visit"] += 1
+                    j = nodes[j]["parent"]
+            mp = np.zeros(A, dtype=np.float32)
+            for c in nodes[0]["children"]:
+                mp[nodes[c]["action"]] = f32(nodes[c]["visit"])
+            sm = f32(0)
+            for a in range(A):
+                sm = f32(sm + mp[a])
+            mp = (mp / sm).astype(np.float32) if sm > 0 else np.full(A, f32(1.0) / f32(A), dtype=np.float32)
+            # az.rs:72-89
+            w = philox4x32_10([ep & 0xFFFFFFFF, ep >> 32, t, 3], [seed & 0xFFFFFFFF, seed >> 32])
+            action = sample_weighted(mp, float(f32(w[0] >> 8) * f32(1.0 / 16777216.0)))
+            obs_l.append([int(x) for x in env.observe()]); prob_l.append(mp); val_l.append(f32(env.value()))
+            if env.is_final():
+                break
+            env.next(action)
+            t += 1
+        total, before = f32(0), []
+        for v in val_l:
+            before.append(total)
+            total = f32(total + v)
+        eps.append((obs_l, prob_l, [f32(total - b) for b in before]))
+    order = ([num_episodes - 1] + list(range(num_episodes - 1))) if merge_order else list(range(num_episodes))
+    n_of = [len(e[2]) for e in eps]
+    cat = lambda k, dt: np.concatenate([np.asarray(eps[i][k], dtype=dt).reshape(n_of[i], -1) for i in order])
+    n = sum(n_of)
+    return Collected(cat(0, np.int64), cat(1, np.float32), np.full(n, -1, dtype=np.int32), np.zeros(0, np.float32), np.zeros(0, np.float32),
+                     np.zeros(0, np.int64), {"remaining_values": cat(2, np.float32).reshape(-1)}, np.asarray(n_of, dtype=np.uint32))

@@ -266,8 +266,8 @@ def test_rccl_exchange_behind_the_c_abi_single_rank(tw, oracle):
 def test_ppo_collect_of_boards_above_16_cells(tw, oracle, w, h, diff, emb, common, E, twists):
     """The reference's Puzzle takes any width x height (rust/src/envs/puzzle.rs:34-42); the kernels pack a board as 16 nibbles.
     Larger boards collect through the any-environment path (the Puzzle steps on the host, one batched policy launch per time
-    step, obs ids beyond 255 as two bytes): every field bit-equal to the oracle's native collector.  Self-play and evaluate of
-    such boards are not implemented and say so."""
+    step, obs ids beyond 255 as two bytes): every field bit-equal to the oracle's native collectors, PPO and self-play.  evaluate
+    / solve of such boards are not implemented and say so."""
     from tests.util import make_deep_policy_arrays
     n2 = w * h
     arrs = make_deep_policy_arrays(n2, seed=5, emb=emb, common=common, scale=2.0)
@@ -280,8 +280,12 @@ def test_ppo_collect_of_boards_above_16_cells(tw, oracle, w, h, diff, emb, commo
         g = coll.collect(genv, gp, seed=17)
         o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=17, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8, merge_order=merge_order)
         _assert_same_collect(g, o, n2)
+    for S, med in ((10, 1), (6, 2)):
+        z = tw.collector.AZCollector(min(E, 20), S, 1.41, med, 32).collect(genv, gp, seed=19)
+        zo = oracle.az_collect(oenv, op, min(E, 20), S, 1.41, med, seed=19, arith=oracle.ARITH_CHAIN, num_threads=8, det_math=True)
+        _assert_same_az(z, zo, n2)
     with pytest.raises(RuntimeError, match="16"):
-        tw.collector.AZCollector(4, 3, 1.41, 1, 1).collect(genv, gp, seed=1)
+        tw.collector.evaluate(genv, gp, num_episodes=4, deterministic=True, num_searches=1, num_mcts_searches=0, seed=1, C=1.41, max_expand_depth=1, num_cores=1)
 
 
 # ------------------------------------------------------------------------------ any Sequential depth (modules.rs:28-34)
@@ -369,8 +373,15 @@ def test_ppo_collect_of_a_python_environment(tw, oracle, w, h, steps, emb, commo
     assert (a["ep_len"] <= steps + 1).all() and a["ep_len"].min() >= 1
     # reference-style access and the consumers' attributes
     assert len(g.obs) == len(g.actions) == len(g.additional_data["rets"]) and set(g.perms) == {-1}
-    with pytest.raises(TypeError, match="PPOCollector"):
-        tw.collector.AZCollector(4, 4, 1.41, 1, 1).collect(env, gp)
+    # self-play of the same environment (tw_az_collect_env: host trees, batched full_predict) against the oracle's restatement
+    oracle.set_det_exp(True)
+    try:
+        for S, med in ((8, 1), (5, 2)):
+            z = tw.collector.AZCollector(min(E, 16), S, 1.41, med, 4).collect(env, gp, seed=79)
+            zo = oracle.az_collect_env(proto, op, min(E, 16), S, 1.41, med, seed=79, difficulty=3)
+            _assert_same_az(z, zo, n)
+    finally:
+        oracle.set_det_exp(False)
 
     class Broken(GridWorld):
         def next(self, action):
@@ -392,8 +403,8 @@ def test_errors(tw, oracle):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(object(), gp)
     with pytest.raises(ValueError):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)   # (a 25-cell board collects; this policy is a 9-cell one)
-    with pytest.raises(RuntimeError, match="width\\*height <= 16"):
-        tw.collector.AZCollector(4, 2, 1.41, 1, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)   # self-play: 16 cells at most
+    with pytest.raises(ValueError):
+        tw.collector.AZCollector(4, 2, 1.41, 1, 1).collect(tw.env.Puzzle(5, 5, 1, 2, 256), gp)
     with pytest.raises(ValueError):
         tw.collector.PPOCollector(4, 0.9, 0.9, 1).collect(tw.env.Puzzle(4, 4, 1, 2, 256), gp)   # obs_size mismatch
     arrs = make_policy_arrays(9, emb=50, hidden=32)

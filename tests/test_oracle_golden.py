@@ -518,3 +518,56 @@ def test_generic_env_collect_dummy_env_known_answer(oracle):
     assert d.obs.shape[0] == 2 and d.values.tolist() == [1.0, 1.0] and d.rewards.tolist() == [1.0, 1.0]
     assert np.allclose(d.additional_data["rets"], [1.9, 1.0]) and np.allclose(d.additional_data["advs"], [0.9, 0.0], atol=1e-7)
     assert d.actions.tolist() == [0, 0] and d.ep_len.tolist() == [2]
+
+
+def test_generic_env_self_play_dummy_env_known_answer(oracle):
+    """The reference's AZCollector test (rust/src/collector/az.rs:132-186): DummyEnv (one action, final after one step, reward
+    1.0), a one-weight policy, 1 episode, 1 search => 2 records with `remaining_values`.  Through the oracle's self-play
+    collector for arbitrary environments (az_collect_env); with one action every MCTS prob is 1 and the remaining values are
+    [2, 1].  And on a Puzzle the restatement must agree with the oracle's native self-play collector, bit for bit."""
+    class DummyEnv:
+        def __init__(self):
+            self.steps = 0
+        def copy(self):
+            c = DummyEnv(); c.steps = self.steps; return c
+        def num_actions(self): return 1
+        def obs_shape(self): return [1]
+        def reset(self, difficulty): self.steps = 0
+        def next(self, action): self.steps += 1
+        def masks(self): return [True]
+        def is_final(self): return self.steps >= 1
+        def value(self): return 1.0
+        def observe(self): return [0]
+    pol = oracle.Policy(np.zeros((1, 1), np.float32), np.ones(1, np.float32), [], [(np.ones(1, np.float32), np.zeros(1, np.float32), False)],
+                        [(np.ones(1, np.float32), np.zeros(1, np.float32), False)], emb_relu=False)
+    oracle.set_det_exp(True)
+    try:
+        d = oracle.az_collect_env(DummyEnv(), pol, 1, 1, 1.0, 1, seed=0)
+        assert d.obs.shape[0] == 2 and "remaining_values" in d.additional_data and d.ep_len.tolist() == [2]
+        assert d.logits.reshape(-1).tolist() == [1.0, 1.0] and d.additional_data["remaining_values"].tolist() == [2.0, 1.0]
+
+        # the same algorithm, two implementations: a Puzzle behind the Python env protocol against two_az_collect
+        class PyPuzzle:
+            def __init__(self, w, h, diff):
+                self.p = oracle.Puzzle(w, h, diff, 2, 256); self.seed = (0, 0)
+            def copy(self):
+                c = PyPuzzle.__new__(PyPuzzle); c.p = self.p.clone(); c.seed = self.seed; return c
+            def seed_episode(self, seed, episode): self.seed = (seed, episode)
+            def num_actions(self): return 4
+            def obs_shape(self): return self.p.obs_shape()
+            def reset(self, difficulty): self.p.reset(seed=self.seed[0], episode=self.seed[1])
+            def next(self, action): self.p.step(action)
+            def masks(self): return self.p.masks()
+            def is_final(self): return self.p.is_final()
+            def value(self): return self.p.reward()
+            def observe(self): return self.p.observe()
+        from tests.util import make_policy_arrays, oracle_policy
+        op = oracle_policy(oracle, make_policy_arrays(9, seed=3, emb=32, hidden=32, scale=3.0))
+        for S, med in ((7, 1), (5, 2)):
+            a = oracle.az_collect_env(PyPuzzle(3, 3, 3), op, 6, S, 1.41, med, seed=23)
+            b = oracle.az_collect(oracle.Puzzle(3, 3, 3, 2, 256), op, 6, S, 1.41, med, seed=23, arith=oracle.ARITH_CHAIN, num_threads=2, det_math=True)
+            assert np.array_equal(a.obs, b.obs) and np.array_equal(a.ep_len, b.ep_len)
+            assert np.array_equal(a.logits.view(np.uint32), b.logits.view(np.uint32))
+            assert np.array_equal(a.additional_data["remaining_values"].view(np.uint32), b.additional_data["remaining_values"].view(np.uint32))
+    finally:
+        oracle.set_det_exp(False)

@@ -131,6 +131,7 @@ SYMBOLS = {
     "tw_ppo_collect": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(PPOParams), C.POINTER(_VP)]),
     "tw_az_collect": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(AZParams), C.POINTER(_VP)]),
     "tw_ppo_collect_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(PPOParams), C.c_uint32, C.POINTER(_VP)]),
+    "tw_az_collect_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(AZParams), C.c_uint32, C.POINTER(_VP)]),
     "tw_evaluate": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(SolveParams), C.c_uint64, C.c_uint64,
                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tw_solve": (C.c_int, [_VP, _VP, C.POINTER(SolveParams), C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -324,8 +324,9 @@ class PPOCollector(PyBaseCollector):
 
 
 def _collect_foreign(self, py_env: PyEnv, policy: Policy, seed) -> CollectedData:
-    """PPOCollector.collect for an environment implemented in Python (tw_ppo_collect_env): the object's methods are handed to
-    the library as the C function table of `trait Env`; clones live here, keyed by small integer handles."""
+    """PPOCollector / AZCollector.collect for an environment implemented in Python (tw_ppo_collect_env / tw_az_collect_env): the
+    object's methods are handed to the library as the C function table of `trait Env`; clones live here, keyed by small integer
+    handles."""
     if not isinstance(policy, Policy):
         raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
     if self.precision not in ("fp32", "f32", "exact"):
@@ -394,11 +395,16 @@ def _collect_foreign(self, py_env: PyEnv, policy: Policy, seed) -> CollectedData
     vt = V(1, int(proto.num_actions()), n_obs, obs_size, fields["clone"](f_clone), fields["destroy"](f_destroy), fields["reset"](f_reset),
            fields["step"](f_step), fields["observe"](f_observe), fields["masks"](f_masks), fields["reward"](f_reward),
            fields["is_final"](f_final))
-    prm = _lib.PPOParams(self.num_episodes, self.episode_offset, self.gamma, self.lambda_,
-                         (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed(), _lib.TW_PREC_F32_EXACT,
-                         int(self.merge_order), 0)
+    sd = (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed()
     out = C.c_void_p()
-    rc = _lib.lib().tw_ppo_collect_env(C.byref(vt), policy._handle(), C.byref(prm), int(getattr(proto, "max_records", 1 << 16)), C.byref(out))
+    max_records = int(getattr(proto, "max_records", 1 << 16))
+    if self._IS_PPO:
+        prm = _lib.PPOParams(self.num_episodes, self.episode_offset, self.gamma, self.lambda_, sd, _lib.TW_PREC_F32_EXACT, int(self.merge_order), 0)
+        rc = _lib.lib().tw_ppo_collect_env(C.byref(vt), policy._handle(), C.byref(prm), max_records, C.byref(out))
+    else:
+        prm = _lib.AZParams(self.num_episodes, self.episode_offset, self.num_mcts_searches, self.C, self.max_expand_depth, sd,
+                            _lib.TW_PREC_F32_EXACT, int(self.merge_order), 0)
+        rc = _lib.lib().tw_az_collect_env(C.byref(vt), policy._handle(), C.byref(prm), max_records, C.byref(out))
     if err:
         if out.value:
             _lib.lib().tw_collected_free(out)
@@ -430,8 +436,11 @@ class AZCollector(PyBaseCollector):
         self._calls = 0
 
     _next_seed = PPOCollector._next_seed
+    _collect_foreign = _collect_foreign
 
     def collect(self, py_env, policy: Policy, *, seed=None) -> CollectedData:
+        if isinstance(py_env, PyEnv):
+            return self._collect_foreign(py_env, policy, seed)
         desc = self._check(py_env, policy)
         prm = _lib.AZParams(self.num_episodes, self.episode_offset, self.num_mcts_searches, self.C,
                             self.max_expand_depth,

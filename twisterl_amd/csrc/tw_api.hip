@@ -978,6 +978,37 @@ int make_env_consts(const tw_puzzle_desc *env, PuzzleConsts *out)
 
 }  // namespace
 
+// Boards above 16 cells (puzzle.rs:34-42 takes any width x height; the kernels pack a board as 16 nibbles): the Puzzle steps
+// on the host through the any-environment collectors (tw_env_generic.hip) -- same RNG spec, same arithmetic, the policy
+// evaluations of a moment in one batched launch.  f32; evaluate / solve of such boards are not implemented.
+static int collect_big_board(const tw_puzzle_desc *env, const tw_policy *policy, const tw_ppo_params *ppo, const tw_az_params *az, tw_collected **out)
+{
+    const uint32_t precision = ppo ? ppo->precision : az->precision;
+    if (precision != TW_PREC_F32_EXACT) { set_error("boards above 16 cells collect in f32 only"); return TW_ERR_UNSUPPORTED; }
+    if ((uint64_t)env->width * env->height > 64) { set_error("Puzzle %ux%u: at most 64 cells", env->width, env->height); return TW_ERR_UNSUPPORTED; }
+    const uint64_t depth0 = (uint64_t)env->depth_slope * env->difficulty;
+    if (depth0 + 1 > 0xffffffffull) { set_error("Puzzle: depth_slope*difficulty too large"); return TW_ERR_UNSUPPORTED; }
+    tw_puzzle *proto = tw_puzzle_create(env->width, env->height, env->difficulty, env->depth_slope, env->max_depth);
+    if (!proto) return TW_ERR_INVALID;
+    tw_env_vtable vt{};
+    vt.prototype = proto; vt.num_actions = 4; vt.n_obs = env->width * env->height; vt.obs_size = vt.n_obs * vt.n_obs;
+    vt.clone = [](void *e) -> void * { return tw_puzzle_clone(static_cast<tw_puzzle *>(e)); };
+    vt.destroy = [](void *e) { tw_puzzle_destroy(static_cast<tw_puzzle *>(e)); };
+    vt.reset = [](void *e, uint64_t seed, uint64_t episode) { (void)tw_puzzle_reset(static_cast<tw_puzzle *>(e), seed, episode); };
+    vt.step = [](void *e, uint32_t a) { (void)tw_puzzle_step(static_cast<tw_puzzle *>(e), a); };
+    vt.observe = [](void *e, int32_t *o) {
+        const tw_puzzle *q = static_cast<const tw_puzzle *>(e);
+        const int64_t n = (int64_t)q->state.size();
+        for (int64_t i = 0; i < n; ++i) o[i] = (int32_t)(i * n + q->state[(size_t)i]);       // puzzle.rs:183-185
+    };
+    vt.masks = [](void *e, uint8_t *m) { (void)tw_puzzle_masks(static_cast<tw_puzzle *>(e), m); };
+    vt.reward = [](void *e) -> float { return tw_puzzle_reward(static_cast<tw_puzzle *>(e)); };
+    vt.is_final = [](void *e) -> int { return tw_puzzle_is_final(static_cast<tw_puzzle *>(e)); };
+    const int rc = ppo ? tw_ppo_collect_env(&vt, policy, ppo, (uint32_t)(depth0 + 1), out) : tw_az_collect_env(&vt, policy, az, (uint32_t)(depth0 + 1), out);
+    tw_puzzle_destroy(proto);
+    return rc;
+}
+
 extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy, const tw_ppo_params *prm,
                               tw_collected **out)
 {
@@ -990,33 +1021,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     if (prm->precision > TW_PREC_F16X2) { set_error("tw_ppo_collect: unknown precision %u", prm->precision); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
 
-    // Boards above 16 cells (puzzle.rs:34-42 takes any width x height; the kernels pack a board as 16 nibbles): the Puzzle
-    // steps on the host through the any-environment collector (tw_env_generic.hip) -- same RNG spec, same arithmetic, one
-    // batched policy launch per time step.  PPO in f32; self-play / evaluate / solve of such boards are not implemented.
-    if ((uint64_t)env->width * env->height > 16) {
-        if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_ppo_collect: boards above 16 cells run in f32 only"); return TW_ERR_UNSUPPORTED; }
-        if ((uint64_t)env->width * env->height > 64) { set_error("Puzzle %ux%u: at most 64 cells", env->width, env->height); return TW_ERR_UNSUPPORTED; }
-        tw_puzzle *proto = tw_puzzle_create(env->width, env->height, env->difficulty, env->depth_slope, env->max_depth);
-        if (!proto) return TW_ERR_INVALID;
-        tw_env_vtable vt{};
-        vt.prototype = proto; vt.num_actions = 4; vt.n_obs = env->width * env->height; vt.obs_size = vt.n_obs * vt.n_obs;
-        vt.clone = [](void *e) -> void * { return tw_puzzle_clone(static_cast<tw_puzzle *>(e)); };
-        vt.destroy = [](void *e) { tw_puzzle_destroy(static_cast<tw_puzzle *>(e)); };
-        vt.reset = [](void *e, uint64_t seed, uint64_t episode) { (void)tw_puzzle_reset(static_cast<tw_puzzle *>(e), seed, episode); };
-        vt.step = [](void *e, uint32_t a) { (void)tw_puzzle_step(static_cast<tw_puzzle *>(e), a); };
-        vt.observe = [](void *e, int32_t *o) {
-            const tw_puzzle *q = static_cast<const tw_puzzle *>(e);
-            const int64_t n = (int64_t)q->state.size();
-            for (int64_t i = 0; i < n; ++i) o[i] = (int32_t)(i * n + q->state[(size_t)i]);       // puzzle.rs:183-185
-        };
-        vt.masks = [](void *e, uint8_t *m) { (void)tw_puzzle_masks(static_cast<tw_puzzle *>(e), m); };
-        vt.reward = [](void *e) -> float { return tw_puzzle_reward(static_cast<tw_puzzle *>(e)); };
-        vt.is_final = [](void *e) -> int { return tw_puzzle_is_final(static_cast<tw_puzzle *>(e)); };
-        const uint64_t depth0 = (uint64_t)env->depth_slope * env->difficulty;
-        rc = depth0 + 1 > 0xffffffffull ? TW_ERR_UNSUPPORTED : tw_ppo_collect_env(&vt, policy, prm, (uint32_t)(depth0 + 1), out);
-        tw_puzzle_destroy(proto);
-        return rc;
-    }
+    if ((uint64_t)env->width * env->height > 16) return collect_big_board(env, policy, prm, nullptr, out);
 
     RolloutArgs ra{};
     rc = make_env_consts(env, &ra.env); if (rc) return rc;
@@ -1126,6 +1131,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     }
     if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_az_collect: precision %u not implemented", prm->precision); return TW_ERR_UNSUPPORTED; }
     int rc = require_device(); if (rc) return rc;
+    if ((uint64_t)env->width * env->height > 16) return collect_big_board(env, policy, nullptr, prm, out);
 
     MctsArgs ma{};
     rc = make_env_consts(env, &ma.env); if (rc) return rc;

@@ -169,3 +169,271 @@ extern "C" int tw_ppo_collect_env(const tw_env_vtable *env, const tw_policy *pol
     collected_adopt_obs_width(*out, OW);
     return TW_OK;
 }
+
+// ======================================================================================================================
+// AZCollector::collect for ANY environment (rust/src/collector/az.rs:51-109 over predict_probs_mcts, rust/src/rl/search.rs:104-189).
+// The trees live on the host (a node owns a clone of the environment, as MCTSNode does); every episode is a little state
+// machine that runs until it needs Policy::full_predict of a state, and all the states wanted at that moment are evaluated
+// by ONE batched launch.  Same RNG keys and the same f32 operation order as the self-play kernels (tw_mcts.hip).
+namespace {
+
+int sample_weighted_host(const float *w, int n, float u)             // nn::policy::sample (policy.rs:153-167), see tw_common.hpp
+{
+    if (n <= 0) return 0;
+    float total = 0.0f;
+    std::vector<float> cum((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!(w[i] >= 0.0f)) return 0;
+        total = total + w[i];
+        cum[(size_t)i] = total;
+    }
+    if (!(total > 0.0f)) return 0;
+    const float chosen = u * total;
+    int idx = 0;
+    while (idx < n - 1 && cum[(size_t)idx] <= chosen) ++idx;
+    return idx;
+}
+
+struct HostNode {                       // MCTSNode + its place in Tree<T> (search.rs:20-26, tree.rs:14-54)
+    void *state; int parent; int action; float prior; uint32_t visit; float value_sum; int first_child, n_children;
+};
+
+}  // namespace
+
+extern "C" int tw_az_collect_env(const tw_env_vtable *env, const tw_policy *policy, const tw_az_params *prm,
+                                 uint32_t max_records_per_episode, tw_collected **out)
+{
+    if (!env || !policy || !prm || !out) { set_error("tw_az_collect_env: null argument"); return TW_ERR_INVALID; }
+    *out = nullptr;
+    if (!env->prototype || !env->clone || !env->destroy || !env->reset || !env->step || !env->observe || !env->masks || !env->reward || !env->is_final) {
+        set_error("tw_az_collect_env: the environment table lacks a method"); return TW_ERR_INVALID;
+    }
+    if (prm->num_episodes == 0) { set_error("Something went wrong. No data in collected data chunks to merge. "); return TW_ERR_EMPTY; }   // collector.rs:41
+    if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_az_collect_env: f32 only"); return TW_ERR_UNSUPPORTED; }
+    const PolicyDev *pd = policy_dev(policy);
+    const uint32_t A = env->num_actions, NO = env->n_obs;
+    if (A == 0 || A > 31 || (int)A != pd->n_actions) { set_error("environment has %u actions, policy has %d (at most 31)", A, pd->n_actions); return TW_ERR_INVALID; }
+    if (NO == 0 || NO > 64) { set_error("tw_az_collect_env: observations of %u ids (1..64 supported)", NO); return TW_ERR_UNSUPPORTED; }
+    if ((int)env->obs_size != pd->obs_size) { set_error("index out of bounds: policy obs_size %d != environment obs ids %u", pd->obs_size, env->obs_size); return TW_ERR_INVALID; }
+    if (max_records_per_episode == 0) { set_error("tw_az_collect_env: max_records_per_episode must be positive"); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+
+    const uint64_t E = prm->num_episodes;
+    const uint32_t S = prm->num_mcts_searches, MED = prm->max_expand_depth, OW = pd->obs_size > 256 ? 2u : 1u;
+    hipStream_t s = current_stream();
+    enum { NEED_ROOT, NEED_LEAF, DONE };
+    struct Ep {
+        void *env = nullptr; int phase = NEED_ROOT; uint32_t t = 0, it = 0, expanded = 0; int node = 0; float value = 0.0f;
+        std::vector<HostNode> tree;
+        std::vector<int32_t> obs; std::vector<float> probs, vals;
+    };
+    std::vector<Ep> eps(E);
+    auto free_tree = [&](Ep &e) { for (auto &n : e.tree) if (n.state) env->destroy(n.state); e.tree.clear(); };
+    auto cleanup = [&]() { for (auto &e : eps) { free_tree(e); if (e.env) { env->destroy(e.env); e.env = nullptr; } } };
+    for (uint64_t i = 0; i < E; ++i) {                                     // az.rs:56-57
+        eps[i].env = env->clone(env->prototype);
+        if (!eps[i].env) { cleanup(); set_error("tw_az_collect_env: clone() returned null"); return TW_ERR_INVALID; }
+        env->reset(eps[i].env, prm->seed, prm->episode_offset + i);
+    }
+    const size_t b_obs = (size_t)E * NO * 4, b_m = (size_t)E * A, b_la = (size_t)E * A * 4, b_v = (size_t)E * 4;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_obs = 0, o_m = up(b_obs), o_la = o_m + up(b_m), o_v = o_la + up(b_la), tot = o_v + up(b_v);
+    uint8_t *dev = nullptr;
+    hipError_t he = hipMalloc((void **)&dev, tot);
+    if (he != hipSuccess) { cleanup(); return hip_fail(he, "hipMalloc(step staging)", __FILE__, __LINE__); }
+    std::vector<int32_t> h_obs((size_t)E * NO); std::vector<uint8_t> h_m((size_t)E * A); std::vector<float> h_la((size_t)E * A), h_v(E);
+    std::vector<uint64_t> want; want.reserve(E);
+#define TW_HIP_E(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); (void)hipFree(dev); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
+
+    // MCTSTree::expand (search.rs:56-75): a child per action with prior > 0, state = clone + step
+    auto expand = [&](Ep &e, int idx, const float *priors) {
+        e.tree[(size_t)idx].first_child = (int)e.tree.size();
+        int cnt = 0;
+        for (uint32_t a = 0; a < A; ++a) {
+            if (!(priors[a] > 0.0f)) continue;
+            void *st = env->clone(e.tree[(size_t)idx].state);
+            env->step(st, a);
+            e.tree.push_back(HostNode{st, idx, (int)a, priors[a], 0u, 0.0f, -1, 0});
+            ++cnt;
+        }
+        e.tree[(size_t)idx].n_children = cnt;
+    };
+    auto backprop = [&](Ep &e, int idx, float v) {                         // search.rs:45-53
+        while (idx >= 0) { HostNode &n = e.tree[(size_t)idx]; n.value_sum = n.value_sum + v; n.visit += 1u; idx = n.parent; }
+    };
+    // runs episode i until it wants a network output (returns true) or is over (false)
+    auto advance = [&](uint64_t i, const float *probs_in, float value_in) -> bool {
+        Ep &e = eps[i];
+        const uint64_t eg = prm->episode_offset + i;
+        bool resume = probs_in != nullptr;
+        for (;;) {
+            if (e.phase == DONE) return false;
+            if (e.phase == NEED_ROOT) {
+                if (!resume) return true;
+                // root (search.rs:110-129): visit_count 1, expanded with the root's priors
+                e.tree.push_back(HostNode{env->clone(e.env), -1, -1, 0.0f, 1u, 0.0f, -1, 0});
+                expand(e, 0, probs_in);
+                e.it = 0; resume = false; e.phase = NEED_LEAF; e.node = -1;
+                continue;
+            } else if (resume) {
+                // the leaf's output (search.rs:154-159): expand, sample a child by the priors, the value is the network's
+                resume = false;
+                expand(e, e.node, probs_in);
+                const HostNode &nd = e.tree[(size_t)e.node];
+                if (nd.n_children > 0) {                                   // (the reference panics on a node without children here)
+                    std::vector<float> pri((size_t)nd.n_children);
+                    for (int c = 0; c < nd.n_children; ++c) pri[(size_t)c] = e.tree[(size_t)(nd.first_child + c)].prior;
+                    const u32x4 w = rng_draw(prm->seed, eg, e.it * MED + e.expanded, (uint32_t)STREAM_MCTS | (e.t << 8));
+                    e.node = nd.first_child + sample_weighted_host(pri.data(), nd.n_children, u32_to_unit(w.x));
+                }
+                e.value = value_in;
+                ++e.expanded;
+            } else if (e.node < 0) {
+                // a new search, or the move is over
+                if (e.it == S) {
+                    // visit counts -> probs (search.rs:166-188); az.rs:72-81: sample the action, store the record
+                    std::vector<float> mp(A, 0.0f);
+                    const HostNode &root = e.tree[0];
+                    for (int c = 0; c < root.n_children; ++c) { const HostNode &ch = e.tree[(size_t)(root.first_child + c)]; mp[(size_t)ch.action] = (float)ch.visit; }
+                    float sum = 0.0f;
+                    for (uint32_t a = 0; a < A; ++a) sum = sum + mp[a];
+                    if (sum > 0.0f) { for (uint32_t a = 0; a < A; ++a) mp[a] = mp[a] / sum; }
+                    else { for (uint32_t a = 0; a < A; ++a) mp[a] = 1.0f / (float)A; }
+                    const u32x4 w = rng_draw(prm->seed, eg, e.t, STREAM_AZ_ACT);
+                    const int action = sample_weighted_host(mp.data(), (int)A, u32_to_unit(w.x));
+                    std::vector<int32_t> ob(NO);
+                    env->observe(e.env, ob.data());
+                    e.obs.insert(e.obs.end(), ob.begin(), ob.end());
+                    e.probs.insert(e.probs.end(), mp.begin(), mp.end());
+                    e.vals.push_back(env->reward(e.env));
+                    free_tree(e);
+                    if (env->is_final(e.env)) { e.phase = DONE; return false; }        // az.rs:84
+                    if (e.t + 1 >= max_records_per_episode) { e.phase = DONE; return false; }   // (reported by the caller below)
+                    env->step(e.env, (uint32_t)action);                                 // az.rs:89
+                    ++e.t;
+                    e.phase = NEED_ROOT;
+                    continue;
+                }
+                // descend by UCB (search.rs:133-138, next :77-91, ucb :29-39)
+                int idx = 0;
+                while (e.tree[(size_t)idx].n_children > 0) {
+                    const HostNode &par = e.tree[(size_t)idx];
+                    int best = -1; float best_ucb = -__builtin_inff();
+                    const float sq = sqrtf((float)par.visit);
+                    for (int c = 0; c < par.n_children; ++c) {
+                        const HostNode &ch = e.tree[(size_t)(par.first_child + c)];
+                        const float q = ch.visit == 0u ? 0.0f : ch.value_sum / (float)ch.visit;
+                        float d = sq / ((float)ch.visit + 1.0f);
+                        d = prm->C * d;
+                        d = d * ch.prior;
+                        const float ucb = q + d;
+                        if (ucb > best_ucb) { best = par.first_child + c; best_ucb = ucb; }
+                    }
+                    if (best < 0) break;                                   // all-NaN UCB: the reference panics here
+                    idx = best;
+                }
+                e.node = idx; e.value = 0.0f; e.expanded = 0;
+            }
+            // leaf phase (search.rs:143-160)
+            bool need = false;
+            while (e.expanded < MED) {
+                void *st = e.tree[(size_t)e.node].state;
+                e.value = env->reward(st);
+                if (env->is_final(st)) break;
+                need = true; break;
+            }
+            if (need) return true;
+            backprop(e, e.node, e.value);                                   // search.rs:163
+            ++e.it; e.node = -1;
+        }
+    };
+
+    std::vector<bool> started(E, false);
+    for (;;) {
+        want.clear();
+        for (uint64_t i = 0; i < E; ++i) {
+            if (eps[i].phase == DONE) continue;
+            if (!started[i]) { started[i] = true; if (advance(i, nullptr, 0.0f)) want.push_back(i); }
+            else want.push_back(i);                                         // (left waiting by the previous round)
+        }
+        if (want.empty()) break;
+        const uint32_t n = (uint32_t)want.size();
+        for (uint32_t r = 0; r < n; ++r) {
+            Ep &e = eps[want[r]];
+            void *st = e.phase == NEED_ROOT ? e.env : e.tree[(size_t)e.node].state;
+            env->observe(st, &h_obs[(size_t)r * NO]);
+            for (uint32_t c = 0; c < NO; ++c) {
+                const int32_t id = h_obs[(size_t)r * NO + c];
+                if (id < 0 || id >= pd->obs_size) { cleanup(); (void)hipFree(dev); set_error("index out of bounds: obs id %d, obs_size %d", id, pd->obs_size); return TW_ERR_INVALID; }
+            }
+            env->masks(st, &h_m[(size_t)r * A]);
+        }
+        TW_HIP_E(hipMemcpyAsync(dev + o_obs, h_obs.data(), (size_t)n * NO * 4, hipMemcpyHostToDevice, s));
+        TW_HIP_E(hipMemcpyAsync(dev + o_m, h_m.data(), (size_t)n * A, hipMemcpyHostToDevice, s));
+        rc = launch_policy_eval(*pd, TW_EVAL_FULL_PREDICT, reinterpret_cast<const int32_t *>(dev + o_obs), n, NO, dev + o_m, nullptr,
+                                reinterpret_cast<float *>(dev + o_la), reinterpret_cast<float *>(dev + o_v), s);
+        if (rc) { cleanup(); (void)hipFree(dev); return rc; }
+        TW_HIP_E(hipMemcpyAsync(h_la.data(), dev + o_la, (size_t)n * A * 4, hipMemcpyDeviceToHost, s));
+        TW_HIP_E(hipMemcpyAsync(h_v.data(), dev + o_v, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        TW_HIP_E(hipStreamSynchronize(s));
+        for (uint32_t r = 0; r < n; ++r) (void)advance(want[r], &h_la[(size_t)r * A], h_v[r]);
+        for (uint32_t r = 0; r < n; ++r) {
+            const Ep &e = eps[want[r]];
+            if (e.phase == DONE && !env->is_final(e.env)) {
+                cleanup(); (void)hipFree(dev);
+                set_error("tw_az_collect_env: an episode did not end within %u records", max_records_per_episode); return TW_ERR_INVALID;
+            }
+        }
+    }
+#undef TW_HIP_E
+    (void)hipFree(dev);
+
+    // ---- remaining values (az.rs:94-95) + merge (collector.rs:40-46) --------------------------------------------------
+    uint64_t total = 0;
+    for (auto &e : eps) total += e.vals.size();
+    std::vector<uint64_t> order(E);
+    for (uint64_t p = 0; p < E; ++p) order[p] = prm->merge_order ? (p == 0 ? E - 1 : p - 1) : p;
+    std::vector<uint8_t> f_obs((size_t)total * NO * OW); std::vector<int8_t> f_perm(total, (int8_t)-1);
+    std::vector<float> f_lg((size_t)total * A), f_rem(total);
+    std::vector<uint32_t> f_len(E); std::vector<uint64_t> f_start(E);
+    uint64_t pos = 0;
+    for (uint64_t p = 0; p < E; ++p) {
+        const Ep &e = eps[order[p]];
+        const size_t nrec = e.vals.size();
+        f_len[order[p]] = (uint32_t)nrec; f_start[order[p]] = pos;
+        float total_val = 0.0f;
+        std::vector<float> before(nrec);
+        for (size_t tt = 0; tt < nrec; ++tt) { before[tt] = total_val; total_val = total_val + e.vals[tt]; }
+        for (size_t tt = 0; tt < nrec; ++tt) {
+            for (uint32_t c = 0; c < NO; ++c) {
+                const int32_t id = e.obs[tt * NO + c];
+                if (OW == 1) f_obs[(pos + tt) * NO + c] = (uint8_t)id;
+                else { const uint16_t v = (uint16_t)id; memcpy(&f_obs[((pos + tt) * NO + c) * 2], &v, 2); }
+            }
+            memcpy(&f_lg[(pos + tt) * A], &e.probs[tt * A], A * 4);
+            f_rem[pos + tt] = total_val - before[tt];
+        }
+        pos += nrec;
+    }
+    cleanup();
+    size_t cur = 0, off[TW_F_COUNT] = {}, bytes[TW_F_COUNT] = {};
+    const void *src[TW_F_COUNT] = {};
+    auto put = [&](int f, const void *p, size_t b) { src[f] = p; bytes[f] = b; off[f] = cur; cur = (cur + b + 255) / 256 * 256; };
+    put(TW_F_OBS, f_obs.data(), f_obs.size()); put(TW_F_LOGITS, f_lg.data(), f_lg.size() * 4); put(TW_F_PERMS, f_perm.data(), f_perm.size());
+    put(TW_F_REMAINING, f_rem.data(), total * 4); put(TW_F_EP_LEN, f_len.data(), E * 4); put(TW_F_EP_START, f_start.data(), E * 8);
+    void *arena = nullptr;
+    TW_HIP(hipMalloc(&arena, cur ? cur : 256));
+    void *fp[TW_F_COUNT] = {};
+    for (int f = 0; f < TW_F_COUNT; ++f) if (bytes[f]) {
+        fp[f] = reinterpret_cast<uint8_t *>(arena) + off[f];
+        he = hipMemcpyAsync(fp[f], src[f], bytes[f], hipMemcpyHostToDevice, s);
+        if (he != hipSuccess) { (void)hipFree(arena); return hip_fail(he, "upload of the collected fields", __FILE__, __LINE__); }
+    }
+    he = hipStreamSynchronize(s);
+    if (he != hipSuccess) { (void)hipFree(arena); return hip_fail(he, "upload of the collected fields", __FILE__, __LINE__); }
+    int dev_id = 0; (void)hipGetDevice(&dev_id);
+    rc = collected_adopt(arena, cur ? cur : 256, dev_id, 0, NO, A, total, E, fp, bytes, out);
+    if (rc) { (void)hipFree(arena); return rc; }
+    collected_adopt_obs_width(*out, OW);
+    return TW_OK;
+}
