@@ -442,6 +442,8 @@ def _assert_same_az(g, o, n_cells):
     (3, 3, 2, 32, 128, 1500, 6, 1, False),   #   more episodes than walkers: the episode queue, arenas reused
     (3, 3, 0, 32, 128, 10, 5, 1, False),     #   difficulty 0: every root is final
     (3, 3, 4, 32, 256, 16, 0, 1, False),     #   zero searches
+    (3, 3, 3, 32, 128, 400, 10, 1, False),   #   two walkers per workgroup (between one and two episodes per CU), 8 columns each
+    (3, 3, 4, 64, 256, 700, 8, 1, True),     #   four walkers per workgroup, 4 columns each
 ])
 def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
     n2 = w * h

@@ -38,7 +38,7 @@ static_assert(sizeof(DeepNode) == 64, "DeepNode must be 64 bytes");
 size_t mcts_deep_node_bytes() { return sizeof(DeepNode); }
 
 constexpr uint32_t DNONE = 0xffffffffu;
-constexpr int DEEP_WALKERS = 4;          // walkers (= waves) per workgroup
+constexpr int DEEP_WAVES = 4;            // waves per workgroup; the first NWK (4, 2 or 1) are walkers, all four run the forward
 constexpr int DEEP_POOL = 40;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
 constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
@@ -55,16 +55,16 @@ __device__ __forceinline__ uint32_t lk_nch(uint32_t link) { return (link >> 24) 
 __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >> 27) & 3u); }
 
 // floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | pool idx [POOL] | pool outputs [POOL][8]
-__host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes)
+__host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers)
 {
-    return (size_t)columns * 10 + (size_t)DEEP_WALKERS * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);
+    return (size_t)columns * 10 + (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);
 }
 
 #ifdef TW_ABLATE
 __device__ unsigned long long g_deep_stamps[16];
 #endif
 
-template <int NT, int NC, int NW>
+template <int NT, int NC, int NW, int NWK>
 __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
 {
     using Eng = typename Geom<NT, NC, 0, NW>::Eng;
@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     typedef __attribute__((address_space(3))) ux2 lds_u2;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     typedef __attribute__((address_space(3))) float lds_f32;
-    constexpr int C = Eng::EPB, CPW = C / DEEP_WALKERS;    // MFMA columns of the workgroup, columns per walker
-    static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WALKERS && CPW >= 2, "one walker per wave");
+    constexpr int C = Eng::EPB, CPW = C / NWK;             // MFMA columns of the workgroup, columns per walker
+    static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WAVES && NWK >= 1 && NWK <= DEEP_WAVES && CPW >= 2 && CPW <= 64, "one walker per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -87,14 +87,15 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     float *xbase = lds + Eng::lds_floats(a.pol.obs_size);
     uint2 *req = reinterpret_cast<uint2 *>(xbase);                               // request boards [C]
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
-    float *wbase = res + 8 * C + (size_t)wave * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
+    const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
+    float *wbase = res + 8 * C + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
     lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 4);                         // pool: node index (DNONE = free)
     lds_f32 *pout = (lds_f32 *)(wbase + (size_t)NL * 4 + DEEP_POOL);             // pool: probs[4], value, - - -
 
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     const uint64_t E = a.num_episodes;
-    const uint64_t slot = (uint64_t)blockIdx.x * DEEP_WALKERS + (uint64_t)wave;        // walker = tree arena index
+    const uint64_t slot = (uint64_t)blockIdx.x * NWK + (uint64_t)(walker ? wave : 0);     // walker = tree arena index
     DeepNode *nodes = reinterpret_cast<DeepNode *>(a.arena) + slot * (uint64_t)a.node_cap;
 
     // hot quad of node idx: LDS for the first NL nodes of the tree, the arena beyond
@@ -140,8 +141,9 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
         t = 0; phase = DP_ROOT;
     };
-    if (slot < E) take(slot);
-    if (lane < DEEP_POOL) pidx[lane] = DNONE;
+    if (walker && slot < E) take(slot);
+    if (walker && lane < DEEP_POOL) pidx[lane] = DNONE;
+    if (!walker) more = false;
 
     uint32_t obs_base[4];
     obs_base_words(env.n_cells, obs_base);
@@ -154,6 +156,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     // request columns of this walker for the next forward: the demand + up to CPW-1 unevaluated frontier nodes in creation order
     auto assemble = [&]() {
         my_take = false; n_spec = 0;
+        if (!walker) return;
         const uint64_t ident = env.ident;
         if (phase == DP_DEAD) {
             if (lane < CPW) req[wave * CPW + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
@@ -541,35 +544,47 @@ bool mcts_deep_applies(const MctsArgs &a)
     return a.num_episodes <= (uint64_t)device_cus() * 16u;
 }
 
+// walkers per workgroup: as few as keep every CU busy -- with fewer walkers each one owns more of the forward's columns (4 / 8 /
+// 16 of 16), i.e. more of its tree is evaluated ahead of the search and fewer searches wait for a forward (misses of a demand:
+// 48 % with three columns of look-ahead, about half of that with seven); the reference's default self-play batch is 512 episodes
+static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus)
+{
+    const int cus = device_cus();
+    const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
+    const uint64_t avail = (uint64_t)(cus - r);
+    return num_episodes <= avail ? 1 : (num_episodes <= 2 * avail ? 2 : 4);
+}
+
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus)
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
-    const uint64_t blocks = (num_episodes + DEEP_WALKERS - 1) / DEEP_WALKERS;
-    return (blocks < (uint64_t)(cus - r) ? blocks : (uint64_t)(cus - r)) * DEEP_WALKERS;
+    const uint64_t nwk = (uint64_t)deep_walkers_per_group(num_episodes, reserve_cus);
+    const uint64_t blocks = (num_episodes + nwk - 1) / nwk;
+    return (blocks < (uint64_t)(cus - r) ? blocks : (uint64_t)(cus - r)) * nwk;
 }
 
-template <int NT, int NC, int NW>
-static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+template <int NT, int NC, int NW, int NWK>
+static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     using G = Geom<NT, NC, 0, NW>;
     constexpr int C = G::Eng::EPB;
-    const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus) / DEEP_WALKERS;
+    const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus) / NWK;
     // the hot quads of the first lds_nodes nodes of every tree live in LDS: as many as fit beside the engine
     MctsArgs b = a;
     const size_t eng_floats = G::Eng::lds_floats(a.pol.obs_size);
     const size_t budget = (size_t)159 * 1024 / sizeof(float);
-    if (eng_floats + deep_extra_floats(C, 0) > budget) { set_error("mcts (deep): the policy engine alone needs %zu bytes of LDS", eng_floats * 4); return TW_ERR_UNSUPPORTED; }
-    size_t nl = (budget - eng_floats - deep_extra_floats(C, 0)) / ((size_t)DEEP_WALKERS * 4);
+    if (eng_floats + deep_extra_floats(C, 0, NWK) > budget) { set_error("mcts (deep): the policy engine alone needs %zu bytes of LDS", eng_floats * 4); return TW_ERR_UNSUPPORTED; }
+    size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK)) / ((size_t)NWK * 4);
     if (nl > a.node_cap) nl = a.node_cap;
     b.lds_nodes = (uint32_t)nl;
-    const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes)) * sizeof(float);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW>), lds_bytes)) return rc;
+    const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK)) * sizeof(float);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
     unsigned long long zeros[16] = {0};
     if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros)));
 #endif
-    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(256), lds_bytes, s, b);
+    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK>), dim3((unsigned)nb), dim3(256), lds_bytes, s, b);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
@@ -588,6 +603,16 @@ static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
     if (blocks) *blocks = (uint32_t)nb;
     if (threads) *threads = 256;
     return TW_OK;
+}
+
+template <int NT, int NC, int NW>
+static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    switch (deep_walkers_per_group(a.num_episodes, a.reserve_cus)) {
+        case 1: return launch_deep_nwk<NT, NC, NW, 1>(a, s, blocks, threads);
+        case 2: return launch_deep_nwk<NT, NC, NW, 2>(a, s, blocks, threads);
+        default: return launch_deep_nwk<NT, NC, NW, 4>(a, s, blocks, threads);
+    }
 }
 
 template <int NT>
