@@ -450,13 +450,23 @@ constexpr int R3S_XCHG = 256 + 1024, R3S_USER = 256;   // floats: head hand-off 
 template <int NT, int NC, int NS>
 struct Engine3S : Engine3<NT, NC, 0, NS> {
     using B = Engine3<NT, NC, 0, NS>;
-    static constexpr int EPB = EPW, NTL = NT / NS, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, NOPS = B::NOPS;
+    static constexpr int EPB = EPW, NTL = NT / NS, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT;
+    static constexpr int WOPS = B::WPIECE / NS, TOPS = (B::TPIECE + NS - 1) / NS, NOPS = WOPS + TOPS;   // DMA ops per wave and chunk: W1 pieces, table pieces
     static constexpr bool SPLIT = true;
     static_assert(NT % NS == 0 && (NTL == 1 || NTL == 2), "Engine3S: one or two row tiles per wave");
 
     float *lds_x, *lds_user;
+    // The same instruction diet as the 16-column shape (a lone wave per SIMD is bound by its instruction count):
+    // ring positions are compile-time facts -- a forward always starts in slot 0, its chunk sequence padded to a multiple of three
+    // steps with "bubble" steps that only stream -- so the slot offsets of all LDS reads are immediates, the gather keeps one LDS
+    // address per row for the whole forward, a stream op is `s_add_u32 m0, piece, literal` + the DMA instruction with a per-op
+    // lane offset in a VGPR and a running source pointer, and the accumulators are pinned to VGPRs (inline-asm MFMA: with the
+    // intrinsic the allocator copied the 32 loop-carried accumulator registers into AGPRs every chunk).
+    const uint8_t *swp, *stp;
+    int sv, n3;                            // virtual step whose data is streamed next (sv == step + 2); steps per forward (multiple of 3)
+    uint32_t voffW[WOPS], voffT[TOPS], mT[TOPS];
 #ifdef TW_ABLATE
-    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk compute | vmcnt wait | barrier wait | heads | -
+    unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};   // prologue | chunk loop | - | - | heads | -
 #define TW_S3(var) const unsigned long long var = __builtin_readcyclecounter()
 #define TW_A3(i, a, b) stq[i] += (b) - (a)
 #else
@@ -473,14 +483,51 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
 
     __device__ __forceinline__ void begin1(const PolicyDev &p, float *lds)
     {
-        B::begin1(p, lds);
+        B::begin1(p, lds);                 // (streams chunks 0 and 1 into slots 0 and 1)
         lds_x = lds + engine3_lds_floats<NT>(p.obs_size);
         lds_user = lds_x + R3S_XCHG;
+        n3 = (this->n_chunks + 2) / 3 * 3;
+        sv = 2;
+        {
+            const int first = 2 < this->n_chunks ? 2 : 0;                        // a bubble step gets chunk 0's data (never read)
+            swp = this->dsrc_w + (size_t)first * (WSLOT * 4);
+            stp = this->dsrc_t + (size_t)first * (R3_TSLOT * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < WOPS; ++k) voffW[k] = this->voff + (uint32_t)k * (NS * 1024u);     // piece wave + NS*k (dsrc_w / ddst_w carry the wave)
+#pragma unroll
+        for (int k = 0; k < TOPS; ++k) {
+            int tp = this->wave + NS * k;
+            tp = tp < B::TPIECE ? tp : B::TPIECE - 1;                                           // past the end: repeat the last piece
+            mT[k] = this->ddst_t + (uint32_t)tp * 1024u;
+            voffT[k] = this->voff + (uint32_t)tp * 1024u;
+        }
+    }
+
+    template <int S, int OP>   // DMA op OP of this wave: a piece of the chunk streamed next into ring slot S
+    __device__ __forceinline__ void stream() const
+    {
+        if constexpr (OP < WOPS)
+            asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                         :: "v"(voffW[OP]), "s"(this->ddst_w), "i"(S * WSLOT * 4 + OP * NS * 1024), "s"(swp) : "memory", "m0", "scc");
+        else
+            asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                         :: "v"(voffT[OP - WOPS]), "s"(mT[OP - WOPS]), "i"(S * R3_TSLOT * 4), "s"(stp) : "memory", "m0", "scc");
+    }
+    // the DMA ops of MFMA slot m of M: ops [m*NOPS/M, (m+1)*NOPS/M) of this wave, into ring slot S
+    template <int S, int OP = 0>
+    __device__ __forceinline__ void ops_of_slot(int m, int M) const
+    {
+        if constexpr (OP < NOPS) {
+            if (OP >= m * NOPS / M && OP < (m + 1) * NOPS / M) stream<S, OP>();     // (m is a constant after unrolling)
+            ops_of_slot<S, OP + 1>(m, M);
+        }
     }
 
     __device__ __forceinline__ void forward(const int (&rowoff)[NC], float (&lg)[4], float &value)
     {
         typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+        typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
         const int j = this->j, h = this->h, wave = this->wave;
         f32x16 acc[NTL];
 #pragma unroll
@@ -489,27 +536,19 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
             for (int g = 0; g < 16; ++g) acc[r][g] = 0.0f;
 
         const int t0    = wave * NTL;                                           // first row tile of this wave
-        const int a_off = ((h * NQ + (t0 >> 2)) * 32 + j) * 4 + (t0 & 3);       // float offset of its A operands in a k-step block
-        lds_cfloat *ga[NC + 1];
+        lds_cfloat *abase = (lds_cfloat *)this->lds_w + ((h * NQ + (t0 >> 2)) * 32 + j) * 4 + (t0 & 3);   // + slot, + ks * 2*NQ*128 for k-step ks
+        // one LDS address per row for the whole forward: the ring slot is an immediate offset of the read
         constexpr int GW = 8 / NS;                                              // k-steps of a chunk this wave gathers
-        ga[0] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT + this->bias_row * R3_LSTR + h * (KC / 2)) + GW * wave;
+        lds_cfloat *ga[NC + 1];
+        ga[0] = (lds_cfloat *)this->lds_t + this->bias_row * R3_LSTR + h * (KC / 2) + GW * wave;
 #pragma unroll
-        for (int q = 0; q < NC; ++q) ga[q + 1] = (lds_cfloat *)(this->lds_t + this->rp * R3_TSLOT) + rowoff[q] + GW * wave;
+        for (int q = 0; q < NC; ++q) ga[q + 1] = (lds_cfloat *)this->lds_t + rowoff[q] + GW * wave;
 
-        // this wave's share (8/NS k-steps) of the B operands of the chunk the gather pointers point at: all LDS reads are
-        // issued first (gather_issue), the sums and the publication into exchange buffer `buf` follow the chunk's MFMAs
+        // this wave's share (8/NS k-steps) of the B operands of a chunk: the LDS reads are spread over the MFMA slots, the sums
+        // and the publication into exchange buffer `buf` follow the chunk's MFMAs
         float *xb = lds_x + 256;
-        typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
         f32x2 gr2[NS == 4 ? NC + 1 : 1];
         f32x4 gr4[NS == 4 ? 1 : NC + 1];
-        auto gather_read = [&](int q) {
-            if constexpr (NS == 4) gr2[q] = *reinterpret_cast<lds_cf2 *>(ga[q]);
-            else gr4[q] = *reinterpret_cast<lds_cf4 *>(ga[q]);
-        };
-        auto gather_issue = [&]() {
-#pragma unroll
-            for (int q = 0; q <= NC; ++q) gather_read(q);
-        };
         auto gather_finish = [&](int buf) {
             if constexpr (NS == 4) {
                 f32x2 sm = gr2[0];                                                 // bias row, then the cells in order
@@ -530,75 +569,76 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
                 *reinterpret_cast<f32x4 *>(xb + ((buf * 2 + wave) * 64 + this->lane) * 4) = b;
             }
         };
-        auto advance = [&](int from, int to) {
-            const int delta = (to - from) * R3_TSLOT;
-#pragma unroll
-            for (int q = 0; q <= NC; ++q) ga[q] += delta;
+        auto read_a = [&](lds_cfloat *ap, float (&a)[NTL]) {
+            if constexpr (NTL == 2) { const f32x2 a2 = *reinterpret_cast<lds_cf2 *>(ap); a[0] = a2[0]; a[1] = a2[1]; }
+            else a[0] = *ap;
         };
 
-        int s0 = this->rp;
         float aw[NTL];
-        {
-            lds_cfloat *ap = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
-            if constexpr (NTL == 2) {
-                const f32x2 a2 = *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(ap);
-                aw[0] = a2[0]; aw[1] = a2[1];
-            } else aw[0] = *ap;
-        }
+        int par = 0;                                                            // B-operand buffer of the current chunk
+        auto stream_advance = [&]() {
+            ++sv; swp += WSLOT * 4; stp += R3_TSLOT * 4;
+            if (sv == this->n_chunks || sv == n3) { swp = this->dsrc_w; stp = this->dsrc_t; }
+            if (sv == n3) sv = 0;
+        };
+        // One step with the ring slots as compile-time facts (S0: this chunk, S1: the next one -- complete, S2: streamed now)
+        auto step = [&](auto s0c, int c) {
+            constexpr int S0 = decltype(s0c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
+            constexpr int M = 8 * NTL;
+            if (c < this->n_chunks) {
+                f32x4 bg[2];
+                bg[0] = *reinterpret_cast<const f32x4 *>(xb + ((par * 2 + 0) * 64 + this->lane) * 4);
+                bg[1] = *reinterpret_cast<const f32x4 *>(xb + ((par * 2 + 1) * 64 + this->lane) * 4);
+                // 8*NTL MFMAs; in the shadow of each: its share of the DMA ops of step c+2, of the gather reads of step c+1 (which
+                // sits complete in slot S1; after the last chunk that is a bubble or chunk 0 of the next forward, gathered with the
+                // rows of this one -- never consumed, the next prologue rewrites exchange buffer 0) and the next A operands
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const int ks = m / NTL, r = m % NTL;
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[r]) : "v"(aw[r]), "v"(bg[ks >> 2][ks & 3]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    ops_of_slot<S2>(m, M);
+#pragma unroll
+                    for (int q = m * (NC + 1) / M; q < (m + 1) * (NC + 1) / M; ++q) {
+                        if constexpr (NS == 4) gr2[q] = *reinterpret_cast<lds_cf2 *>(ga[q] + S1 * R3_TSLOT);
+                        else gr4[q] = *reinterpret_cast<lds_cf4 *>(ga[q] + S1 * R3_TSLOT);
+                    }
+                    if (r == NTL - 1) {
+                        if (ks < 7) read_a(abase + S0 * WSLOT + (ks + 1) * 2 * NQ * 128, aw); else read_a(abase + S1 * WSLOT, aw);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                gather_finish(par ^ 1);
+                par ^= 1;
+            } else {                                                            // bubble: only the streams
+                ops_of_slot<S2>(0, 1);
+            }
+            stream_advance();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of step c+2 have landed
+            __syncthreads();
+        };
+
         TW_S3(q_in);
         {
-            const int s1 = s0 == 2 ? 0 : s0 + 1;
-            gather_issue();
+            read_a(abase, aw);                                                  // slot 0
+#pragma unroll
+            for (int q = 0; q <= NC; ++q) {
+                if constexpr (NS == 4) gr2[q] = *reinterpret_cast<lds_cf2 *>(ga[q]);
+                else gr4[q] = *reinterpret_cast<lds_cf4 *>(ga[q]);
+            }
             gather_finish(0);
-            advance(s0, s1);
             __syncthreads();
         }
         TW_S3(q_pro);
         TW_A3(0, q_in, q_pro);
-        for (int c = 0; c < this->n_chunks; ++c) {
-            const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-            int sc = c + 2; if (sc >= this->n_chunks) sc -= this->n_chunks;     // chunk streamed now (wraps into the next forward)
-            if (this->n_chunks == 1) sc = 0;
-            TW_S3(q_c0);
-            f32x4 bg[2];
-            bg[0] = *reinterpret_cast<const f32x4 *>(xb + (((c & 1) * 2 + 0) * 64 + this->lane) * 4);
-            bg[1] = *reinterpret_cast<const f32x4 *>(xb + (((c & 1) * 2 + 1) * 64 + this->lane) * 4);
-            lds_cfloat *wb = (lds_cfloat *)(this->lds_w + s0 * WSLOT + a_off);
-            lds_cfloat *wn = (lds_cfloat *)(this->lds_w + s1 * WSLOT + a_off);
-            // 8*NTL MFMAs; in the shadow of each: its share of the DMA ops of chunk c+2 (scalar work), of the gather reads of
-            // chunk c+1 (which sits complete in slot s1; after the last chunk that is chunk 0 of the next forward, gathered with
-            // the rows of this one -- never consumed, the next prologue rewrites exchange buffer 0) and the next A operands
-            constexpr int M = 8 * NTL;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const int ks = m / NTL, r = m % NTL;
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[r], bg[ks >> 2][ks & 3], acc[r], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int op = m * NOPS / M; op < (m + 1) * NOPS / M; ++op) this->stream_op(sc, s2, op);
-#pragma unroll
-                for (int q = m * (NC + 1) / M; q < (m + 1) * (NC + 1) / M; ++q) gather_read(q);
-                if (r == NTL - 1) {
-                    lds_cfloat *ap = ks < 7 ? wb + (ks + 1) * 2 * NQ * 128 : wn;
-                    if constexpr (NTL == 2) {
-                        const f32x2 a2 = *reinterpret_cast<const __attribute__((address_space(3))) f32x2 *>(ap);
-                        aw[0] = a2[0]; aw[1] = a2[1];
-                    } else aw[0] = *ap;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            gather_finish((c + 1) & 1);
-            advance(s1, s2);
-            TW_S3(q_c1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c+2 have landed
-            TW_S3(q_c2);
-            __syncthreads();
-            TW_S3(q_c3);
-            TW_A3(1, q_c0, q_c1); TW_A3(2, q_c1, q_c2); TW_A3(3, q_c2, q_c3);
-            s0 = s1;
+        for (int c = 0; c < n3; c += 3) {
+            step(std::integral_constant<int, 0>{}, c);
+            step(std::integral_constant<int, 1>{}, c + 1);
+            step(std::integral_constant<int, 2>{}, c + 2);
         }
-        this->rp = s0;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> vector ALU: the wait states the compiler would count for the intrinsic
+        TW_S3(q_lp);
+        TW_A3(1, q_pro, q_lp);
 
         // heads.  The k-ordered chain over the hidden units is serial, and as a chain of dependent 32x32x2 MFMAs it costs
         // 64 cycles per two units.  Here instead: every wave writes its ReLU'd hidden units into the ring slot the last chunk
@@ -606,7 +646,7 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
         // output hw (4 logits, value) for its 32 episodes as 4-cycle v_fma_f32 steps -- the same fma chain, bit for bit.
         TW_S3(q_h0);
         {
-            const int fs = s0 == 0 ? 2 : s0 - 1;                                 // the slot of the chunk consumed last
+            constexpr int fs = 2;                                                // the last step's slot: free until step 0 of the next forward streams into it
             float *hid_lo = this->lds_t + fs * R3_TSLOT, *hid_hi = this->lds_w + fs * WSLOT;
             lds_cfloat *b1_lane = (lds_cfloat *)(this->lds_b1 + h * (NT * 16)) + 16 * t0;
 #pragma unroll
