@@ -126,7 +126,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 struct PooledArena { void *ptr; size_t cap; int device; };
 static std::mutex g_pool_mutex;
 static std::vector<PooledArena> g_pool;
-constexpr size_t POOL_ENTRIES = 4;
+constexpr size_t POOL_ENTRIES = 16;     // (a pipelined multi-GPU step keeps one arena per pipeline step alive until its gather is done)
 
 static void pool_drop()
 {
