@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 2
+#define TW_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -218,6 +218,7 @@ typedef struct {
     void   (*masks)(void *env, uint8_t *out /* num_actions, 0/1 */);
     float  (*reward)(void *env);
     int    (*is_final)(void *env);
+    int    (*success)(void *env);         /* Env::success; only tw_evaluate_env / tw_solve_env call it (may be NULL for the collectors) */
 } tw_env_vtable;
 
 /* solve / evaluate (rust/src/rl/solve.rs:73-101, rust/src/rl/evaluate.rs:22-89; PyO3 functions
@@ -256,6 +257,14 @@ int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, const tw_sol
  * actions_out (capacity actions_cap, may be NULL) receives the best attempt's actions. */
 int tw_solve(const tw_puzzle *env, const tw_policy *policy, const tw_solve_params *params,
              float *success, float *reward, uint8_t *actions_out, uint32_t actions_cap, uint32_t *n_actions);
+/* evaluate() / solve() for any environment (rust/src/rl/evaluate.rs:22-89, rust/src/rl/solve.rs:17-101): the environment (and,
+ * with num_mcts_searches > 0, the search trees) on the host, the policy outputs of all attempts of a moment in one batched
+ * launch.  tw_evaluate_env resets a clone of the prototype per episode; tw_solve_env starts every attempt from a clone of the
+ * prototype AS IT IS.  An attempt that has not ended after max_steps steps is an error. */
+int tw_evaluate_env(const tw_env_vtable *env, const tw_policy *policy, const tw_solve_params *params, uint64_t num_episodes,
+                    uint64_t episode_offset, uint32_t max_steps, float *success_rate, float *mean_reward);
+int tw_solve_env(const tw_env_vtable *env, const tw_policy *policy, const tw_solve_params *params, uint32_t max_steps,
+                 float *success, float *reward, uint8_t *actions_out, uint32_t actions_cap, uint32_t *n_actions);
 
 /* Fields of the result (device-resident, compact, in the order params.merge_order asked for) */
 enum {

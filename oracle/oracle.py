@@ -510,6 +510,124 @@ def ppo_collect_env(proto, policy: Policy, num_episodes, gamma, lam, seed=0, epi
                      np.asarray([len(e[3]) for e in eps], dtype=np.uint32))
 
 
+def mcts_probs_env(env, policy: Policy, num_mcts_searches, C_, max_expand_depth, seed, key, t, arith=ARITH_CHAIN):
+    """predict_probs_mcts (rust/src/rl/search.rs:104-189) over an environment object with the reference's Python env protocol:
+    root full_predict, expand (a child per action with prior > 0: copy + next), `num_mcts_searches` times: descend by UCB
+    (:29-39, first maximum), up to `max_expand_depth` times reward / is_final / full_predict / expand / next_sample,
+    backpropagate; visit counts -> probs.  next_sample's draw: stream 4 | t << 8 of (seed, key), index it * max_expand_depth +
+    expanded (the build's RNG spec).  Pure Python."""
+    f32 = np.float32
+    A = policy.n_actions
+    root_state = env.copy()
+    probs, _ = policy.full_predict([int(x) for x in root_state.observe()], [bool(m) for m in root_state.masks()], arith=arith)
+    nodes = [dict(state=root_state, parent=-1, action=-1, prior=f32(0), visit=1, vsum=f32(0), children=[])]
+
+    def expand(idx, pri):
+        for a in range(A):
+            if not (pri[a] > 0):
+                continue
+            st = nodes[idx]["state"].copy()
+            st.next(a)
+            nodes.append(dict(state=st, parent=idx, action=a, prior=f32(pri[a]), visit=0, vsum=f32(0), children=[]))
+            nodes[idx]["children"].append(len(nodes) - 1)
+    expand(0, probs)
+    for it in range(num_mcts_searches):
+        idx = 0
+        while nodes[idx]["children"]:
+            par, best, best_ucb = nodes[idx], None, f32(-np.inf)
+            for c in par["children"]:
+                ch = nodes[c]
+                q = f32(0) if ch["visit"] == 0 else f32(ch["vsum"] / f32(ch["visit"]))
+                d = f32(np.sqrt(f32(par["visit"])) / f32(f32(ch["visit"]) + f32(1)))
+                d = f32(f32(C_) * d)
+                d = f32(d * ch["prior"])
+                ucb = f32(q + d)
+                if ucb > best_ucb:
+                    best, best_ucb = c, ucb
+            idx = best
+        value, expanded = f32(0), 0
+        while expanded < max_expand_depth:
+            st = nodes[idx]["state"]
+            value = f32(st.value())
+            if st.is_final():
+                break
+            pr, nv = policy.full_predict([int(x) for x in st.observe()], [bool(m) for m in st.masks()], arith=arith)
+            expand(idx, pr)
+            ch = nodes[idx]["children"]
+            w = philox4x32_10([key & 0xFFFFFFFF, key >> 32, it * max_expand_depth + expanded, 4 | (t << 8)], [seed & 0xFFFFFFFF, seed >> 32])
+            u = float(f32(w[0] >> 8) * f32(1.0 / 16777216.0))
+            idx = ch[sample_weighted([nodes[c]["prior"] for c in ch], u)]
+            value = f32(nv)
+            expanded += 1
+        j = idx
+        while j >= 0:
+            nodes[j]["vsum"] = f32(nodes[j]["vsum"] + value)
+            nodes[j]["visit"] += 1
+            j = nodes[j]["parent"]
+    mp = np.zeros(A, dtype=np.float32)
+    for c in nodes[0]["children"]:
+        mp[nodes[c]["action"]] = f32(nodes[c]["visit"])
+    sm = f32(0)
+    for a in range(A):
+        sm = f32(sm + mp[a])
+    return (mp / sm).astype(np.float32) if sm > 0 else np.full(A, f32(1.0) / f32(A), dtype=np.float32)
+
+
+def solve_env(env, policy: Policy, deterministic, num_searches, num_mcts_searches=0, C_=1.41, max_expand_depth=1, seed=0, episode=0,
+              arith=ARITH_CHAIN):
+    """solve (rust/src/rl/solve.rs:73-101) over single_solve (:17-71) from the CURRENT state of `env` (not modified): best of
+    num_searches attempts by `(success, total) >` on the tuples.  Attempt k's draws are keyed episode * num_searches + k: twist of
+    Policy::predict stream 2, action sample stream 5, index = the move (the build's RNG spec).  Pure Python."""
+    f32 = np.float32
+    best = ((0.0, float("-inf")), [])
+    for k in range(num_searches):
+        e = env.copy()
+        key = episode * num_searches + k
+        total, acts, t = f32(0), [], 0
+        while not e.is_final():
+            total = f32(total + f32(e.value()))
+            if num_mcts_searches == 0:
+                perm = -1
+                if policy.n_perms > 0:
+                    w = philox4x32_10([key & 0xFFFFFFFF, key >> 32, t, 2], [seed & 0xFFFFFFFF, seed >> 32])
+                    perm = (w[0] * policy.n_perms) >> 32
+                probs = np.asarray(policy.predict([int(x) for x in e.observe()], [bool(m) for m in e.masks()], perm=perm, arith=arith)[0], dtype=np.float32)
+            else:
+                probs = mcts_probs_env(e, policy, num_mcts_searches, C_, max_expand_depth, seed, key, t, arith=arith)
+            if deterministic:
+                action, bv = 0, probs[0]
+                for i in range(1, len(probs)):
+                    if probs[i] > bv:
+                        action, bv = i, probs[i]
+            else:
+                w = philox4x32_10([key & 0xFFFFFFFF, key >> 32, t, 5], [seed & 0xFFFFFFFF, seed >> 32])
+                action = sample_weighted(probs, float(f32(w[0] >> 8) * f32(1.0 / 16777216.0)))
+            e.next(action)
+            acts.append(action)
+            t += 1
+        total = f32(total + f32(e.value()))
+        val = ((1.0 if e.success() else 0.0, float(total)), acts)
+        if val[0] > best[0]:
+            best = val
+    return best
+
+
+def evaluate_env(proto, policy: Policy, num_episodes, deterministic, num_searches, num_mcts_searches=0, C_=1.41, max_expand_depth=1, seed=0,
+                 difficulty=1, arith=ARITH_CHAIN):
+    """evaluate (rust/src/rl/evaluate.rs:22-89): per episode reset a clone, solve, accumulate successes and rewards in episode
+    order (f32), divide by the episode count.  Pure Python."""
+    f32 = np.float32
+    succ, rew = f32(0), f32(0)
+    for ep in range(num_episodes):
+        e = proto.copy()
+        if hasattr(e, "seed_episode"):
+            e.seed_episode(seed, ep)
+        e.reset(difficulty)
+        (s_, r_), _ = solve_env(e, policy, deterministic, num_searches, num_mcts_searches, C_, max_expand_depth, seed=seed, episode=ep, arith=arith)
+        succ, rew = f32(succ + f32(s_)), f32(rew + f32(r_))
+    return float(f32(succ / f32(num_episodes))), float(f32(rew / f32(num_episodes)))
+
+
 def az_collect_env(proto, policy: Policy, num_episodes, num_mcts_searches, C_, max_expand_depth, seed=0, episode_offset=0,
                    difficulty=1, arith=ARITH_CHAIN, merge_order=True) -> Collected:
     """AZCollector::collect (rust/src/collector/az.rs:51-109) with predict_probs_mcts (rust/src/rl/search.rs:104-189) over ANY
@@ -530,60 +648,7 @@ def az_collect_env(proto, policy: Policy, num_episodes, num_mcts_searches, C_, m
         obs_l, prob_l, val_l = [], [], []
         t = 0
         while True:
-            # predict_probs_mcts (search.rs:104-189)
-            root_state = env.copy()
-            probs, _ = policy.full_predict([int(x) for x in root_state.observe()], [bool(m) for m in root_state.masks()], arith=arith)
-            nodes = [dict(state=root_state, parent=-1, action=-1, prior=f32(0), visit=1, vsum=f32(0), children=[])]
-
-            def expand(idx, pri):
-                for a in range(A):
-                    if not (pri[a] > 0):
-                        continue
-                    st = nodes[idx]["state"].copy()
-                    st.next(a)
-                    nodes.append(dict(state=st, parent=idx, action=a, prior=f32(pri[a]), visit=0, vsum=f32(0), children=[]))
-                    nodes[idx]["children"].append(len(nodes) - 1)
-            expand(0, probs)
-            for it in range(num_mcts_searches):
-                idx = 0
-                while nodes[idx]["children"]:
-                    par, best, best_ucb = nodes[idx], None, f32(-np.inf)
-                    for c in par["children"]:
-                        ch = nodes[c]
-                        q = f32(0) if ch["visit"] == 0 else f32(ch["vsum"] / f32(ch["visit"]))
-                        d = f32(np.sqrt(f32(par["visit"])) / f32(f32(ch["visit"]) + f32(1)))
-                        d = f32(f32(C_) * d)
-                        d = f32(d * ch["prior"])
-                        ucb = f32(q + d)
-                        if ucb > best_ucb:
-                            best, best_ucb = c, ucb
-                    idx = best
-                value, expanded = f32(0), 0
-                while expanded < max_expand_depth:
-                    st = nodes[idx]["state"]
-                    value = f32(st.value())
-                    if st.is_final():
-                        break
-                    pr, nv = policy.full_predict([int(x) for x in st.observe()], [bool(m) for m in st.masks()], arith=arith)
-                    expand(idx, pr)
-                    ch = nodes[idx]["children"]
-                    w = philox4x32_10([ep & 0xFFFFFFFF, ep >> 32, it * max_expand_depth + expanded, 4 | (t << 8)], [seed & 0xFFFFFFFF, seed >> 32])
-                    u = float(f32(w[0] >> 8) * f32(1.0 / 16777216.0))
-                    idx = ch[sample_weighted([nodes[c]["prior"] for c in ch], u)]
-                    value = f32(nv)
-                    expanded += 1
-                j = idx
-                while j >= 0:
-                    nodes[j]["vsum"] = f32(nodes[j]["vsum"] + value)
-                    nodes[j]["visit"] += 1
-                    j = nodes[j]["parent"]
-            mp = np.zeros(A, dtype=np.float32)
-            for c in nodes[0]["children"]:
-                mp[nodes[c]["action"]] = f32(nodes[c]["visit"])
-            sm = f32(0)
-            for a in range(A):
-                sm = f32(sm + mp[a])
-            mp = (mp / sm).astype(np.float32) if sm > 0 else np.full(A, f32(1.0) / f32(A), dtype=np.float32)
+            mp = mcts_probs_env(env, policy, num_mcts_searches, C_, max_expand_depth, seed, ep, t, arith=arith)
             # az.rs:72-89
             w = philox4x32_10([ep & 0xFFFFFFFF, ep >> 32, t, 3], [seed & 0xFFFFFFFF, seed >> 32])
             action = sample_weighted(mp, float(f32(w[0] >> 8) * f32(1.0 / 16777216.0)))

@@ -266,8 +266,8 @@ def test_rccl_exchange_behind_the_c_abi_single_rank(tw, oracle):
 def test_ppo_collect_of_boards_above_16_cells(tw, oracle, w, h, diff, emb, common, E, twists):
     """The reference's Puzzle takes any width x height (rust/src/envs/puzzle.rs:34-42); the kernels pack a board as 16 nibbles.
     Larger boards collect through the any-environment path (the Puzzle steps on the host, one batched policy launch per time
-    step, obs ids beyond 255 as two bytes): every field bit-equal to the oracle's native collectors, PPO and self-play.  evaluate
-    / solve of such boards are not implemented and say so."""
+    step, obs ids beyond 255 as two bytes): every field bit-equal to the oracle's native collectors, PPO and self-play; evaluate
+    and solve (plain and MCTS-guided) give the oracle's numbers and action lists."""
     from tests.util import make_deep_policy_arrays
     n2 = w * h
     arrs = make_deep_policy_arrays(n2, seed=5, emb=emb, common=common, scale=2.0)
@@ -284,8 +284,21 @@ def test_ppo_collect_of_boards_above_16_cells(tw, oracle, w, h, diff, emb, commo
         z = tw.collector.AZCollector(min(E, 20), S, 1.41, med, 32).collect(genv, gp, seed=19)
         zo = oracle.az_collect(oenv, op, min(E, 20), S, 1.41, med, seed=19, arith=oracle.ARITH_CHAIN, num_threads=8, det_math=True)
         _assert_same_az(z, zo, n2)
-    with pytest.raises(RuntimeError, match="16"):
-        tw.collector.evaluate(genv, gp, num_episodes=4, deterministic=True, num_searches=1, num_mcts_searches=0, seed=1, C=1.41, max_expand_depth=1, num_cores=1)
+    # evaluate / solve of such boards (tw_evaluate_env / tw_solve_env behind tw_evaluate / tw_solve), plain and MCTS-guided
+    for det, ns, S in ((True, 1, 0), (False, 3, 0), (False, 2, 5)):
+        g = tw.collector.evaluate(genv, gp, num_episodes=25, deterministic=det, num_searches=ns, num_mcts_searches=S, seed=7, C=1.41,
+                                  max_expand_depth=1, num_cores=32)
+        o = oracle.evaluate(oenv, op, 25, det, ns, num_mcts_searches=S, seed=7, Cc=1.41, max_expand_depth=1, arith=oracle.ARITH_CHAIN, det_math=True)
+        assert f32_bits(g[0]) == f32_bits(o[0]) and f32_bits(g[1]) == f32_bits(o[1]), (det, ns, S, g, o)
+    start = oracle.Puzzle(w, h, diff, 2, 256); start.reset(seed=9, episode=3)
+    state = start.get_state()
+    genv.set_state(state); oenv.set_state(state)
+    before = genv.get_state()
+    for det, ns, S in ((True, 1, 0), (False, 4, 0), (False, 2, 4)):
+        (gs, gr), gact = tw.collector.solve(genv, gp, det, ns, S, 1.41, 1, seed=5)
+        (os_, or_), oact = oracle.solve(oenv, op, det, ns, num_mcts_searches=S, Cc=1.41, max_expand_depth=1, seed=5, arith=oracle.ARITH_CHAIN, det_math=True)
+        assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact, (det, ns, S)
+    assert genv.get_state() == before
 
 
 # ------------------------------------------------------------------------------ any Sequential depth (modules.rs:28-34)
@@ -380,6 +393,16 @@ def test_ppo_collect_of_a_python_environment(tw, oracle, w, h, steps, emb, commo
             z = tw.collector.AZCollector(min(E, 16), S, 1.41, med, 4).collect(env, gp, seed=79)
             zo = oracle.az_collect_env(proto, op, min(E, 16), S, 1.41, med, seed=79, difficulty=3)
             _assert_same_az(z, zo, n)
+        # evaluate / solve of the same environment (tw_evaluate_env / tw_solve_env), plain and MCTS-guided
+        for det, ns, S in ((True, 1, 0), (False, 3, 0), (False, 2, 4)):
+            ge = tw.collector.evaluate(env, gp, num_episodes=12, deterministic=det, num_searches=ns, num_mcts_searches=S, seed=5, C=1.41,
+                                       max_expand_depth=1, num_cores=4)
+            oe = oracle.evaluate_env(proto, op, 12, det, ns, S, 1.41, 1, seed=5, difficulty=3)
+            assert f32_bits(ge[0]) == f32_bits(oe[0]) and f32_bits(ge[1]) == f32_bits(oe[1]), (det, ns, S, ge, oe)
+            cur = proto.copy(); cur.seed_episode(3, 1); cur.reset(3)
+            (gs, gr), gact = tw.collector.solve(tw.env.PyEnv(cur), gp, det, ns, S, 1.41, 1, seed=9)
+            (os_, or_), oact = oracle.solve_env(cur, op, det, ns, S, 1.41, 1, seed=9)
+            assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == list(oact), (det, ns, S)
     finally:
         oracle.set_det_exp(False)
 

@@ -569,5 +569,19 @@ def test_generic_env_self_play_dummy_env_known_answer(oracle):
             assert np.array_equal(a.obs, b.obs) and np.array_equal(a.ep_len, b.ep_len)
             assert np.array_equal(a.logits.view(np.uint32), b.logits.view(np.uint32))
             assert np.array_equal(a.additional_data["remaining_values"].view(np.uint32), b.additional_data["remaining_values"].view(np.uint32))
+        # evaluate / solve of the same Puzzle through the restatements for arbitrary environments against two_evaluate / two_solve
+        PyPuzzle.success = lambda self: self.p.solved()
+        f = lambda x: np.float32(x).view(np.uint32)
+        for det, ns, S in ((True, 1, 0), (False, 3, 0), (False, 2, 4)):
+            a = oracle.evaluate_env(PyPuzzle(3, 3, 4), op, 12, det, ns, S, 1.41, 1, seed=7)
+            b = oracle.evaluate(oracle.Puzzle(3, 3, 4, 2, 256), op, 12, det, ns, num_mcts_searches=S, seed=7, Cc=1.41, max_expand_depth=1,
+                                arith=oracle.ARITH_CHAIN, det_math=True)
+            assert (f(a[0]), f(a[1])) == (f(b[0]), f(b[1])), (det, ns, S, a, b)
+            start = PyPuzzle(3, 3, 4); start.seed_episode(9, 3); start.reset(0)
+            nat = oracle.Puzzle(3, 3, 4, 2, 256); nat.set_state(start.p.get_state())
+            start.p.set_state(start.p.get_state())                       # (set_state: depth = max_depth, as the native side)
+            (s1, r1), a1 = oracle.solve_env(start, op, det, ns, S, 1.41, 1, seed=5)
+            (s2, r2), a2 = oracle.solve(nat, op, det, ns, num_mcts_searches=S, Cc=1.41, max_expand_depth=1, seed=5, arith=oracle.ARITH_CHAIN, det_math=True)
+            assert (s1, f(r1)) == (s2, f(r2)) and list(a1) == list(a2), (det, ns, S)
     finally:
         oracle.set_det_exp(False)

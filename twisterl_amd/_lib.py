@@ -16,7 +16,7 @@ TW_OK, TW_ERR_INVALID, TW_ERR_UNSUPPORTED, TW_ERR_NO_DEVICE, TW_ERR_HIP, TW_ERR_
 TW_PREC_F32_EXACT, TW_PREC_F16, TW_PREC_F16X2 = 0, 1, 2
 TW_EVAL_FORWARD, TW_EVAL_PREDICT, TW_EVAL_FULL_PREDICT = 0, 1, 2
 TW_OPT_FORCE_GEOM, TW_OPT_NO_PERSIST, TW_OPT_AZ_VARIANT = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 (TW_F_OBS, TW_F_LOGITS, TW_F_PERMS, TW_F_VALUES, TW_F_REWARDS, TW_F_ACTIONS, TW_F_ADVS, TW_F_RETS,
  TW_F_REMAINING, TW_F_EP_LEN, TW_F_EP_START, TW_F_COUNT) = range(12)
 
@@ -82,7 +82,8 @@ class EnvVTable(C.Structure):
                 ("clone", C.CFUNCTYPE(C.c_void_p, C.c_void_p)), ("destroy", C.CFUNCTYPE(None, C.c_void_p)),
                 ("reset", C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)), ("step", C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)),
                 ("observe", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32))), ("masks", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8))),
-                ("reward", C.CFUNCTYPE(C.c_float, C.c_void_p)), ("is_final", C.CFUNCTYPE(C.c_int, C.c_void_p))]
+                ("reward", C.CFUNCTYPE(C.c_float, C.c_void_p)), ("is_final", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+                ("success", C.CFUNCTYPE(C.c_int, C.c_void_p))]
 
 
 class CommId(C.Structure):
@@ -132,6 +133,10 @@ SYMBOLS = {
     "tw_az_collect": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(AZParams), C.POINTER(_VP)]),
     "tw_ppo_collect_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(PPOParams), C.c_uint32, C.POINTER(_VP)]),
     "tw_az_collect_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(AZParams), C.c_uint32, C.POINTER(_VP)]),
+    "tw_evaluate_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(SolveParams), C.c_uint64, C.c_uint64, C.c_uint32,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tw_solve_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(SolveParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                               C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint32)]),
     "tw_evaluate": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(SolveParams), C.c_uint64, C.c_uint64,
                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tw_solve": (C.c_int, [_VP, _VP, C.POINTER(SolveParams), C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -323,93 +323,109 @@ class PPOCollector(PyBaseCollector):
         return CollectedData._from_device(_DeviceResult(out.value))
 
 
+class _PyEnvBridge:
+    """A Python environment (reference protocol, python_interface/pyenv.rs) as the C function table of `trait Env`
+    (tw_env_vtable): clones live here, keyed by small integer handles; an exception raised by the environment's code is kept
+    and re-raised by the caller once the library call has returned (it must not unwind through the C frames)."""
+
+    def __init__(self, py_env: PyEnv, prototype=None):
+        proto = py_env._env if prototype is None else prototype
+        self.proto, self.err = proto, []
+        envs, nxt, err = {1: proto}, [2], self.err
+        V = _lib.EnvVTable
+
+        def guard(default=None):
+            def deco(fn):
+                def wrapped(*a):
+                    if err:
+                        return default
+                    try:
+                        return fn(*a)
+                    except BaseException as e:
+                        err.append(e)
+                        return default
+                return wrapped
+            return deco
+
+        @guard(0)
+        def f_clone(h):
+            envs[nxt[0]] = envs[h].copy()
+            nxt[0] += 1
+            return nxt[0] - 1
+
+        @guard()
+        def f_destroy(h):
+            envs.pop(h, None)
+
+        @guard()
+        def f_reset(h, sd, ep):
+            e = envs[h]
+            if hasattr(e, "seed_episode"):
+                e.seed_episode(int(sd), int(ep))
+            e.reset(py_env.difficulty)                  # PyEnvImpl::reset (pyenv.rs:93-100)
+
+        @guard()
+        def f_step(h, a):
+            envs[h].next(int(a))
+
+        @guard()
+        def f_observe(h, out_p):
+            for i, v in enumerate(envs[h].observe()):
+                out_p[i] = int(v)
+
+        @guard()
+        def f_masks(h, out_p):
+            for i, v in enumerate(envs[h].masks()):
+                out_p[i] = 1 if v else 0
+
+        @guard(0.0)
+        def f_reward(h):
+            return float(envs[h].value())
+
+        @guard(1)
+        def f_final(h):
+            return 1 if envs[h].is_final() else 0
+
+        @guard(0)
+        def f_success(h):
+            return 1 if envs[h].success() else 0         # PyEnvImpl::success (pyenv.rs:141-149)
+
+        n_obs = len(proto.observe())
+        obs_size = 1
+        for x in proto.obs_shape():
+            obs_size *= int(x)
+        fields = dict(V._fields_)
+        self._keep = (f_clone, f_destroy, f_reset, f_step, f_observe, f_masks, f_reward, f_final, f_success)
+        self.vt = V(1, int(proto.num_actions()), n_obs, obs_size, fields["clone"](f_clone), fields["destroy"](f_destroy), fields["reset"](f_reset),
+                    fields["step"](f_step), fields["observe"](f_observe), fields["masks"](f_masks), fields["reward"](f_reward),
+                    fields["is_final"](f_final), fields["success"](f_success))
+        self.max_records = int(getattr(proto, "max_records", 1 << 16))
+
+    def finish(self, rc):
+        if self.err:
+            raise self.err[0]
+        _lib.check(rc)
+
+
 def _collect_foreign(self, py_env: PyEnv, policy: Policy, seed) -> CollectedData:
-    """PPOCollector / AZCollector.collect for an environment implemented in Python (tw_ppo_collect_env / tw_az_collect_env): the
-    object's methods are handed to the library as the C function table of `trait Env`; clones live here, keyed by small integer
-    handles."""
+    """PPOCollector / AZCollector.collect for an environment implemented in Python (tw_ppo_collect_env / tw_az_collect_env)."""
     if not isinstance(policy, Policy):
         raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
     if self.precision not in ("fp32", "f32", "exact"):
         raise RuntimeError("environments implemented in Python are collected in f32")
-    proto = py_env._env
-    envs, nxt, err = {1: proto}, [2], []
-    V = _lib.EnvVTable
-
-    def guard(default=None):
-        def deco(fn):
-            def wrapped(*a):
-                if err:
-                    return default
-                try:
-                    return fn(*a)
-                except BaseException as e:          # an exception must not unwind through the C frames
-                    err.append(e)
-                    return default
-            return wrapped
-        return deco
-
-    @guard(0)
-    def f_clone(h):
-        envs[nxt[0]] = envs[h].copy()
-        nxt[0] += 1
-        return nxt[0] - 1
-
-    @guard()
-    def f_destroy(h):
-        envs.pop(h, None)
-
-    @guard()
-    def f_reset(h, sd, ep):
-        e = envs[h]
-        if hasattr(e, "seed_episode"):
-            e.seed_episode(int(sd), int(ep))
-        e.reset(py_env.difficulty)                  # PyEnvImpl::reset (pyenv.rs:93-100)
-
-    @guard()
-    def f_step(h, a):
-        envs[h].next(int(a))
-
-    @guard()
-    def f_observe(h, out_p):
-        for i, v in enumerate(envs[h].observe()):
-            out_p[i] = int(v)
-
-    @guard()
-    def f_masks(h, out_p):
-        for i, v in enumerate(envs[h].masks()):
-            out_p[i] = 1 if v else 0
-
-    @guard(0.0)
-    def f_reward(h):
-        return float(envs[h].value())
-
-    @guard(1)
-    def f_final(h):
-        return 1 if envs[h].is_final() else 0
-
-    n_obs = len(proto.observe())
-    obs_size = 1
-    for x in proto.obs_shape():
-        obs_size *= int(x)
-    fields = dict(V._fields_)
-    vt = V(1, int(proto.num_actions()), n_obs, obs_size, fields["clone"](f_clone), fields["destroy"](f_destroy), fields["reset"](f_reset),
-           fields["step"](f_step), fields["observe"](f_observe), fields["masks"](f_masks), fields["reward"](f_reward),
-           fields["is_final"](f_final))
+    br = _PyEnvBridge(py_env)
     sd = (int(seed) & (2**64 - 1)) if seed is not None else self._next_seed()
     out = C.c_void_p()
-    max_records = int(getattr(proto, "max_records", 1 << 16))
     if self._IS_PPO:
         prm = _lib.PPOParams(self.num_episodes, self.episode_offset, self.gamma, self.lambda_, sd, _lib.TW_PREC_F32_EXACT, int(self.merge_order), 0)
-        rc = _lib.lib().tw_ppo_collect_env(C.byref(vt), policy._handle(), C.byref(prm), max_records, C.byref(out))
+        rc = _lib.lib().tw_ppo_collect_env(C.byref(br.vt), policy._handle(), C.byref(prm), br.max_records, C.byref(out))
     else:
         prm = _lib.AZParams(self.num_episodes, self.episode_offset, self.num_mcts_searches, self.C, self.max_expand_depth, sd,
                             _lib.TW_PREC_F32_EXACT, int(self.merge_order), 0)
-        rc = _lib.lib().tw_az_collect_env(C.byref(vt), policy._handle(), C.byref(prm), max_records, C.byref(out))
-    if err:
-        if out.value:
-            _lib.lib().tw_collected_free(out)
-        raise err[0]
-    _lib.check(rc)
+        rc = _lib.lib().tw_az_collect_env(C.byref(br.vt), policy._handle(), C.byref(prm), br.max_records, C.byref(out))
+    if br.err and out.value:
+        _lib.lib().tw_collected_free(out)
+    br.finish(rc)
     return CollectedData._from_device(_DeviceResult(out.value))
 
 
@@ -464,10 +480,17 @@ def solve(py_env, policy: Policy, deterministic, num_searches, num_mcts_searches
     """solve(py_env, policy, deterministic, num_searches, num_mcts_searches, C, max_expand_depth)
     -> ((success, reward), actions)   (python_interface/env.rs:180-191 over rl/solve.rs:73-101).
     Best of `num_searches` greedy/sampled roll-outs from the env's CURRENT state; the env is not modified."""
-    get_env_desc(py_env)
     if not isinstance(policy, Policy):
         raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
     prm = _solve_params(deterministic, num_searches, num_mcts_searches, C, max_expand_depth, seed)
+    if isinstance(py_env, PyEnv):
+        br = _PyEnvBridge(py_env, prototype=py_env._env.copy())             # (the caller's object is not touched)
+        cap = br.max_records + 1
+        acts = (ctypes_u8 * cap)()
+        s, r, n = _c.c_float(), _c.c_float(), _c.c_uint32()
+        br.finish(_lib.lib().tw_solve_env(_c.byref(br.vt), policy._handle(), _c.byref(prm), br.max_records, _c.byref(s), _c.byref(r), acts, cap, _c.byref(n)))
+        return (float(s.value), float(r.value)), [int(acts[i]) for i in range(n.value)]
+    get_env_desc(py_env)
     cap = int(py_env.depth) + 2
     acts = (ctypes_u8 * cap)()
     s, r, n = _c.c_float(), _c.c_float(), _c.c_uint32()
@@ -481,12 +504,17 @@ def evaluate(py_env, policy: Policy, num_episodes, deterministic, num_searches, 
     max_expand_depth, num_cores) -> (success_rate, mean_reward)   (python_interface/env.rs:194-207 over
     rl/evaluate.rs:22-89).  `seed` keys the episode scrambles and action draws (the reference ignores it);
     `num_cores` is accepted for compatibility."""
-    desc = get_env_desc(py_env)
     if not isinstance(policy, Policy):
         raise TypeError("argument 'policy': expected twisterl_amd.nn.Policy")
     _u("num_cores", num_cores)
     prm = _solve_params(deterministic, num_searches, num_mcts_searches, C, max_expand_depth, seed)
     s, r = _c.c_float(), _c.c_float()
+    if isinstance(py_env, PyEnv):
+        br = _PyEnvBridge(py_env)
+        br.finish(_lib.lib().tw_evaluate_env(_c.byref(br.vt), policy._handle(), _c.byref(prm), _u("num_episodes", num_episodes), 0, br.max_records,
+                                             _c.byref(s), _c.byref(r)))
+        return float(s.value), float(r.value)
+    desc = get_env_desc(py_env)
     _lib.check(_lib.lib().tw_evaluate(_c.byref(desc), policy._handle(), _c.byref(prm), _u("num_episodes", num_episodes), 0,
                                       _c.byref(s), _c.byref(r)))
     return float(s.value), float(r.value)

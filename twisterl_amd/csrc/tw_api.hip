@@ -981,17 +981,10 @@ int make_env_consts(const tw_puzzle_desc *env, PuzzleConsts *out)
 // Boards above 16 cells (puzzle.rs:34-42 takes any width x height; the kernels pack a board as 16 nibbles): the Puzzle steps
 // on the host through the any-environment collectors (tw_env_generic.hip) -- same RNG spec, same arithmetic, the policy
 // evaluations of a moment in one batched launch.  f32; evaluate / solve of such boards are not implemented.
-static int collect_big_board(const tw_puzzle_desc *env, const tw_policy *policy, const tw_ppo_params *ppo, const tw_az_params *az, tw_collected **out)
+static tw_env_vtable puzzle_env_table(tw_puzzle *proto)
 {
-    const uint32_t precision = ppo ? ppo->precision : az->precision;
-    if (precision != TW_PREC_F32_EXACT) { set_error("boards above 16 cells collect in f32 only"); return TW_ERR_UNSUPPORTED; }
-    if ((uint64_t)env->width * env->height > 64) { set_error("Puzzle %ux%u: at most 64 cells", env->width, env->height); return TW_ERR_UNSUPPORTED; }
-    const uint64_t depth0 = (uint64_t)env->depth_slope * env->difficulty;
-    if (depth0 + 1 > 0xffffffffull) { set_error("Puzzle: depth_slope*difficulty too large"); return TW_ERR_UNSUPPORTED; }
-    tw_puzzle *proto = tw_puzzle_create(env->width, env->height, env->difficulty, env->depth_slope, env->max_depth);
-    if (!proto) return TW_ERR_INVALID;
     tw_env_vtable vt{};
-    vt.prototype = proto; vt.num_actions = 4; vt.n_obs = env->width * env->height; vt.obs_size = vt.n_obs * vt.n_obs;
+    vt.prototype = proto; vt.num_actions = 4; vt.n_obs = (uint32_t)proto->state.size(); vt.obs_size = vt.n_obs * vt.n_obs;
     vt.clone = [](void *e) -> void * { return tw_puzzle_clone(static_cast<tw_puzzle *>(e)); };
     vt.destroy = [](void *e) { tw_puzzle_destroy(static_cast<tw_puzzle *>(e)); };
     vt.reset = [](void *e, uint64_t seed, uint64_t episode) { (void)tw_puzzle_reset(static_cast<tw_puzzle *>(e), seed, episode); };
@@ -1004,7 +997,27 @@ static int collect_big_board(const tw_puzzle_desc *env, const tw_policy *policy,
     vt.masks = [](void *e, uint8_t *m) { (void)tw_puzzle_masks(static_cast<tw_puzzle *>(e), m); };
     vt.reward = [](void *e) -> float { return tw_puzzle_reward(static_cast<tw_puzzle *>(e)); };
     vt.is_final = [](void *e) -> int { return tw_puzzle_is_final(static_cast<tw_puzzle *>(e)); };
-    const int rc = ppo ? tw_ppo_collect_env(&vt, policy, ppo, (uint32_t)(depth0 + 1), out) : tw_az_collect_env(&vt, policy, az, (uint32_t)(depth0 + 1), out);
+    vt.success = [](void *e) -> int { return tw_puzzle_solved(static_cast<tw_puzzle *>(e)); };   // puzzle.rs:179-181
+    return vt;
+}
+
+static int big_board_checks(const tw_puzzle_desc *env, uint32_t precision, uint64_t *depth0)
+{
+    if (precision != TW_PREC_F32_EXACT) { set_error("boards above 16 cells run in f32 only"); return TW_ERR_UNSUPPORTED; }
+    if ((uint64_t)env->width * env->height > 64) { set_error("Puzzle %ux%u: at most 64 cells", env->width, env->height); return TW_ERR_UNSUPPORTED; }
+    *depth0 = (uint64_t)env->depth_slope * env->difficulty;
+    if (*depth0 + 1 > 0xfffffffeull) { set_error("Puzzle: depth_slope*difficulty too large"); return TW_ERR_UNSUPPORTED; }
+    return TW_OK;
+}
+
+static int collect_big_board(const tw_puzzle_desc *env, const tw_policy *policy, const tw_ppo_params *ppo, const tw_az_params *az, tw_collected **out)
+{
+    uint64_t depth0 = 0;
+    int rc = big_board_checks(env, ppo ? ppo->precision : az->precision, &depth0); if (rc) return rc;
+    tw_puzzle *proto = tw_puzzle_create(env->width, env->height, env->difficulty, env->depth_slope, env->max_depth);
+    if (!proto) return TW_ERR_INVALID;
+    tw_env_vtable vt = puzzle_env_table(proto);
+    rc = ppo ? tw_ppo_collect_env(&vt, policy, ppo, (uint32_t)(depth0 + 1), out) : tw_az_collect_env(&vt, policy, az, (uint32_t)(depth0 + 1), out);
     tw_puzzle_destroy(proto);
     return rc;
 }
@@ -1351,6 +1364,16 @@ extern "C" int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, c
 {
     if (!env || !policy || !prm || !success_rate || !mean_reward) { set_error("tw_evaluate: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
+    if ((uint64_t)env->width * env->height > 16) {                       // boards above 16 cells: the any-environment path (host env)
+        uint64_t depth0 = 0;
+        rc = big_board_checks(env, prm->precision, &depth0); if (rc) return rc;
+        tw_puzzle *proto = tw_puzzle_create(env->width, env->height, env->difficulty, env->depth_slope, env->max_depth);
+        if (!proto) return TW_ERR_INVALID;
+        tw_env_vtable vt = puzzle_env_table(proto);
+        rc = tw_evaluate_env(&vt, policy, prm, num_episodes, episode_offset, (uint32_t)(depth0 + 1), success_rate, mean_reward);
+        tw_puzzle_destroy(proto);
+        return rc;
+    }
     PuzzleConsts envc; rc = make_env_consts(env, &envc); if (rc) return rc;
     if (num_episodes == 0) { *success_rate = __builtin_nanf(""); *mean_reward = __builtin_nanf(""); return TW_OK; }   // 0/0 (evaluate.rs:52)
     std::vector<float> bs, br; std::vector<uint8_t> acts;
@@ -1368,6 +1391,17 @@ extern "C" int tw_solve(const tw_puzzle *env, const tw_policy *policy, const tw_
 {
     if (!env || !policy || !prm || !success || !reward) { set_error("tw_solve: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
+    if (env->state.size() > 16) {                                          // boards above 16 cells: the any-environment path (host env)
+        tw_puzzle_desc bd; tw_puzzle_get_desc(env, &bd);
+        uint64_t depth0 = 0;
+        rc = big_board_checks(&bd, prm->precision, &depth0); if (rc) return rc;
+        if (env->depth > 0xfffffff0ll) { set_error("tw_solve: depth %lld too large", (long long)env->depth); return TW_ERR_UNSUPPORTED; }
+        tw_puzzle *proto = tw_puzzle_clone(env);                           // (the caller's env is not modified)
+        tw_env_vtable vt = puzzle_env_table(proto);
+        rc = tw_solve_env(&vt, policy, prm, (uint32_t)env->depth + 1u, success, reward, actions_out, actions_cap, n_actions);
+        tw_puzzle_destroy(proto);
+        return rc;
+    }
     tw_puzzle_desc d; tw_puzzle_get_desc(env, &d);
     PuzzleConsts envc; rc = make_env_consts(&d, &envc); if (rc) return rc;
     if (env->depth > 4096) { set_error("tw_solve: depth %lld too large", (long long)env->depth); return TW_ERR_UNSUPPORTED; }
