@@ -34,15 +34,16 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0, "fp16x2": 2500.0}     # MI355X_MIC
 
 
 def measured_traffic_per_record(kernel="rollout_f32"):
-    """HBM bytes per record of the rollout kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-        for k, v in d.items():
-            if k.endswith(kernel) or (kernel == "rollout_f32" and kernel in k):
-                return float(v["bytes_per_record"])
-    except Exception:
-        pass
+    """HBM bytes per record of the rollout kernel from the committed rocprofv3 PMC passes (the latest round's
+    profiles/rNN_hbm_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)."""
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            for k, v in d.items():
+                if isinstance(v, dict) and (k.endswith(kernel) or (kernel == "rollout_f32" and kernel in k)):
+                    return float(v["bytes_per_record"])
+        except Exception:
+            pass
     return None
 
 
