@@ -57,11 +57,12 @@ __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >
 // floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | pool idx [POOL] | pool outputs [POOL][8]
 __host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers)
 {
-    return (size_t)columns * 10 + (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);
+    return (size_t)columns * 10 + 8 + (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);   // (+ 8: the walkers' alive flags)
 }
 
 #ifdef TW_ABLATE
 __device__ unsigned long long g_deep_stamps[16];
+__device__ unsigned long long g_deep_extra[4];
 #endif
 
 template <int NT, int NC, int NW, int NWK>
@@ -88,7 +89,8 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     uint2 *req = reinterpret_cast<uint2 *>(xbase);                               // request boards [C]
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
     const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
-    float *wbase = res + 8 * C + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
+    int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][4 waves]: walker still has an episode
+    float *wbase = res + 8 * C + 8 + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
     lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 4);                         // pool: node index (DNONE = free)
     lds_f32 *pout = (lds_f32 *)(wbase + (size_t)NL * 4 + DEEP_POOL);             // pool: probs[4], value, - - -
@@ -129,6 +131,9 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     bool my_take = false; uint32_t my_idx = 0; int my_rank = 0, my_slot = 0;
     uint32_t pool_head = 0; int n_spec = 0;
     bool yielded = false;                                                           // stopped at a search boundary without a demand
+    // this walker's columns of the forward being assembled / evaluated: the C columns are dealt out to the walkers that still
+    // have an episode (4, 5, 8 or 16 each) -- at the tail of a collect the long episodes get the look-ahead of the finished ones
+    int my_base = 0, my_share = 0; uint32_t trip = 0;
 
     auto take = [&](uint64_t e) {
         e_local = e; e_global = a.episode_offset + e; rec_base = e * (uint64_t)a.out.t_pad;
@@ -144,6 +149,8 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     if (walker && slot < E) take(slot);
     if (walker && lane < DEEP_POOL) pidx[lane] = DNONE;
     if (!walker) more = false;
+    if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[4 + wave] = phase != DP_DEAD ? 1 : 0; }
+    __syncthreads();
 
     uint32_t obs_base[4];
     obs_base_words(env.n_cells, obs_base);
@@ -156,16 +163,27 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     // request columns of this walker for the next forward: the demand + up to CPW-1 unevaluated frontier nodes in creation order
     auto assemble = [&]() {
         my_take = false; n_spec = 0;
-        if (!walker) return;
+        // publish whether this walker still has an episode (read by everybody one trip later: a walker that ran out THIS trip
+        // keeps its columns for one more forward and fills them with the identity board)
+        if (lane == 0) alive_f[(trip & 1u) * 4 + wave] = (walker && phase != DP_DEAD) ? 1 : 0;
+        const int *af = alive_f + ((trip & 1u) ^ 1u) * 4;
+        ++trip;
+        int n_alive = 0, rank_me = 0;
+#pragma unroll
+        for (int w = 0; w < DEEP_WAVES; ++w) { const int f = uni(af[w]); rank_me += (w < wave) ? f : 0; n_alive += f; }
+        const bool mine = walker && uni(af[wave]) != 0;
+        if (!mine) { my_share = 0; return; }
+        my_share = C / n_alive; my_base = rank_me * my_share;
+        if (rank_me == n_alive - 1) my_share = C - my_base;                  // the last one takes the remainder (16 = 5 + 5 + 6)
         const uint64_t ident = env.ident;
         if (phase == DP_DEAD) {
-            if (lane < CPW) req[wave * CPW + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
+            if (lane < my_share) req[my_base + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
             return;
         }
         uint64_t db = cur.board;
         if (phase == DP_ROOT) db = st.board;
         const int col0 = yielded ? 0 : 1;                                // a walker that stopped between two searches has no demand
-        if (lane == 0 && !yielded) req[wave * CPW] = make_uint2((uint32_t)db, (uint32_t)(db >> 32));
+        if (lane == 0 && !yielded) req[my_base] = make_uint2((uint32_t)db, (uint32_t)(db >> 32));
         // 64 candidates in one round trip: nodes cursor .. cursor+63
         const uint32_t idx = cursor + (uint32_t)lane;
         const bool in_tree = phase == DP_LEAF && idx < n_nodes;         // (a new move's tree does not exist yet)
@@ -174,16 +192,16 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         const uint64_t cb64 = ((uint64_t)c1.y << 32) | c1.x;
         // a node needs the network if it is not final (search.rs:149), not expanded and holds no output yet
         const bool valid = in_tree && !(ch.w & LK_OUT) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && (yielded || idx != dem_idx);
-        const int quota = CPW - col0;
+        const int quota = my_share - col0;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
         const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
         const int n_valid = __builtin_popcountll(m);
         if (valid && rank < quota) {
-            req[wave * CPW + col0 + rank] = make_uint2(c1.x, c1.y);
+            req[my_base + col0 + rank] = make_uint2(c1.x, c1.y);
             my_take = true; my_idx = idx; my_rank = col0 + rank; my_slot = rank;     // (my_rank: column inside the walker's share)
         }
         const int n_take = n_valid < quota ? n_valid : quota;
-        if (lane >= col0 + n_take && lane < CPW) req[wave * CPW + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
+        if (lane >= col0 + n_take && lane < my_share) req[my_base + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
         // everything below the cursor is evaluated, expanded, final or being evaluated now
         uint32_t nc2;
         if (n_valid >= quota) {
@@ -201,7 +219,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     assemble();
 
 #ifdef TW_ABLATE
-    unsigned long long c_fwd = 0, c_tree = 0, c_bar = 0, c_trips = 0, c_search = 0, c_hits = 0, c_asm = 0;
+    unsigned long long c_fwd = 0, c_tree = 0, c_bar = 0, c_trips = 0, c_search = 0, c_hits = 0, c_asm = 0, c_yield = 0, c_root = 0, c_dead = 0, c_nspec = 0;
     unsigned long long c_pre = 0, c_desc = 0, c_leaf = 0, c_bp = 0, c_fin = 0, c_res = 0, c_lvl = 0;
 #define TW_DS(var) const unsigned long long var = __builtin_readcyclecounter()
 #define TW_DA(acc, x, y) acc += (y) - (x)
@@ -244,7 +262,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
             float probs[4];
             masked_softmax4(lsum, puzzle_maskbits(lf, env), probs);
             // every wave holds every column's output: wave w publishes the columns of walker w, for itself
-            if (eng.h == 0 && col / CPW == wave) {
+            if (eng.h == 0 && col >= my_base && col < my_base + my_share) {
                 float4 *dst = reinterpret_cast<float4 *>(res + col * 8);
                 dst[0] = make_float4(probs[0], probs[1], probs[2], probs[3]);
                 dst[1] = make_float4(vsum, 0.0f, 0.0f, 0.0f);
@@ -257,6 +275,8 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         TW_DA(c_fwd, z1, z2);
 #ifdef TW_ABLATE
         ++c_trips;
+        if (phase == DP_DEAD) ++c_dead; else if (yielded) ++c_yield; else if (phase == DP_ROOT) ++c_root;
+        c_nspec += (unsigned long long)n_spec;
 #endif
 
         // ---- tree phase of this wave's walker ------------------------------------------------------------------------
@@ -264,7 +284,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
             TW_DS(y0);
             // outputs evaluated ahead of the search -> their nodes (arena) and the LDS pool; the node's hot quad gets the flag
             if (my_take) {
-                const float4 *src = reinterpret_cast<const float4 *>(res + (wave * CPW + my_rank) * 8);
+                const float4 *src = reinterpret_cast<const float4 *>(res + (my_base + my_rank) * 8);
                 const float4 pr = src[0]; const float4 vv = src[1];
                 nodes[my_idx].q2 = make_uint4(__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w));
                 nodes[my_idx].q3 = make_uint4(__float_as_uint(vv.x), 0u, 0u, 0u);
@@ -280,7 +300,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
             // the demanded output
             float probs[4], nn_value;
             {
-                const float4 *src = reinterpret_cast<const float4 *>(res + (wave * CPW) * 8);
+                const float4 *src = reinterpret_cast<const float4 *>(res + my_base * 8);
                 const float4 pr = src[0]; const float4 vv = src[1];
                 probs[0] = unif(pr.x); probs[1] = unif(pr.y); probs[2] = unif(pr.z); probs[3] = unif(pr.w); nn_value = unif(vv.x);
             }
@@ -519,6 +539,8 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     if (lane == 0) {
         atomicAdd(&g_deep_stamps[0], c_fwd); atomicAdd(&g_deep_stamps[1], c_tree); atomicAdd(&g_deep_stamps[2], c_bar);
         atomicAdd(&g_deep_stamps[3], c_trips); atomicAdd(&g_deep_stamps[4], c_search); atomicAdd(&g_deep_stamps[5], c_hits);
+        if (wave < NWK) { atomicAdd(&g_deep_stamps[15], c_yield); }
+        atomicAdd(&g_deep_extra[0], c_root); atomicAdd(&g_deep_extra[1], c_dead); atomicAdd(&g_deep_extra[2], c_nspec); atomicAdd(&g_deep_extra[3], wave < NWK ? c_trips : 0ull);
         atomicAdd(&g_deep_stamps[6], 1ull); atomicAdd(&g_deep_stamps[7], c_asm);
         atomicAdd(&g_deep_stamps[8], c_pre); atomicAdd(&g_deep_stamps[9], c_desc); atomicAdd(&g_deep_stamps[10], c_leaf);
         atomicAdd(&g_deep_stamps[11], c_bp); atomicAdd(&g_deep_stamps[12], c_fin); atomicAdd(&g_deep_stamps[13], c_res); atomicAdd(&g_deep_stamps[14], c_lvl);
@@ -582,7 +604,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
     unsigned long long zeros[16] = {0};
-    if (getenv("TW_STAMPS")) TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros)));
+    if (getenv("TW_STAMPS")) { TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros))); TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_extra), zeros, 32)); }
 #endif
     hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK>), dim3((unsigned)nb), dim3(256), lds_bytes, s, b);
     TW_HIP(hipGetLastError());
@@ -591,6 +613,10 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
         unsigned long long h[16];
         TW_HIP(hipStreamSynchronize(s));
         TW_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_deep_stamps), sizeof(h)));
+        unsigned long long x[4];
+        TW_HIP(hipMemcpyFromSymbol(x, HIP_SYMBOL(g_deep_extra), sizeof(x)));
+        fprintf(stderr, "  walker trips %llu: dead %llu, yielded (no demand) %llu, root evaluations %llu, leaf demands %llu | columns evaluated ahead %llu, consumed %llu\n",
+                x[3], x[1], h[15], x[0], x[3] - x[1] - h[15] - x[0], x[2], h[5]);
         const double w = (double)h[6], tr = (double)h[3];
         fprintf(stderr, "deep stamps: waves %.0f, lds nodes %u | per wave: fwd %.0f, tree %.0f, assembly %.0f, barrier wait %.0f cycles, trips %.1f | per trip: fwd %.0f, tree %.0f, assembly %.0f, barrier %.0f | "
                         "search-loop passes per trip %.2f, stored outputs consumed per trip %.2f\n",
