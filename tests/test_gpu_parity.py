@@ -658,6 +658,19 @@ def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, h
         assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact
 
 
+def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_busy(tw, oracle):
+    """tw_mcts_deep.hip: one walker x 16 columns per workgroup up to one episode per CU, two x 8 up to two, four x 4 beyond (and
+    at most one workgroup per CU: the rest of the episodes comes off the queue).  The parity cases of
+    test_az_collect_bit_exact_vs_oracle run all three; this pins which launch each batch size gets."""
+    import twisterl_amd
+    cus = twisterl_amd.device_info()["compute_units"]
+    gp, _ = _pair(oracle, 9, 2, 32, 128)
+    env = tw.env.Puzzle(3, 3, 2, 2, 256)
+    for E, want in ((cus // 2, cus // 2), (cus, cus), (cus + cus // 2, (cus + cus // 2 + 1) // 2), (2 * cus, cus), (3 * cus, (3 * cus + 3) // 4), (5 * cus, cus)):
+        d = tw.collector.AZCollector(E, 4, 1.41, 1, 1).collect(env, gp, seed=3)
+        assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == (want, 256), (E, d.stats["rollout_blocks"], want)
+
+
 # ------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_puzzle8_65k(tw, oracle):
     """BASELINE config 2 size (65,536 envs): determinism, replay parity on a sample, GAE parity on
