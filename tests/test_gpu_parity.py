@@ -353,6 +353,22 @@ def test_policies_of_any_depth(tw, oracle, n2, emb, common, pl, vl, twists):
         tw.collector.PPOCollector(8, 0.9, 0.9, 1, precision="fp16").collect(genv, gp, seed=1)
 
 
+def test_generic_policy_with_more_episodes_than_lanes_uses_the_queue(tw, oracle):
+    """Policies of any depth run 16 episodes per workgroup; with more episodes than one workgroup per CU the lanes are
+    persistent and take the next episode off the queue (as the MFMA shapes do): bit-equal to the oracle, one workgroup per CU."""
+    import twisterl_amd
+    from tests.util import make_deep_policy_arrays
+    cus = twisterl_amd.device_info()["compute_units"]
+    arrs = make_deep_policy_arrays(9, seed=3, emb=32, common=(48, 32), scale=2.0)
+    gp, op = amd_policy(arrs), oracle_policy(oracle, arrs)
+    genv, oenv = tw.env.Puzzle(3, 3, 4, 2, 256), oracle.Puzzle(3, 3, 4, 2, 256)
+    E = cus * 16 + 1500
+    g = tw.collector.PPOCollector(E, 0.995, 0.995, 32).collect(genv, gp, seed=29)
+    assert (g.stats["rollout_blocks"], g.stats["rollout_threads"]) == (cus, 256)
+    o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=29, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8)
+    _assert_same_collect(g, o, 9)
+
+
 # ------------------------------------------------------------------------------ any environment (SURVEY §8f rank 4a)
 @pytest.mark.parametrize("w,h,steps,emb,common,E", [(3, 3, 8, 64, (64,), 120), (5, 5, 12, 64, (128, 32), 60)])
 def test_ppo_collect_of_a_python_environment(tw, oracle, w, h, steps, emb, common, E):

@@ -1058,9 +1058,11 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
     // persistent-lane mode (more episodes than resident lanes): start boards + episode queue
     ra.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
-    const uint64_t resident = prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false, ra.reserve_cus)
+    // (generic policy stacks: one 16-episode workgroup per CU -- rollout_f32_resident_episodes counts 256 per CU)
+    const uint64_t resident = ra.pol.generic ? rollout_f32_resident_episodes(ra.reserve_cus) / 16
+                            : prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false, ra.reserve_cus)
                                                                   : rollout_f32_resident_episodes(ra.reserve_cus);
-    const bool persist = E > resident && !launch_options().no_persist && !ra.pol.generic;
+    const bool persist = E > resident && !launch_options().no_persist;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
                  o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     void *wsp = nullptr;

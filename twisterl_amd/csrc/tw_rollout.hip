@@ -264,11 +264,16 @@ int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
 {
     if (a.pol.generic) {          // any Sequential depth: the vector-ALU engine (tw_engine_generic.hpp); shapes validated by tw_policy_create
         if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
-            a.out.t_pad < a.env.depth0 + 1 || a.queue || a.init_boards) {
+            a.out.t_pad < a.env.depth0 + 1 || (a.queue == nullptr) != (a.init_boards == nullptr)) {
             set_error("rollout: unsupported shape for a generic policy (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
             return TW_ERR_UNSUPPORTED;
         }
         const int nc = a.env.n_cells;
+        if (a.queue) {            // more episodes than one 16-episode workgroup per CU: persistent lanes + episode queue
+            if (nc <= 4) return launch_geom<0, 4, 0, -64, true>(a, s, blocks, threads);
+            if (nc <= 9) return launch_geom<0, 9, 0, -64, true>(a, s, blocks, threads);
+            return launch_geom<0, 16, 0, -64, true>(a, s, blocks, threads);
+        }
         if (nc <= 4) return launch_geom<0, 4, 0, -64>(a, s, blocks, threads);
         if (nc <= 9) return launch_geom<0, 9, 0, -64>(a, s, blocks, threads);
         return launch_geom<0, 16, 0, -64>(a, s, blocks, threads);
