@@ -157,6 +157,10 @@ void       tw_policy_destroy(tw_policy *p);
  * [1][hidden], value.0.bias [1].  Shapes, ReLU flags and twists stay those given to tw_policy_create. */
 int tw_policy_update_device(tw_policy *p, const float *emb_w, const float *emb_b, const float *w1, const float *b1,
                             const float *wa, const float *ba, const float *wv, const float *bv);
+/* The same for a policy of any Sequential depth (the stacks tw_policy_create ran through its generic engine): the Linear
+ * layers' torch parameters in the order common.., action.., value.. (weight [out][in], bias [out]), device pointers. */
+int tw_policy_update_device_layers(tw_policy *p, const float *emb_w, const float *emb_b, const float *const *weights,
+                                   const float *const *biases, uint32_t n_layers);
 uint32_t   tw_policy_num_actions(const tw_policy *p);
 uint32_t   tw_policy_num_perms(const tw_policy *p);
 

@@ -920,6 +920,41 @@ def test_policy_update_from_torch_equals_rebuilding(tw, oracle, n2, emb, hidden,
         pol.update_from_torch({**state, "common.0.bias": torch.zeros(3).cuda()})
 
 
+@pytest.mark.parametrize("n2,emb,common,pl,vl", [(9, 64, (128, 64), (), ()), (16, 128, (96,), (32,), (16,)), (4, 32, (), (24,), ())])
+def test_policy_update_from_torch_for_any_depth(tw, oracle, n2, emb, common, pl, vl):
+    """Policy.update_from_torch for the stacks the generic engine runs (tw_policy_update_device_layers): the Linear layers of a
+    BasicPolicy stack are the even entries of its torch Sequential (nn/utils.py:82-93).  Same policy, bit for bit, as one built
+    from the host export: identical PPO and self-play collects and batched evaluations."""
+    import torch
+    from tests.util import make_deep_policy_arrays
+    w = int(round(n2 ** 0.5))
+    arrs_old = make_deep_policy_arrays(n2, seed=1, emb=emb, common=common, policy_layers=pl, value_layers=vl, scale=2.0)
+    arrs_new = make_deep_policy_arrays(n2, seed=2, emb=emb, common=common, policy_layers=pl, value_layers=vl, scale=2.0)
+    pol, ref = amd_policy(arrs_old), amd_policy(arrs_new)
+    we, be, cs, as_, vs = arrs_new
+    state = {"embeddings.weight": torch.tensor(we.T.copy()).cuda(), "embeddings.bias": torch.tensor(be).cuda()}
+    for name, layers in (("common", cs), ("action", as_), ("value", vs)):
+        for i, (wl, bl, _) in enumerate(layers):
+            state[f"{name}.{2 * i}.weight"] = torch.tensor(np.asarray(wl).reshape(-1, len(bl)).T.copy()).cuda()     # export: weight.T.flatten()
+            state[f"{name}.{2 * i}.bias"] = torch.tensor(np.asarray(bl)).cuda()
+    env = tw.env.Puzzle(w, w, 4, 2, 256)
+    before = tw.collector.PPOCollector(64, 0.99, 0.95, 1).collect(env, pol, seed=3).to_numpy()
+    pol.update_from_torch(state)
+    a, b = (tw.collector.PPOCollector(300, 0.99, 0.95, 1).collect(env, p_, seed=3).to_numpy() for p_ in (pol, ref))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert not np.array_equal(before["logits"][:8], a["logits"][:8])
+    za, zb = (tw.collector.AZCollector(30, 8, 1.41, 1, 1).collect(env, p_, seed=5).to_numpy() for p_ in (pol, ref))
+    for k in za:
+        assert np.array_equal(za[k], zb[k]), k
+    obs = np.arange(n2)[None, :] * n2 + np.arange(n2)[None, :]
+    la, va = pol.evaluate_batch(0, obs, np.ones((1, 4), np.uint8))
+    lb, vb = ref.evaluate_batch(0, obs, np.ones((1, 4), np.uint8))
+    assert np.array_equal(f32_bits(la), f32_bits(lb)) and np.array_equal(f32_bits(va), f32_bits(vb))
+    with pytest.raises(KeyError):
+        pol.update_from_torch({k: v for k, v in state.items() if k != "embeddings.bias"})
+
+
 # ------------------------------------------------------------------------------ f32-equivalent split-f16 mode
 @pytest.mark.parametrize("w,h,diff,emb,hidden,E,twists", [
     (3, 3, 5, 64, 32, 300, False),      # two embedding tiles (the minimum), ragged workgroup tail

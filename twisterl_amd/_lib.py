@@ -124,6 +124,7 @@ SYMBOLS = {
     "tw_policy_create": (_VP, [C.POINTER(PolicyDesc)]),
     "tw_policy_destroy": (None, [_VP]),
     "tw_policy_update_device": (C.c_int, [_VP] * 9),
+    "tw_policy_update_device_layers": (C.c_int, [_VP, _VP, _VP, C.POINTER(_VP), C.POINTER(_VP), C.c_uint32]),
     "tw_policy_num_actions": (C.c_uint32, [_VP]),
     "tw_policy_num_perms": (C.c_uint32, [_VP]),
     "tw_policy_evaluate": (C.c_int, [_VP, C.c_int, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32,

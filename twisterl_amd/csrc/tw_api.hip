@@ -366,6 +366,8 @@ struct tw_policy {
     size_t arena_bytes = 0;
     int device = -1;
     uint32_t n16 = 0, sp16 = 0, sps = 0;      // f16 / split-f16 image geometry (tw_policy_update_device)
+    std::vector<LayerDev> gen_layers;          // generic stacks: the layer table (device pointers) and the un-padded widths
+    std::vector<uint32_t> gen_out;
 };
 
 namespace {
@@ -473,6 +475,7 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
         tab[i].in = (int32_t)all[i]->in_features; tab[i].out = (int32_t)pad4(all[i]->out_features); tab[i].relu = all[i]->apply_relu ? 1 : 0; tab[i].pad = 0;
         tab[i].wm = reinterpret_cast<const float *>(base + o_wm[i]);
         tab[i].kg = (int32_t)((all[i]->in_features + 3u) / 4u); tab[i].nb = (int32_t)blocks_of(all[i]->out_features); tab[i].tb = (int32_t)tiles_per_block(all[i]->out_features); tab[i].pad2 = 0;
+        pol->gen_layers.push_back(tab[i]); pol->gen_out.push_back(all[i]->out_features);
     }
     e = hipMemcpy(pol->arena, img.data(), img.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hip_fail(e, "policy upload", __FILE__, __LINE__); (void)hipFree(pol->arena); delete pol; return nullptr; }
@@ -733,7 +736,7 @@ extern "C" int tw_policy_update_device(tw_policy *p, const float *emb_w, const f
     if (!p || !emb_w || !emb_b || !w1 || !b1 || !wa || !ba || !wv || !bv) { set_error("tw_policy_update_device: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
     const PolicyDev &d = p->dev;
-    if (d.generic) { set_error("tw_policy_update_device: policies with more than one common layer or non-linear heads are rebuilt with tw_policy_create"); return TW_ERR_UNSUPPORTED; }
+    if (d.generic) { set_error("tw_policy_update_device: policies of another depth take tw_policy_update_device_layers"); return TW_ERR_UNSUPPORTED; }
     SyncArgs a{};
     a.emb_w = emb_w; a.emb_b = emb_b; a.w1 = w1; a.b1 = b1; a.wa = wa; a.ba = ba; a.wv = wv; a.bv = bv;
     a.OS = d.obs_size; a.E = d.emb; a.H = d.hidden; a.A = d.n_actions; a.NT = d.hidden / 32; a.NQ = (a.NT + 3) / 4;
@@ -757,6 +760,31 @@ extern "C" int tw_policy_update_device(tw_policy *p, const float *emb_w, const f
     unsigned long long run = 0;
     for (int i = 0; i < 18; ++i) { run += cnt[i]; a.seg_end[i] = run; }
     return launch_policy_sync(a, current_stream());
+}
+
+extern "C" int tw_policy_update_device_layers(tw_policy *p, const float *emb_w, const float *emb_b, const float *const *weights,
+                                              const float *const *biases, uint32_t n_layers)
+{
+    if (!p || !emb_w || !emb_b || (n_layers && (!weights || !biases))) { set_error("tw_policy_update_device_layers: null argument"); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+    const PolicyDev &d = p->dev;
+    if (!d.generic) { set_error("tw_policy_update_device_layers: this policy has the one-common-layer shape: tw_policy_update_device"); return TW_ERR_UNSUPPORTED; }
+    if (n_layers != p->gen_layers.size() || n_layers > (uint32_t)GEN_SYNC_MAX_LAYERS) { set_error("tw_policy_update_device_layers: the policy has %zu layers, %u given", p->gen_layers.size(), n_layers); return TW_ERR_INVALID; }
+    GenSyncArgs a{};
+    a.emb_w = emb_w; a.emb_b = emb_b; a.emb_rows = const_cast<float *>(d.emb_rows); a.OS = d.obs_size; a.E = d.emb; a.n_layers = (int)n_layers;
+    unsigned long long run = (unsigned long long)(a.OS + 2) * a.E;
+    a.seg_end[0] = run;
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        if (!weights[l] || !biases[l]) { set_error("tw_policy_update_device_layers: null layer %u", l); return TW_ERR_INVALID; }
+        const LayerDev &L = p->gen_layers[l];
+        a.w[l] = weights[l]; a.b[l] = biases[l];
+        a.w_nat[l] = const_cast<float *>(L.w); a.b_img[l] = const_cast<float *>(L.b); a.wm[l] = const_cast<float *>(L.wm);
+        a.in[l] = L.in; a.out[l] = (int)p->gen_out[l]; a.outp[l] = L.out; a.kg[l] = L.kg; a.nb[l] = L.nb; a.tb[l] = L.tb;
+        run += (unsigned long long)L.in * L.out; a.seg_end[1 + 3 * l] = run;
+        run += (unsigned long long)L.nb * L.tb * 16; a.seg_end[2 + 3 * l] = run;
+        run += (unsigned long long)L.kg * 4 * L.nb * 16 * L.tb; a.seg_end[3 + 3 * l] = run;
+    }
+    return launch_policy_sync_generic(a, current_stream());
 }
 
 extern "C" void tw_policy_destroy(tw_policy *p)

@@ -514,6 +514,18 @@ struct SyncArgs {
 
 int launch_policy_sync(const SyncArgs &a, hipStream_t s);
 
+// the same for policies of any Sequential depth (EngineV's images): layer l of [common.. | action.. | value..]
+constexpr int GEN_SYNC_MAX_LAYERS = 24;
+struct GenSyncArgs {
+    const float *emb_w, *emb_b;                    // torch layout: [E][OS], [E]
+    float *emb_rows; int OS, E, n_layers;
+    const float *w[GEN_SYNC_MAX_LAYERS], *b[GEN_SYNC_MAX_LAYERS];      // torch layout: [out][in], [out]
+    float *w_nat[GEN_SYNC_MAX_LAYERS], *b_img[GEN_SYNC_MAX_LAYERS], *wm[GEN_SYNC_MAX_LAYERS];
+    int in[GEN_SYNC_MAX_LAYERS], out[GEN_SYNC_MAX_LAYERS], outp[GEN_SYNC_MAX_LAYERS], kg[GEN_SYNC_MAX_LAYERS], nb[GEN_SYNC_MAX_LAYERS], tb[GEN_SYNC_MAX_LAYERS];
+    unsigned long long seg_end[1 + 3 * GEN_SYNC_MAX_LAYERS];           // embedding rows | per layer: natural weights, bias image, matrix-core image
+};
+int launch_policy_sync_generic(const GenSyncArgs &a, hipStream_t s);
+
 // tw_api.hip internals the exchange (tw_comm.hip) and the generic-env collector (tw_env_generic.hip) work on
 int require_device();
 const PolicyDev *policy_dev(const tw_policy *p);

@@ -117,6 +117,44 @@ __global__ void __launch_bounds__(256) policy_sync_kernel(const SyncArgs a)
     }
 }
 
+// policies of any Sequential depth: the embedding rows and, per layer, the natural weights (policy_eval kernels), the padded bias
+// and the matrix-core image (EngineV) -- the index maps of create_generic_policy (tw_api.hip)
+__global__ void __launch_bounds__(256) policy_sync_generic_kernel(const GenSyncArgs a)
+{
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const int n_seg = 1 + 3 * a.n_layers;
+    if (gid >= a.seg_end[n_seg - 1]) return;
+    int seg = 0;
+    while (gid >= a.seg_end[seg]) ++seg;
+    const unsigned long long i = gid - (seg ? a.seg_end[seg - 1] : 0ull);
+    if (seg == 0) {   // emb_rows [(OS+2)][E]: rows, bias row, zero row; table[id][k] = Linear.weight[k][id]
+        const int r = (int)(i / a.E), k = (int)(i % a.E);
+        a.emb_rows[i] = r < a.OS ? a.emb_w[(size_t)k * a.OS + r] : (r == a.OS ? a.emb_b[k] : 0.0f);
+        return;
+    }
+    const int l = (seg - 1) / 3, what = (seg - 1) % 3;
+    const int in = a.in[l], out = a.out[l];
+    if (what == 0) {          // natural [in][outp]: W[k][o] = Linear.weight[o][k], 0 in the padding columns
+        const int k = (int)(i / a.outp[l]), o = (int)(i % a.outp[l]);
+        a.w_nat[l][i] = o < out ? a.w[l][(size_t)o * in + k] : 0.0f;
+    } else if (what == 1) {   // bias image [nb * tb * 16]
+        a.b_img[l][i] = (int)i < out ? a.b[l][i] : 0.0f;
+    } else {                  // matrix-core image [kg * 4][nb][16][tb]: element (k, b, r, t) = W[k][(b * tb + t) * 16 + r], -0.0 outside
+        const int tb = a.tb[l], nb = a.nb[l];
+        const int t = (int)(i % tb), r = (int)((i / tb) % 16), b = (int)((i / (tb * 16)) % nb), k = (int)(i / ((unsigned long long)tb * 16 * nb));
+        const int o = (b * tb + t) * 16 + r;
+        a.wm[l][i] = (k < in && o < out) ? a.w[l][(size_t)o * in + k] : -0.0f;
+    }
+}
+
+int launch_policy_sync_generic(const GenSyncArgs &a, hipStream_t s)
+{
+    const unsigned long long n = a.seg_end[3 * a.n_layers];
+    hipLaunchKernelGGL(policy_sync_generic_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
 int launch_policy_sync(const SyncArgs &a, hipStream_t s)
 {
     const unsigned long long n = a.seg_end[17];

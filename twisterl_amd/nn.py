@@ -226,6 +226,8 @@ def _sync_from_torch(policy: "Policy", state) -> None:
         state = dict(state)
         state["embeddings.weight"] = dense.reshape(n_slices * v, rows * cols)
         state["embeddings.bias"] = torch.zeros(n_slices * v, device="cuda", dtype=torch.float32)
+    if not _is_basic_shape(policy):
+        return _sync_generic_from_torch(policy, state)
     keys = ["embeddings.weight", "embeddings.bias", "common.0.weight", "common.0.bias", "action.0.weight", "action.0.bias",
             "value.0.weight", "value.0.bias"]
     missing = [k for k in keys if k not in state]
@@ -246,6 +248,46 @@ def _sync_from_torch(policy: "Policy", state) -> None:
     torch.cuda.current_stream().synchronize()        # the parameters are final before the library's stream reads them
     _lib.check(_lib.lib().tw_policy_update_device(h, *[C.c_void_p(t.data_ptr()) for t in ts]))
     torch.cuda.synchronize()                          # the temporaries in `ts` may be freed after this returns
+
+
+def _is_basic_shape(policy: "Policy") -> bool:
+    """the one-common-layer shape the MFMA engines implement (tw_api.hip is_mfma_shape); everything else is a generic stack"""
+    c, a, v = policy.common.layers, policy.action_net.layers, policy.value_net.layers
+    if len(c) != 1 or len(a) != 1 or len(v) != 1:
+        return False
+    emb, hid = int(policy.embeddings.bias.size), c[0].out_features
+    obs_size = int(np.prod(policy.embeddings.obs_shape)) if len(policy.embeddings.obs_shape) == 2 else int(policy.embeddings.vectors.shape[0])
+    return (emb % 32 == 0 and hid in (32, 64, 128, 256) and obs_size <= 256 and not a[0].apply_relu and not v[0].apply_relu
+            and v[0].out_features == 1)
+
+
+def _sync_generic_from_torch(policy: "Policy", state) -> None:
+    """update_from_torch for policies of any Sequential depth: BasicPolicy builds its stacks with make_sequential
+    (src/twisterl/nn/utils.py:82-93: Linear, ReLU, Linear, ReLU, ..), so the Linear layers of a stack are its even entries."""
+    import torch
+    stacks = (("common", policy.common.layers), ("action", policy.action_net.layers), ("value", policy.value_net.layers))
+    emb = int(policy.embeddings.bias.size)
+    obs_size = int(np.prod(policy.embeddings.obs_shape)) if len(policy.embeddings.obs_shape) == 2 else int(policy.embeddings.vectors.shape[0])
+    want = [("embeddings.weight", (emb, obs_size)), ("embeddings.bias", (emb,))]
+    for name, layers in stacks:
+        for i, lay in enumerate(layers):
+            want.append((f"{name}.{2 * i}.weight", (lay.out_features, lay.in_features)))
+            want.append((f"{name}.{2 * i}.bias", (lay.out_features,)))
+    missing = [k for k, _ in want if k not in state]
+    if missing:
+        raise KeyError(f"update_from_torch: the state has no {missing} (BasicPolicy layout: embeddings, common.0/2/.., action.0/2/.., value.0/2/..)")
+    ts = []
+    for k, shape in want:
+        t = state[k].detach()
+        if tuple(t.shape) != shape:
+            raise ValueError(f"update_from_torch: {k} has shape {tuple(t.shape)}, the policy was built for {shape}")
+        ts.append(t.to(device="cuda", dtype=torch.float32).contiguous())
+    n = (len(ts) - 2) // 2
+    ws = (C.c_void_p * max(n, 1))(*[ts[2 + 2 * i].data_ptr() for i in range(n)])
+    bs = (C.c_void_p * max(n, 1))(*[ts[3 + 2 * i].data_ptr() for i in range(n)])
+    torch.cuda.current_stream().synchronize()
+    _lib.check(_lib.lib().tw_policy_update_device_layers(policy._handle(), C.c_void_p(ts[0].data_ptr()), C.c_void_p(ts[1].data_ptr()), ws, bs, n))
+    torch.cuda.synchronize()
 
 
 def _update_from_torch(self, state) -> "Policy":
