@@ -246,6 +246,14 @@ def test_rccl_exchange_behind_the_c_abi_single_rank(tw, oracle):
         comm.broadcast_policy(gp, root=0)
         coll = tw.collector.PPOCollector(300, 0.99, 0.95, 1)
         want = coll.collect(env, gp, seed=3).to_numpy()                       # merge order
+        # a policy of another depth: its image holds a table of device pointers, which the broadcast must leave this process's own
+        from tests.util import make_deep_policy_arrays
+        gdeep = amd_policy(make_deep_policy_arrays(9, seed=4, emb=32, common=(48, 32), scale=2.0))
+        dwant = coll.collect(env, gdeep, seed=3).to_numpy()
+        comm.broadcast_policy(gdeep, root=0)
+        dgot = coll.collect(env, gdeep, seed=3).to_numpy()
+        for k in dwant:
+            assert np.array_equal(dgot[k], dwant[k]), k
         for kw in ({}, {"chunks": 3, "max_episode_records": 11}, {"step_episodes": 64, "max_episode_records": 11, "reserve_cus": 8}):
             merged, parts = collect_sharded(coll, env, gp, seed=3, comm=comm, **kw)
             assert sum(len(p) for p in parts) == want["obs"].shape[0]

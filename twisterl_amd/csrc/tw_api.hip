@@ -946,6 +946,14 @@ int policy_device_image(tw_policy *p, void **image, size_t *bytes)
     *image = p->arena; *bytes = p->arena_bytes;
     return TW_OK;
 }
+// after the arena was overwritten with another process's image (tw_comm_broadcast_policy): the layer table of a generic stack
+// holds device POINTERS, which are this process's own -- put them back
+int policy_restore_local_tables(tw_policy *p, hipStream_t s)
+{
+    if (!p->dev.generic || p->gen_layers.empty()) return TW_OK;
+    TW_HIP(hipMemcpyAsync(const_cast<LayerDev *>(p->dev.layers), p->gen_layers.data(), p->gen_layers.size() * sizeof(LayerDev), hipMemcpyHostToDevice, s));
+    return TW_OK;
+}
 int collected_describe(const tw_collected *c, int *is_ppo, uint32_t *n_cells, uint32_t *n_actions, uint64_t *n_records, uint64_t *n_episodes)
 {
     if (!c) { set_error("null collected data"); return TW_ERR_INVALID; }

@@ -157,6 +157,7 @@ extern "C" int tw_comm_broadcast_policy(tw_comm *c, tw_policy *p, int root)
     // the collectors' stream may still read the image: the broadcast is ordered behind it and waited for
     hipStream_t s = current_stream();
     TW_NCCL(g_rccl.Broadcast(img, img, bytes, ncclChar, root, c->comm, s));
+    rc = policy_restore_local_tables(p, s); if (rc) return rc;
     TW_HIP(hipStreamSynchronize(s));
     return TW_OK;
 }

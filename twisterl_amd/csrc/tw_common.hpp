@@ -531,6 +531,7 @@ int require_device();
 const PolicyDev *policy_dev(const tw_policy *p);
 void collected_adopt_obs_width(tw_collected *c, uint32_t obs_width);
 int policy_device_image(tw_policy *p, void **image, size_t *bytes);       // the one allocation holding every weight image
+int policy_restore_local_tables(tw_policy *p, hipStream_t s);             // ... and what in it is process-local (pointers)
 int collected_describe(const tw_collected *c, int *is_ppo, uint32_t *n_cells, uint32_t *n_actions, uint64_t *n_records, uint64_t *n_episodes);
 const void *collected_field(const tw_collected *c, int field);
 // wraps device memory the caller allocated with hipMalloc into a result object (which frees it through the arena pool)
