@@ -1,4 +1,4 @@
-"""CPU, world_size 2, 3 and 4 over gloo: the N>1 path of the collector.
+"""CPU, world_size 2, 3, 4 and 8 over gloo: the N>1 path of the collector.
 
 Each rank plays one GPU.  The PRODUCT's sharding and gather logic (twisterl_amd.dist: chunk-major episode ranges,
 count all_gather, point-to-point receives at their final offsets, the E-1 rotation) runs unchanged; only the per-rank
@@ -137,7 +137,8 @@ def _worker(rank, world, port, E, chunks, q):
         raise
 
 
-@pytest.mark.parametrize("world,E,chunks", [(2, 37, 3), (3, 10, 4), (2, 2, 1), (4, 23, 2), (3, 2, 4), (4, 1, 3), (2, 9, 1), (2, 20, 0), (3, 11, 0)])
+@pytest.mark.parametrize("world,E,chunks", [(2, 37, 3), (3, 10, 4), (2, 2, 1), (4, 23, 2), (3, 2, 4), (4, 1, 3), (2, 9, 1), (2, 20, 0), (3, 11, 0),
+                                            (8, 50, 3), (8, 100, 0)])     # the driver's widest run: eight ranks
 def test_sharded_gather_matches_unsharded_merge_order(oracle, world, E, chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
