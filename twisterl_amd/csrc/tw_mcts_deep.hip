@@ -568,13 +568,19 @@ bool mcts_deep_applies(const MctsArgs &a)
 
 // walkers per workgroup: as few as keep every CU busy -- with fewer walkers each one owns more of the forward's columns (4 / 8 /
 // 16 of 16), i.e. more of its tree is evaluated ahead of the search and fewer searches wait for a forward (misses of a demand:
-// 48 % with three columns of look-ahead, about half of that with seven); the reference's default self-play batch is 512 episodes
+// 48 % with three columns of look-ahead, about half of that with seven); the reference's default self-play batch is 512 episodes.
+// More episodes than walkers go through the episode queue in rounds, and up to a point that is still the faster shape (measured,
+// 256 CUs, 100 searches, 1 / 2 / 4 walkers): 384 episodes 12.3 / 13.9 / - ms, 512: 13.9 / 14.0 / -, 768: 21.0 / 15.4 / 19.6,
+// 1,024: - / 16.9 / 19.6, 1,280: 27.8 / 19.7 / 20.4, 1,536: - / 25.3 / 20.7 -- one walker up to 1.5 x CUs, two up to 5 x CUs.
 static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus)
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
     const uint64_t avail = (uint64_t)(cus - r);
-    return num_episodes <= avail ? 1 : (num_episodes <= 2 * avail ? 2 : 4);
+    const int v = launch_options().az_variant;                      // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 pin two / one walker per workgroup
+    if (v == 3) return 2;
+    if (v == 4) return 1;
+    return num_episodes <= avail + avail / 2 ? 1 : (num_episodes <= 5 * avail ? 2 : 4);
 }
 
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus)
