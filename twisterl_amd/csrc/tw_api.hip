@@ -212,7 +212,7 @@ extern "C" int tw_set_launch_option(int option, int value)
             g_force_geom.store(value); return TW_OK;
         case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
         case TW_OPT_AZ_VARIANT:
-            if (value < 0 || value > 4) { set_error("TW_OPT_AZ_VARIANT: value %d not in {0, 1, 2, 3, 4}", value); return TW_ERR_INVALID; }
+            if (value < 0 || (value & 7) > 5 || (value & ~55) != 0 || (value & 48) == 48) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 5} (+ 16 | 32)", value); return TW_ERR_INVALID; }
             g_az_variant.store(value); return TW_OK;
         default: set_error("tw_set_launch_option: unknown option %d", option); return TW_ERR_INVALID;
     }

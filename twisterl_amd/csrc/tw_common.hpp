@@ -480,6 +480,7 @@ struct MctsArgs {
     unsigned int   *queue;
     int32_t         reserve_cus;
     uint32_t        lds_nodes;     // deep shape: nodes per tree whose statistics live in LDS (set by the launcher)
+    uint32_t        tree_budget;   // deep shape: cycles of tree walk per trip after which a walker stops at the next search boundary (launcher)
 };
 size_t mcts_node_bytes();
 // the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue

@@ -42,9 +42,11 @@ constexpr int DEEP_WAVES = 4;            // waves per workgroup; the first NWK (
 constexpr int DEEP_POOL = 40;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
 constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
-constexpr unsigned long long DEEP_TREE_BUDGET = 48000;   // cycles of tree walk per trip after which a walker stops at the next search
-                                                          // boundary (all its columns then carry frontier nodes): the other three
-                                                          // walkers and the engine do not wait for one long streak of stored outputs
+// MctsArgs::tree_budget: cycles of tree walk per trip after which a walker stops at the next search boundary (all its columns
+// then carry frontier nodes): the other walkers and the engine do not wait for one long streak of stored outputs.  Measured
+// (profiles/r02_az_param_sweep.txt; 32,000 / 48,000 / 72,000 / 100,000 cycles): 4,096 x 100 38.9 / 37.3 / 37.9 / 38.6 ms, 1,024 x 100
+// 18.1 / 17.1 / 16.6 / 16.5, 4,096 x 1,000 279 / 233 / 218 / 221, 512 x 1,000 146 / 131 / 126 / 125
+static uint32_t deep_tree_budget(uint32_t num_searches, int walkers) { return (walkers == 4 && num_searches < 256) ? 48000u : 72000u; }
 
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform); }
 __device__ __forceinline__ float    rdlf(float v, int lane_uniform) { return __uint_as_float(rdl(__float_as_uint(v), lane_uniform)); }
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
                 bool need_nn = false;
                 TW_DS(y2);
                 if (!resume) {
-                    if (it != S && __builtin_readcyclecounter() - tree_t0 > DEEP_TREE_BUDGET) { yielded = true; dem_idx = DNONE; break; }
+                    if (it != S && __builtin_readcyclecounter() - tree_t0 > (unsigned long long)a.tree_budget) { yielded = true; dem_idx = DNONE; break; }
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) ------------------------------
                         float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -562,26 +564,40 @@ bool mcts_deep_applies(const MctsArgs &a)
 {
     const int force = launch_options().force_geom;
     if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
-    if (force == 8 || force == 1 || launch_options().az_variant == 2) return false;     // diagnostic: pin the lane-per-episode shapes
+    if (force == 8 || force == 1 || (launch_options().az_variant & 7) == 2) return false;     // diagnostic: pin the lane-per-episode shapes
     return a.num_episodes <= (uint64_t)device_cus() * 16u;
 }
 
-// walkers per workgroup: as few as keep every CU busy -- with fewer walkers each one owns more of the forward's columns (4 / 8 /
-// 16 of 16), i.e. more of its tree is evaluated ahead of the search and fewer searches wait for a forward (misses of a demand:
-// 48 % with three columns of look-ahead, about half of that with seven); the reference's default self-play batch is 512 episodes.
-// More episodes than walkers go through the episode queue in rounds, and up to a point that is still the faster shape (measured,
-// 256 CUs, 100 searches, 1 / 2 / 4 walkers): 384 episodes 12.3 / 13.9 / - ms, 512: 13.9 / 14.0 / -, 768: 21.0 / 15.4 / 19.6,
-// 1,024: - / 16.9 / 19.6, 1,280: 27.8 / 19.7 / 20.4, 1,536: - / 25.3 / 20.7 -- one walker up to 1.5 x CUs, two up to 5 x CUs.
-static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus)
+// Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
+// owns more of the forward's columns, i.e. more of its tree is evaluated ahead of the search and fewer searches wait for a
+// forward (misses of a demand: 38 % with three columns of look-ahead, 22 % with seven, 13 % with fifteen); more episodes than
+// walkers go through the episode queue in rounds.  Beyond four episodes per CU four walkers share the 32-column engine (8
+// columns each: the forward costs 1.45x the 16-column one and serves twice the look-ahead).  Measured (256 CUs, ms per collect,
+// 16-column engine with 1 / 2 / 4 walkers | 32-column engine with 1 / 2 / 4; scripts/az_shape_grid.sh, profiles/r02_az_shape_grid.txt):
+//   100 searches    256 episodes 11.0 13.8 18.6 | 13.0 13.6 16.6     512: 13.8 14.0 19.2 | 16.5 13.9 17.2
+//                   1,024: 23.8 17.1 19.6 | 28.3 17.4 17.8            2,048: 41.2 29.7 22.9 | 48.9 30.1 21.6
+//                   4,096: 75.9 50.9 40.4 | 90.0 51.8 37.4
+//   1,000 searches  512: 134 132 162 | 159 137 150    1,024: 178 154 163 | 209 159 150    4,096: 465 313 243 | 548 330 235
+struct DeepShape { int walkers; bool wide; };
+static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus)
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
     const uint64_t avail = (uint64_t)(cus - r);
-    const int v = launch_options().az_variant;                      // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 pin two / one walker per workgroup
-    if (v == 3) return 2;
-    if (v == 4) return 1;
-    return num_episodes <= avail + avail / 2 ? 1 : (num_episodes <= 5 * avail ? 2 : 4);
+    DeepShape sh;
+    sh.walkers = num_episodes <= avail + avail / 2 ? 1 : (num_episodes <= 4 * avail ? 2 : 4);
+    sh.wide = sh.walkers == 4;
+    // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 / 5 pin two / one / four walkers per workgroup, + 16 / + 32 the 16- / 32-column engine
+    const int v = launch_options().az_variant;
+    if ((v & 7) == 3) sh.walkers = 2;
+    if ((v & 7) == 4) sh.walkers = 1;
+    if ((v & 7) == 5) sh.walkers = 4;
+    if (v & 16) sh.wide = false;
+    if (v & 32) sh.wide = true;
+    if (!(v & 48) && launch_options().force_geom == 32) sh.wide = true;
+    return sh;
 }
+static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus) { return deep_shape(num_episodes, reserve_cus).walkers; }
 
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus)
 {
@@ -606,6 +622,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK)) / ((size_t)NWK * 4);
     if (nl > a.node_cap) nl = a.node_cap;
     b.lds_nodes = (uint32_t)nl;
+    b.tree_budget = deep_tree_budget(a.num_searches, NWK);
     const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK)) * sizeof(float);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
@@ -651,7 +668,7 @@ template <int NT>
 static int launch_deep_nt(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     const int nc = a.env.n_cells;
-    const bool wide = launch_options().force_geom == 32;          // diagnostic: 32 columns (8 per walker) instead of 16 (4 per walker)
+    const bool wide = deep_shape(a.num_episodes, a.reserve_cus).wide;
     if (wide) {
         if (nc <= 4) return launch_deep_geom<NT, 4, -4>(a, s, blocks, threads);
         if (nc <= 9) return launch_deep_geom<NT, 9, -4>(a, s, blocks, threads);
