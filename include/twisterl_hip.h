@@ -77,9 +77,10 @@ int tw_release_cached_memory(void);
 enum {
     TW_OPT_FORCE_GEOM = 0,  /* 8: the 256-episode workgroup shape, 32: the 32-episode shape, 1: small-batch, 0: automatic */
     TW_OPT_NO_PERSIST = 1,  /* 1: never use persistent lanes + episode queue                                               */
+    TW_OPT_AZ_TREE_BUDGET = 3, /* walker kernel: cycles of tree walk per forward before a walker yields; 0: automatic           */
     TW_OPT_AZ_VARIANT = 2   /* self-play with few deep searches: 0 automatic (walker-per-wave kernel where it applies),    */
-                            /* 2 always the lane-per-episode kernel; walker kernel with a pinned shape: 3 / 4 / 5 = two /  */
-                            /* one / four walkers per workgroup, + 16 / + 32 = the 16- / 32-column engine                  */
+                            /* 2 always the lane-per-episode kernel; walker kernel with a pinned shape: 3 / 4 / 5 / 6 =    */
+                            /* two / one / four / eight walkers per workgroup, + 16 / + 32 = the 16- / 32-column engine    */
 };
 int tw_set_launch_option(int option, int value);
 

@@ -3,8 +3,10 @@
 set -e
 out=$PWD/gpurun_out/azst; mkdir -p $out
 TW_ABLATE=1 python3 -m twisterl_amd.build --force > $out/build.log 2>&1 || { tail -20 $out/build.log; exit 1; }
-for cfg in "1024 100" "4096 100"; do
-  set -- $cfg
-  echo "== $1 x $2"
-  TW_STAMPS=1 python3 scripts/bench_az.py --envs $1 --searches $2 --steps 1 2>&1 | grep -v amdgpu.ids | tail -4 | tee -a $out/stamps.log
+# AZ_VARIANTS: TW_OPT_AZ_VARIANT values to stamp (default: the automatic shape); AZ_SEARCHES: searches per move
+for E in 1024 4096; do
+  for v in ${AZ_VARIANTS:-0}; do
+    echo "== $E x ${AZ_SEARCHES:-100}, variant $v" | tee -a $out/stamps.log
+    TW_STAMPS=1 python3 scripts/bench_az.py --envs $E --searches ${AZ_SEARCHES:-100} --steps 1 --variant $v 2>&1 | grep -v amdgpu.ids | tail -4 | tee -a $out/stamps.log
+  done
 done

@@ -492,6 +492,7 @@ def _assert_same_az(g, o, n_cells):
     (3, 3, 3, 32, 128, 400, 10, 1, False),   #   two walkers per workgroup (1.5 to 4 episodes per CU), 8 columns each
     (3, 3, 4, 64, 256, 700, 8, 1, True),     #   two walkers per workgroup and the episode queue
     (3, 3, 4, 64, 256, 1300, 5, 1, True),    #   four walkers per workgroup on the 32-column engine (more than 4 episodes per CU), 8 columns each
+    (3, 3, 3, 32, 128, 3300, 4, 2, True),    #   eight walkers per workgroup (more than 12 episodes per CU, short searches), 4 columns each
 ])
 def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
     n2 = w * h
@@ -685,10 +686,10 @@ def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, h
 
 def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_busy(tw, oracle):
     """tw_mcts_deep.hip: one walker x 16 columns per workgroup up to 1.5 episodes per CU, two x 8 up to four, beyond that four x 8
-    on the 32-column engine (and at most one workgroup per CU: the rest of the episodes comes off the queue).  The parity cases
-    of test_az_collect_bit_exact_vs_oracle run all three; this pins the launches the workgroup count tells apart, and every
-    pinned shape (TW_OPT_AZ_VARIANT: 4 / 3 / 5 = one / two / four walkers, + 16 / + 32 = 16- / 32-column engine) gives the same
-    bytes as the automatic choice."""
+    on the 32-column engine, beyond twelve (short searches) eight x 4 in workgroups of eight waves (and at most one workgroup per
+    CU: the rest of the episodes comes off the queue).  The parity cases of test_az_collect_bit_exact_vs_oracle run all of them;
+    this pins the launches the workgroup shape tells apart, and every pinned shape (TW_OPT_AZ_VARIANT: 4 / 3 / 5 / 6 = one /
+    two / four / eight walkers, + 16 / + 32 = 16- / 32-column engine) gives the same bytes as the automatic choice."""
     import twisterl_amd
     cus = twisterl_amd.device_info()["compute_units"]
     gp, _ = _pair(oracle, 9, 2, 32, 128)
@@ -696,10 +697,12 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
     for E, want in ((cus // 2, cus // 2), (cus, cus), (cus + cus // 2, cus), (cus + 3 * cus // 4, (cus + 3 * cus // 4 + 1) // 2), (3 * cus, cus), (6 * cus, cus)):
         d = tw.collector.AZCollector(E, 4, 1.41, 1, 1).collect(env, gp, seed=3)
         assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == (want, 256), (E, d.stats["rollout_blocks"], want)
+    d = tw.collector.AZCollector(13 * cus, 4, 1.41, 1, 1).collect(env, gp, seed=3)
+    assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == (cus, 512)
     E = 3 * cus
     auto = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
     from twisterl_amd import _lib
-    for variant in (16 + 4, 16 + 3, 16 + 5, 32 + 4, 32 + 3, 32 + 5):
+    for variant in (16 + 4, 16 + 3, 16 + 5, 32 + 4, 32 + 3, 32 + 5, 32 + 6):
         with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, variant):
             pinned = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
         for k in auto:

@@ -45,8 +45,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 hipStream_t current_stream() { return g_stream; }
 
 // ---------------------------------------------------------------------------------- launch options / per-device caches
-static std::atomic<int> g_force_geom{0}, g_no_persist{0}, g_az_variant{0};
-LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load(), g_az_variant.load()}; }
+static std::atomic<int> g_force_geom{0}, g_no_persist{0}, g_az_variant{0}, g_az_tree_budget{0};
+LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load(), g_az_variant.load(), g_az_tree_budget.load()}; }
 
 static std::mutex g_dev_mutex;
 
@@ -212,8 +212,11 @@ extern "C" int tw_set_launch_option(int option, int value)
             g_force_geom.store(value); return TW_OK;
         case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
         case TW_OPT_AZ_VARIANT:
-            if (value < 0 || (value & 7) > 5 || (value & ~55) != 0 || (value & 48) == 48) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 5} (+ 16 | 32)", value); return TW_ERR_INVALID; }
+            if (value < 0 || (value & 7) > 6 || (value & ~55) != 0 || (value & 48) == 48) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32)", value); return TW_ERR_INVALID; }
             g_az_variant.store(value); return TW_OK;
+        case TW_OPT_AZ_TREE_BUDGET:
+            if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }
+            g_az_tree_budget.store(value); return TW_OK;
         default: set_error("tw_set_launch_option: unknown option %d", option); return TW_ERR_INVALID;
     }
 }
@@ -1212,7 +1215,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     ma.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
     // few, deep searches: the walker-per-wave shape (tw_mcts_deep.hip) -- always persistent, 64-byte nodes, one arena per walker
     const bool deep = mcts_deep_applies(ma);
-    const uint64_t resident = deep ? mcts_deep_walkers(E, ma.reserve_cus) : f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
+    const uint64_t resident = deep ? mcts_deep_walkers(E, ma.reserve_cus, ma.num_searches) : f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
     const bool persist = deep || (E > resident && !launch_options().no_persist && !ma.pol.generic);
     const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),

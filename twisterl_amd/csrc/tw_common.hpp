@@ -30,7 +30,7 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
 hipStream_t current_stream();
 
 // Diagnostic launch overrides (tw_set_launch_option; the tests pin launch shapes with them).  Read once per collect.
-struct LaunchOptions { int force_geom; int no_persist; int az_variant; };
+struct LaunchOptions { int force_geom; int no_persist; int az_variant; int az_tree_budget; };
 LaunchOptions launch_options();
 // Raises a kernel's dynamic-LDS limit above the 64 KiB default; cached per (kernel, device), thread-safe.
 int ensure_dynamic_lds(const void *kernel, size_t bytes);
@@ -485,7 +485,7 @@ struct MctsArgs {
 size_t mcts_node_bytes();
 // the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue
 bool     mcts_deep_applies(const MctsArgs &a);
-uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus);   // tree arenas = episodes in flight
+uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches);   // tree arenas = episodes in flight
 size_t   mcts_deep_node_bytes();
 int      launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);

@@ -504,6 +504,21 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
         }
     }
 
+    // A wave of the workgroup beyond the NS engine waves (self-play walkers, tw_mcts_deep.hip): it holds no engine state and
+    // takes part in a forward only through the workgroup barriers -- one in the prologue, one per step, two in the heads.
+    __device__ __forceinline__ void begin_idle(const PolicyDev &p)
+    {
+        this->pol = p;
+        this->tid = threadIdx.x; this->lane = this->tid & 63; this->wave = __builtin_amdgcn_readfirstlane(this->tid >> 6);
+        this->j = this->lane & 31; this->h = this->lane >> 5;
+        this->n_chunks = this->pol.emb / KC;
+        n3 = (this->n_chunks + 2) / 3 * 3;
+    }
+    __device__ __forceinline__ void idle_forward() const
+    {
+        for (int i = 0; i < n3 + 3; ++i) __builtin_amdgcn_s_barrier();
+    }
+
     template <int S, int OP>   // DMA op OP of this wave: a piece of the chunk streamed next into ring slot S
     __device__ __forceinline__ void stream() const
     {

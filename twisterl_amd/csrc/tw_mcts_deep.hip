@@ -38,7 +38,8 @@ static_assert(sizeof(DeepNode) == 64, "DeepNode must be 64 bytes");
 size_t mcts_deep_node_bytes() { return sizeof(DeepNode); }
 
 constexpr uint32_t DNONE = 0xffffffffu;
-constexpr int DEEP_WAVES = 4;            // waves per workgroup; the first NWK (4, 2 or 1) are walkers, all four run the forward
+constexpr int DEEP_WAVES = 4;            // waves that run the forward; the first NWK (1, 2, 4) of them are walkers -- or, with NWK = 8 on the
+                                         // 32-column engine, four more waves that only walk (eight waves per workgroup, two per SIMD)
 constexpr int DEEP_POOL = 40;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
 constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
@@ -46,7 +47,12 @@ enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
 // then carry frontier nodes): the other walkers and the engine do not wait for one long streak of stored outputs.  Measured
 // (profiles/r02_az_param_sweep.txt; 32,000 / 48,000 / 72,000 / 100,000 cycles): 4,096 x 100 38.9 / 37.3 / 37.9 / 38.6 ms, 1,024 x 100
 // 18.1 / 17.1 / 16.6 / 16.5, 4,096 x 1,000 279 / 233 / 218 / 221, 512 x 1,000 146 / 131 / 126 / 125
-static uint32_t deep_tree_budget(uint32_t num_searches, int walkers) { return (walkers == 4 && num_searches < 256) ? 48000u : 72000u; }
+static uint32_t deep_tree_budget(uint32_t num_searches, int walkers)
+{
+    const int pinned = launch_options().az_tree_budget;             // diagnostic (TW_OPT_AZ_TREE_BUDGET)
+    if (pinned > 0) return (uint32_t)pinned;
+    return (walkers >= 4 && num_searches < 256) ? 48000u : 72000u;
+}
 
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform); }
 __device__ __forceinline__ float    rdlf(float v, int lane_uniform) { return __uint_as_float(rdl(__float_as_uint(v), lane_uniform)); }
@@ -59,7 +65,7 @@ __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >
 // floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | pool idx [POOL] | pool outputs [POOL][8]
 __host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers)
 {
-    return (size_t)columns * 10 + 8 + (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);   // (+ 8: the walkers' alive flags)
+    return (size_t)columns * 10 + 16 + (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);   // (+ 16: the walkers' alive flags)
 }
 
 #ifdef TW_ABLATE
@@ -68,7 +74,7 @@ __device__ unsigned long long g_deep_extra[4];
 #endif
 
 template <int NT, int NC, int NW, int NWK>
-__global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
+__global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(const MctsArgs a)
 {
     using Eng = typename Geom<NT, NC, 0, NW>::Eng;
     typedef unsigned int ux4 __attribute__((ext_vector_type(4)));
@@ -78,10 +84,17 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     typedef __attribute__((address_space(3))) float lds_f32;
     constexpr int C = Eng::EPB, CPW = C / NWK;             // MFMA columns of the workgroup, columns per walker
-    static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WAVES && NWK >= 1 && NWK <= DEEP_WAVES && CPW >= 2 && CPW <= 64, "one walker per wave");
+    constexpr int TWV = NWK > DEEP_WAVES ? NWK : DEEP_WAVES;   // waves per workgroup
+    static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WAVES && NWK >= 1 && NWK <= 8 && CPW >= 2 && CPW <= 64, "one walker per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
-    eng.begin1(a.pol, lds);
+    bool engw = true;                                          // this wave runs the forward
+    if constexpr (TWV > DEEP_WAVES) {
+        engw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < DEEP_WAVES;
+        if (engw) eng.begin1(a.pol, lds); else eng.begin_idle(a.pol);
+    } else {
+        eng.begin1(a.pol, lds);
+    }
 
     const PuzzleConsts env = a.env;
     const int lane = eng.lane, wave = eng.wave;
@@ -91,8 +104,8 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     uint2 *req = reinterpret_cast<uint2 *>(xbase);                               // request boards [C]
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
     const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
-    int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][4 waves]: walker still has an episode
-    float *wbase = res + 8 * C + 8 + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
+    int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][TWV waves]: walker still has an episode
+    float *wbase = res + 8 * C + 16 + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
     lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 4);                         // pool: node index (DNONE = free)
     lds_f32 *pout = (lds_f32 *)(wbase + (size_t)NL * 4 + DEEP_POOL);             // pool: probs[4], value, - - -
@@ -151,7 +164,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
     if (walker && slot < E) take(slot);
     if (walker && lane < DEEP_POOL) pidx[lane] = DNONE;
     if (!walker) more = false;
-    if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[4 + wave] = phase != DP_DEAD ? 1 : 0; }
+    if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[TWV + wave] = phase != DP_DEAD ? 1 : 0; }
     __syncthreads();
 
     uint32_t obs_base[4];
@@ -167,12 +180,12 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         my_take = false; n_spec = 0;
         // publish whether this walker still has an episode (read by everybody one trip later: a walker that ran out THIS trip
         // keeps its columns for one more forward and fills them with the identity board)
-        if (lane == 0) alive_f[(trip & 1u) * 4 + wave] = (walker && phase != DP_DEAD) ? 1 : 0;
-        const int *af = alive_f + ((trip & 1u) ^ 1u) * 4;
+        if (lane == 0) alive_f[(trip & 1u) * TWV + wave] = (walker && phase != DP_DEAD) ? 1 : 0;
+        const int *af = alive_f + ((trip & 1u) ^ 1u) * TWV;
         ++trip;
         int n_alive = 0, rank_me = 0;
 #pragma unroll
-        for (int w = 0; w < DEEP_WAVES; ++w) { const int f = uni(af[w]); rank_me += (w < wave) ? f : 0; n_alive += f; }
+        for (int w = 0; w < TWV; ++w) { const int f = uni(af[w]); rank_me += (w < wave) ? f : 0; n_alive += f; }
         const bool mine = walker && uni(af[wave]) != 0;
         if (!mine) { my_share = 0; return; }
         my_share = C / n_alive; my_base = rank_me * my_share;
@@ -217,7 +230,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         spec_evals += (unsigned long long)n_take;
     };
 
-    eng.begin2();
+    if (engw) eng.begin2();
     assemble();
 
 #ifdef TW_ABLATE
@@ -235,7 +248,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         TW_DS(z1);
         TW_DA(c_bar, z0, z1);
         // ---- Policy::full_predict of the C requested boards (policy.rs:102-126) -------------------------------------
-        {
+        if (engw) {
             const uint2 rb = req[col];
             const uint64_t board = ((uint64_t)rb.y << 32) | rb.x;
             float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
@@ -263,16 +276,26 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
             lf.zx = z % env.width; lf.zy = z / env.width;
             float probs[4];
             masked_softmax4(lsum, puzzle_maskbits(lf, env), probs);
-            // every wave holds every column's output: wave w publishes the columns of walker w, for itself
-            if (eng.h == 0 && col >= my_base && col < my_base + my_share) {
+            // every engine wave holds every column's output: wave w publishes the columns of walker w, for itself -- or, when
+            // there are walkers beyond the engine waves, every fourth column for everybody
+            const bool pub = TWV > DEEP_WAVES ? (col & 3) == wave : (col >= my_base && col < my_base + my_share);
+            if (eng.h == 0 && pub) {
                 float4 *dst = reinterpret_cast<float4 *>(res + col * 8);
                 dst[0] = make_float4(probs[0], probs[1], probs[2], probs[3]);
                 dst[1] = make_float4(vsum, 0.0f, 0.0f, 0.0f);
             }
+        } else if constexpr (TWV > DEEP_WAVES) {
+            // a wave that only walks: the barriers of the forwards the engine waves run (nothing else synchronises in there)
+            const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
+            for (int pass = 0; pass < n_pass; ++pass) eng.idle_forward();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (TWV > DEEP_WAVES) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         TW_DS(z2);
         TW_DA(c_fwd, z1, z2);
 #ifdef TW_ABLATE
@@ -548,7 +571,7 @@ __global__ void __launch_bounds__(256, 1) mcts_deep_kernel(const MctsArgs a)
         atomicAdd(&g_deep_stamps[11], c_bp); atomicAdd(&g_deep_stamps[12], c_fin); atomicAdd(&g_deep_stamps[13], c_res); atomicAdd(&g_deep_stamps[14], c_lvl);
     }
 #endif
-    eng.end();
+    if (engw) eng.end();
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
@@ -565,6 +588,7 @@ bool mcts_deep_applies(const MctsArgs &a)
     const int force = launch_options().force_geom;
     if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
     if (force == 8 || force == 1 || (launch_options().az_variant & 7) == 2) return false;     // diagnostic: pin the lane-per-episode shapes
+    if ((launch_options().az_variant & 7) >= 3) return true;                              // diagnostic: a pinned walker shape, whatever the batch
     return a.num_episodes <= (uint64_t)device_cus() * 16u;
 }
 
@@ -572,38 +596,43 @@ bool mcts_deep_applies(const MctsArgs &a)
 // owns more of the forward's columns, i.e. more of its tree is evaluated ahead of the search and fewer searches wait for a
 // forward (misses of a demand: 38 % with three columns of look-ahead, 22 % with seven, 13 % with fifteen); more episodes than
 // walkers go through the episode queue in rounds.  Beyond four episodes per CU four walkers share the 32-column engine (8
-// columns each: the forward costs 1.45x the 16-column one and serves twice the look-ahead).  Measured (256 CUs, ms per collect,
+// columns each: the forward costs 1.45x the 16-column one and serves twice the look-ahead); beyond twelve, with short searches,
+// EIGHT walkers do (four waves that only walk beside the four that also run the forward, two waves per SIMD, 4 columns each:
+// 4,096 x 100 34.3 ms against 38.5, 3,072 x 100 30.9 / 31.2, 4,096 x 1,000 236 / 229 -- the kernel then has 256 registers per
+// lane instead of 512 and a third of the tree statistics in LDS).  Measured (256 CUs, ms per collect,
 // 16-column engine with 1 / 2 / 4 walkers | 32-column engine with 1 / 2 / 4; scripts/az_shape_grid.sh, profiles/r02_az_shape_grid.txt):
 //   100 searches    256 episodes 11.0 13.8 18.6 | 13.0 13.6 16.6     512: 13.8 14.0 19.2 | 16.5 13.9 17.2
 //                   1,024: 23.8 17.1 19.6 | 28.3 17.4 17.8            2,048: 41.2 29.7 22.9 | 48.9 30.1 21.6
 //                   4,096: 75.9 50.9 40.4 | 90.0 51.8 37.4
 //   1,000 searches  512: 134 132 162 | 159 137 150    1,024: 178 154 163 | 209 159 150    4,096: 465 313 243 | 548 330 235
 struct DeepShape { int walkers; bool wide; };
-static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus)
+static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num_searches)
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
     const uint64_t avail = (uint64_t)(cus - r);
     DeepShape sh;
     sh.walkers = num_episodes <= avail + avail / 2 ? 1 : (num_episodes <= 4 * avail ? 2 : 4);
-    sh.wide = sh.walkers == 4;
+    if (num_episodes > 12 * avail && num_searches < 256) sh.walkers = 8;
+    sh.wide = sh.walkers >= 4;
     // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 / 5 pin two / one / four walkers per workgroup, + 16 / + 32 the 16- / 32-column engine
     const int v = launch_options().az_variant;
     if ((v & 7) == 3) sh.walkers = 2;
     if ((v & 7) == 4) sh.walkers = 1;
     if ((v & 7) == 5) sh.walkers = 4;
-    if (v & 16) sh.wide = false;
+    if ((v & 7) == 6) { sh.walkers = 8; sh.wide = true; }
+    if ((v & 16) && sh.walkers != 8) sh.wide = false;
     if (v & 32) sh.wide = true;
     if (!(v & 48) && launch_options().force_geom == 32) sh.wide = true;
     return sh;
 }
-static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus) { return deep_shape(num_episodes, reserve_cus).walkers; }
+static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus, uint32_t num_searches) { return deep_shape(num_episodes, reserve_cus, num_searches).walkers; }
 
-uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus)
+uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches)
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
-    const uint64_t nwk = (uint64_t)deep_walkers_per_group(num_episodes, reserve_cus);
+    const uint64_t nwk = (uint64_t)deep_walkers_per_group(num_episodes, reserve_cus, num_searches);
     const uint64_t blocks = (num_episodes + nwk - 1) / nwk;
     return (blocks < (uint64_t)(cus - r) ? blocks : (uint64_t)(cus - r)) * nwk;
 }
@@ -613,7 +642,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
 {
     using G = Geom<NT, NC, 0, NW>;
     constexpr int C = G::Eng::EPB;
-    const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus) / NWK;
+    const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus, a.num_searches) / NWK;
     // the hot quads of the first lds_nodes nodes of every tree live in LDS: as many as fit beside the engine
     MctsArgs b = a;
     const size_t eng_floats = G::Eng::lds_floats(a.pol.obs_size);
@@ -629,7 +658,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     unsigned long long zeros[16] = {0};
     if (getenv("TW_STAMPS")) { TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros))); TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_extra), zeros, 32)); }
 #endif
-    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK>), dim3((unsigned)nb), dim3(256), lds_bytes, s, b);
+    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK>), dim3((unsigned)nb), dim3(NWK > DEEP_WAVES ? 64 * NWK : 64 * DEEP_WAVES), lds_bytes, s, b);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
@@ -650,16 +679,17 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     }
 #endif
     if (blocks) *blocks = (uint32_t)nb;
-    if (threads) *threads = 256;
+    if (threads) *threads = NWK > DEEP_WAVES ? 64 * NWK : 64 * DEEP_WAVES;
     return TW_OK;
 }
 
 template <int NT, int NC, int NW>
 static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    switch (deep_walkers_per_group(a.num_episodes, a.reserve_cus)) {
+    switch (deep_walkers_per_group(a.num_episodes, a.reserve_cus, a.num_searches)) {
         case 1: return launch_deep_nwk<NT, NC, NW, 1>(a, s, blocks, threads);
         case 2: return launch_deep_nwk<NT, NC, NW, 2>(a, s, blocks, threads);
+        case 8: if constexpr (NW == -4) return launch_deep_nwk<NT, NC, NW, 8>(a, s, blocks, threads);     // (32-column engine only)
         default: return launch_deep_nwk<NT, NC, NW, 4>(a, s, blocks, threads);
     }
 }
@@ -668,7 +698,7 @@ template <int NT>
 static int launch_deep_nt(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     const int nc = a.env.n_cells;
-    const bool wide = deep_shape(a.num_episodes, a.reserve_cus).wide;
+    const bool wide = deep_shape(a.num_episodes, a.reserve_cus, a.num_searches).wide;
     if (wide) {
         if (nc <= 4) return launch_deep_geom<NT, 4, -4>(a, s, blocks, threads);
         if (nc <= 9) return launch_deep_geom<NT, 9, -4>(a, s, blocks, threads);
