@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/r02; mkdir -p $out
 python3 bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/bench.err
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $out/stats -o s -f csv -- python3 $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/stats.log 2>&1)
-for cfg in "256 100 8" "512 100 8" "512 1000 8" "4096 100 8" "4096 1000 8" "1024 100 8" "1024 1000 8" "16384 32 4" "65536 32 4" "262144 32 4"; do set -- $cfg
+for cfg in "256 100 8" "512 100 8" "512 1000 8" "1024 100 8" "1024 1000 8" "2048 100 8" "4096 100 8" "4096 1000 8" "6144 100 8" "16384 32 4" "65536 32 4" "262144 32 4"; do set -- $cfg
   python3 scripts/bench_az.py --envs $1 --searches $2 --difficulty $3 --steps 2 2>/dev/null | grep metric >> $out/az_batches.jsonl
 done
 python3 scripts/bench_az.py --envs 4096 --searches 100 --variant 2 --steps 2 2>/dev/null | grep metric > $out/az_4096x100_lane_per_episode.json

@@ -9,7 +9,7 @@
 // an episode of 17 moves x 101 evaluations is 1,717 dependent (tree walk -> policy forward) steps however many episodes run
 // beside it.  The lane-per-episode kernel pays one whole forward (~45k cycles for the 16 MFMA columns of a workgroup) plus
 // the slowest lane's tree walk for each of them -- while 2/3 of the columns belong to episodes that are already over.
-// Here a workgroup runs only FOUR episodes at a time on the same 16 (or 32) columns:
+// Here a workgroup runs only ONE to EIGHT episodes at a time (deep_shape below) on the 16 or 32 columns of a forward; with four:
 //   * column 0 of a walker's share carries the leaf its search is blocked on (the "demand"), the other 3 (7) columns
 //     carry nodes of its tree that exist but have not been evaluated, in creation order -- UCB with an untrained
 //     (flat) prior visits nodes nearly breadth-first, so 60 % (77 %) of the later demands find their network output already
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         TW_DA(c_fwd, z1, z2);
 #ifdef TW_ABLATE
         ++c_trips;
-        if (phase == DP_DEAD) ++c_dead; else if (yielded) ++c_yield; else if (phase == DP_ROOT) ++c_root;
+        if (phase == DP_DEAD) { if (walker) ++c_dead; } else if (yielded) ++c_yield; else if (phase == DP_ROOT) ++c_root;
         c_nspec += (unsigned long long)n_spec;
 #endif
 
@@ -575,13 +575,14 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
-// The deep shape serves AlphaZero self-play of up to CUs x 16 episodes (4,096 on an MI355X: the reference's per-GPU batch) on
-// policies the 16-episode engine supports (128 or 256 hidden units); everything else runs the lane-per-episode kernel of
-// tw_mcts.hip.  Measured (scripts/bench_az.py, Puzzle-15, 512/256 policy; walker kernel vs lane-per-episode kernel):
-//   1,024 x 100: 21.8 vs 48.9 ms    1,024 x 1,000: 211 vs 498 ms    4,096 x 100: 46.3 vs 47.3 ms    4,096 x 1,000: 319 vs 509 ms
-//   8,192 x 32: 11.5 vs 9.5 ms      16,384 x 32: 20.7 vs 12.1 ms    32,768 x 32: 39.5 vs 20.3 ms
-// One episode's chain of searches runs 2.2x faster here (about 2.2 evaluations per forward instead of one), but only
-// CUs x 4 episodes are in flight: beyond CUs x 16 episodes the lane-per-episode kernel's 16+ columns of distinct episodes win.
+// The deep shape serves AlphaZero self-play of up to CUs x 16 episodes (4,096 on an MI355X: the reference's per-GPU batch; CUs x
+// 24 from 100 searches per move on) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
+// runs the lane-per-episode kernel of tw_mcts.hip.  Measured (scripts/bench_az.py, Puzzle-15, 512/256 policy, difficulty 8;
+// walker kernel vs lane-per-episode kernel, end of round 2):
+//   1,024 x 100: 16.6 vs 48.9 ms    1,024 x 1,000: 146 vs 498 ms    4,096 x 100: 34.2 vs 42.3 ms    4,096 x 1,000: 227 vs 509 ms
+//   6,144 x 100: 47.2 vs 60.4 ms    8,192 x 100: 61.5 vs 60.9 ms    8,192 x 32: 24.8 vs 17.8 ms
+// One episode's chain of searches runs about 3x faster here (2 - 3 evaluations consumed per forward and walker instead of one),
+// but at most CUs x 8 episodes are in flight: beyond that many the lane-per-episode kernel's 16+ columns of distinct episodes win.
 
 bool mcts_deep_applies(const MctsArgs &a)
 {
@@ -589,7 +590,8 @@ bool mcts_deep_applies(const MctsArgs &a)
     if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
     if (force == 8 || force == 1 || (launch_options().az_variant & 7) == 2) return false;     // diagnostic: pin the lane-per-episode shapes
     if ((launch_options().az_variant & 7) >= 3) return true;                              // diagnostic: a pinned walker shape, whatever the batch
-    return a.num_episodes <= (uint64_t)device_cus() * 16u;
+    // (6,144 x 100: 47.2 ms with eight walkers per workgroup against 60.4 lane-per-episode; 8,192 x 100: 61.5 / 60.9; 8,192 x 32: 24.8 / 17.8)
+    return a.num_episodes <= (uint64_t)device_cus() * (a.num_searches >= 100 ? 24u : 16u);
 }
 
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
