@@ -42,15 +42,20 @@ for E, rep in ((1024, 4 * n), (4096, 4 * n), (8000, 2 * n), (20000, 2 * n)):
             if ref is None: ref = dg
             elif dg != ref: bad += 1
         print("fp32 small E", E, "difficulty", env.difficulty, "repeats", rep, "mismatching repeats", bad, flush=True)
-for E, S, rep in ((1024, 50, n), (4096, 30, n), (20000, 16, n), (70000, 8, max(2, n // 3))):
-    env = twisterl.env.Puzzle(4, 4, 4, 2, 256)
+# (walker kernel: 256 episodes = one walker per workgroup, 800 / 1,024 two, 2,000 four on the 32-column engine, 4,096 and 6,000 x 100
+#  eight in eight-wave workgroups; 20,000 and 70,000: lane-per-episode kernel)
+for E, S, rep, p in ((256, 60, n, pol0), (800, 40, n, pol), (1024, 50, n, pol0), (2000, 40, n, pol), (4096, 30, n, pol0), (4096, 100, n, pol),
+                     (6000, 100, max(2, n // 2), pol0), (20000, 16, n, pol0), (70000, 8, max(2, n // 3), pol0)):
+    env = twisterl.env.Puzzle(4, 4, 4 if S < 100 else 8, 2, 256)
     coll = twisterl.collector.AZCollector(E, S, 1.41, 1, 1)
     ref = None; bad = 0
     for i in range(rep):
-        dg = digest(coll.collect(env, pol0, seed=7))
+        d = coll.collect(env, p, seed=7)
+        dg = digest(d)
         if ref is None: ref = dg
         elif dg != ref: bad += 1
-    print("self-play E", E, "searches", S, "repeats", rep, "mismatching repeats", bad, flush=True)
+    print("self-play E", E, "searches", S, "twists" if p is pol else "no twists", "launch", d.stats["rollout_blocks"], "x", d.stats["rollout_threads"],
+          "repeats", rep, "mismatching repeats", bad, flush=True)
 # policies of any depth (EngineV: inline-asm MFMA chains, weights and activations prefetched through running pointers)
 from tests.util import amd_policy, make_deep_policy_arrays
 for kw, E, rep in ((dict(emb=508, common=(256,)), 65536, n), (dict(emb=512, common=(256, 256), policy_layers=(64,), value_layers=(64,)), 20000, n),
