@@ -22,20 +22,21 @@
 //     expanded by four lanes, the search path lives one level per lane (back-propagation is ONE store instruction);
 //   * workgroups are persistent: a walker whose episode is over takes the next one from the queue (start boards from
 //     init_boards_kernel), its tree arena is reused.
-// A 64-byte node record (DeepNode) holds the statistics, the board and the stored network output.
+// 64 bytes per node in the walker's arena, as separate arrays: statistics (touched only beyond the nodes kept in LDS), boards,
+// and the stored network outputs (written once and read at most once -- non-temporal): what a walk re-reads stays small enough
+// for the weights and the trees of the 32 CUs of an XCD to share its 4 MB L2 (eight walkers per CU: 105 M L2 misses per
+// 4,096 x 100 collect with 64-byte node records, scripts/pmc_az_l2.sh).
 #include "tw_engine.hpp"
 
 namespace tw {
 
-struct __attribute__((aligned(16))) DeepNode {
-    uint4 q0;   // HOT quad: value_sum (f32 bits), visit_count, prior (f32 bits), link = child_base | n_children << 24 | action << 27 | has_output << 29
-                //           -- for the first `lds_nodes` nodes of a tree this quad lives in LDS instead (same layout)
-    uint4 q1;   // board.lo, board.hi, parent, depth
-    uint4 q2;   // masked-softmax probs[4] of full_predict (f32 bits), once evaluated ahead of the search
-    uint4 q3;   // network value (f32 bits), 0, 0, 0
-};
-static_assert(sizeof(DeepNode) == 64, "DeepNode must be 64 bytes");
-size_t mcts_deep_node_bytes() { return sizeof(DeepNode); }
+// arena of one walker: uint4 hot[node_cap] | uint4 brd[node_cap] | uint4 out[node_cap][2]
+//   hot: value_sum (f32 bits), visit_count, prior (f32 bits), link = child_base | n_children << 24 | action << 27 | has_output << 29
+//        -- for the first `lds_nodes` nodes of a tree this quad lives in LDS instead (same layout), its arena slot is never touched
+//   brd: board.lo, board.hi, parent, depth
+//   out: masked-softmax probs[4] of full_predict (f32 bits) | network value (f32 bits), 0, 0, 0 -- once evaluated ahead of the search
+constexpr size_t DEEP_NODE_BYTES = 64;
+size_t mcts_deep_node_bytes() { return DEEP_NODE_BYTES; }
 
 constexpr uint32_t DNONE = 0xffffffffu;
 constexpr int DEEP_WAVES = 4;            // waves that run the forward; the first NWK (1, 2, 4) of them are walkers -- or, with NWK = 8 on the
@@ -65,7 +66,9 @@ __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >
 // floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | pool idx [POOL] | pool outputs [POOL][8]
 __host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers)
 {
-    return (size_t)columns * 10 + 16 + (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);   // (+ 16: the walkers' alive flags)
+    // (+ 16: the walkers' alive flags; eight walkers: + 64 dwords each, where the wave-uniform walker state waits during a forward)
+    return (size_t)columns * 10 + 16 + (walkers > DEEP_WAVES ? (size_t)walkers * 64 : 0) +
+           (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);
 }
 
 #ifdef TW_ABLATE
@@ -105,7 +108,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
     const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
     int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][TWV waves]: walker still has an episode
-    float *wbase = res + 8 * C + 16 + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
+    float *park_base = res + 8 * C + 16;                                         // [TWV][64] parked walker state (eight-walker shape)
+    float *wbase = park_base + (TWV > DEEP_WAVES ? TWV * 64 : 0) + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
     lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 4);                         // pool: node index (DNONE = free)
     lds_f32 *pout = (lds_f32 *)(wbase + (size_t)NL * 4 + DEEP_POOL);             // pool: probs[4], value, - - -
@@ -113,19 +117,22 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     const uint64_t E = a.num_episodes;
     const uint64_t slot = (uint64_t)blockIdx.x * NWK + (uint64_t)(walker ? wave : 0);     // walker = tree arena index
-    DeepNode *nodes = reinterpret_cast<DeepNode *>(a.arena) + slot * (uint64_t)a.node_cap;
+    uint8_t *arena_w = reinterpret_cast<uint8_t *>(a.arena) + slot * (uint64_t)a.node_cap * DEEP_NODE_BYTES;
+    ux4   *hotq = reinterpret_cast<ux4 *>(arena_w);                                   // [node_cap] statistics
+    uint4 *brdq = reinterpret_cast<uint4 *>(arena_w + (size_t)a.node_cap * 16);       // [node_cap] boards
+    ux4   *outs = reinterpret_cast<ux4 *>(arena_w + (size_t)a.node_cap * 32);         // [node_cap][2] outputs
 
     // hot quad of node idx: LDS for the first NL nodes of the tree, the arena beyond
-    auto hot_ld = [&](uint32_t idx) -> ux4 { if (idx < NL) return tbl[idx]; return *reinterpret_cast<const ux4 *>(&nodes[idx].q0); };
-    auto hot_st = [&](uint32_t idx, ux4 v) { if (idx < NL) tbl[idx] = v; else *reinterpret_cast<ux4 *>(&nodes[idx].q0) = v; };
+    auto hot_ld = [&](uint32_t idx) -> ux4 { if (idx < NL) return tbl[idx]; return hotq[idx]; };
+    auto hot_st = [&](uint32_t idx, ux4 v) { if (idx < NL) tbl[idx] = v; else hotq[idx] = v; };
     auto hot_st_stats = [&](uint32_t idx, float vs, uint32_t vis) {                // value_sum, visit_count: one 8-byte store
         ux2 w; w.x = __float_as_uint(vs); w.y = vis;
         if (idx < NL) *reinterpret_cast<lds_u2 *>(tbl + idx) = w;
-        else *reinterpret_cast<ux2 *>(&nodes[idx].q0) = w;
+        else *reinterpret_cast<ux2 *>(hotq + idx) = w;
     };
     auto hot_st_link = [&](uint32_t idx, uint32_t link) {
         if (idx < NL) reinterpret_cast<lds_u32 *>(tbl + idx)[3] = link;
-        else reinterpret_cast<uint32_t *>(&nodes[idx].q0)[3] = link;
+        else reinterpret_cast<uint32_t *>(hotq + idx)[3] = link;
     };
 
     // ---- walker state (wave-uniform) ----------------------------------------------------------------------------------
@@ -203,7 +210,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         const uint32_t idx = cursor + (uint32_t)lane;
         const bool in_tree = phase == DP_LEAF && idx < n_nodes;         // (a new move's tree does not exist yet)
         uint4 c1 = make_uint4(0, 0, 0, 0); ux4 ch = {0u, 0u, 0u, 0u};
-        if (in_tree) { c1 = nodes[idx].q1; ch = hot_ld(idx); }
+        if (in_tree) { c1 = brdq[idx]; ch = hot_ld(idx); }
         const uint64_t cb64 = ((uint64_t)c1.y << 32) | c1.x;
         // a node needs the network if it is not final (search.rs:149), not expanded and holds no output yet
         const bool valid = in_tree && !(ch.w & LK_OUT) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && (yielded || idx != dem_idx);
@@ -230,8 +237,47 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         spec_evals += (unsigned long long)n_take;
     };
 
+    // Eight-walker shape (256 registers per lane): the wave-uniform walker state -- about 45 values that would otherwise be
+    // spilled to scratch as 64-lane registers around every forward (368 bytes per lane: the scratch of the eight waves of each
+    // of an XCD's 32 CUs, the trees and the weights do not fit its L2 together; 64 M L2 misses per collect) -- waits in LDS
+    // while the forward runs: one dword per value and wave.
+    volatile lds_u32 *pkw = (volatile lds_u32 *)(park_base + wave * 64);
+    auto park = [&]() {
+        if constexpr (TWV > DEEP_WAVES) {
+            if (lane == 0) {
+                pkw[0] = (uint32_t)st.board; pkw[1] = (uint32_t)(st.board >> 32); pkw[2] = (uint32_t)st.zx; pkw[3] = (uint32_t)st.zy; pkw[4] = (uint32_t)st.depth;
+                pkw[5] = (uint32_t)cur.board; pkw[6] = (uint32_t)(cur.board >> 32); pkw[7] = (uint32_t)cur.zx; pkw[8] = (uint32_t)cur.zy; pkw[9] = (uint32_t)cur.depth;
+                pkw[10] = (uint32_t)e_local; pkw[11] = (uint32_t)(e_local >> 32);
+                pkw[12] = (uint32_t)phase; pkw[13] = (uint32_t)t; pkw[14] = it; pkw[15] = expanded; pkw[16] = node; pkw[17] = n_nodes; pkw[18] = cursor; pkw[19] = cur_link;
+                pkw[20] = __float_as_uint(value); pkw[21] = __float_as_uint(root_vs); pkw[22] = root_visit; pkw[23] = root_cb; pkw[24] = root_nc; pkw[25] = dem_idx;
+                pkw[26] = (uint32_t)evals; pkw[27] = (uint32_t)(evals >> 32); pkw[28] = (uint32_t)spec_evals; pkw[29] = (uint32_t)(spec_evals >> 32);
+                pkw[30] = (more ? 1u : 0u) | (overflow ? 2u : 0u) | (yielded ? 4u : 0u);
+                pkw[31] = (uint32_t)plen; pkw[32] = pool_head; pkw[33] = (uint32_t)n_spec; pkw[34] = (uint32_t)my_base; pkw[35] = (uint32_t)my_share; pkw[36] = trip;
+            }
+        }
+    };
+    auto unpark = [&]() {
+        if constexpr (TWV > DEEP_WAVES) {
+            st.board = ((uint64_t)uniu(pkw[1]) << 32) | uniu(pkw[0]); st.zx = (int)uniu(pkw[2]); st.zy = (int)uniu(pkw[3]); st.depth = (int)uniu(pkw[4]);
+            cur.board = ((uint64_t)uniu(pkw[6]) << 32) | uniu(pkw[5]); cur.zx = (int)uniu(pkw[7]); cur.zy = (int)uniu(pkw[8]); cur.depth = (int)uniu(pkw[9]);
+            e_local = ((uint64_t)uniu(pkw[11]) << 32) | uniu(pkw[10]);
+            e_global = a.episode_offset + e_local; rec_base = e_local * (uint64_t)a.out.t_pad;
+            phase = (int)uniu(pkw[12]); t = (int)uniu(pkw[13]); it = uniu(pkw[14]); expanded = uniu(pkw[15]); node = uniu(pkw[16]); n_nodes = uniu(pkw[17]);
+            cursor = uniu(pkw[18]); cur_link = uniu(pkw[19]);
+            value = __uint_as_float(uniu(pkw[20])); root_vs = __uint_as_float(uniu(pkw[21])); root_visit = uniu(pkw[22]); root_cb = uniu(pkw[23]);
+            root_nc = uniu(pkw[24]); dem_idx = uniu(pkw[25]);
+            evals = ((unsigned long long)uniu(pkw[27]) << 32) | uniu(pkw[26]); spec_evals = ((unsigned long long)uniu(pkw[29]) << 32) | uniu(pkw[28]);
+            const uint32_t fl = uniu(pkw[30]);
+            more = (fl & 1u) != 0; overflow = (fl & 2u) != 0; yielded = (fl & 4u) != 0;
+            plen = (int)uniu(pkw[31]); pool_head = uniu(pkw[32]); n_spec = (int)uniu(pkw[33]); my_base = (int)uniu(pkw[34]); my_share = (int)uniu(pkw[35]);
+            trip = uniu(pkw[36]);
+        }
+    };
+
     if (engw) eng.begin2();
     assemble();
+    int live = phase != DP_DEAD ? 1 : 0;
+    park();
 
 #ifdef TW_ABLATE
     unsigned long long c_fwd = 0, c_tree = 0, c_bar = 0, c_trips = 0, c_search = 0, c_hits = 0, c_asm = 0, c_yield = 0, c_root = 0, c_dead = 0, c_nspec = 0;
@@ -244,7 +290,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 #endif
     for (;;) {
         TW_DS(z0);
-        if (!__syncthreads_or(phase != DP_DEAD ? 1 : 0)) break;
+        if (!__syncthreads_or(live)) break;
         TW_DS(z1);
         TW_DA(c_bar, z0, z1);
         // ---- Policy::full_predict of the C requested boards (policy.rs:102-126) -------------------------------------
@@ -291,6 +337,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         }
         if constexpr (TWV > DEEP_WAVES) {
             __syncthreads();
+            unpark();
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -311,8 +358,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             if (my_take) {
                 const float4 *src = reinterpret_cast<const float4 *>(res + (my_base + my_rank) * 8);
                 const float4 pr = src[0]; const float4 vv = src[1];
-                nodes[my_idx].q2 = make_uint4(__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w));
-                nodes[my_idx].q3 = make_uint4(__float_as_uint(vv.x), 0u, 0u, 0u);
+                __builtin_nontemporal_store(ux4{__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w)}, outs + 2 * my_idx);
+                __builtin_nontemporal_store(ux4{__float_as_uint(vv.x), 0u, 0u, 0u}, outs + 2 * my_idx + 1);
                 const uint32_t ps = (pool_head + (uint32_t)my_slot) % (uint32_t)DEEP_POOL;
                 pidx[ps] = my_idx;
                 lds_f32 *po = pout + ps * 8;
@@ -345,7 +392,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 if (has && lane < 4) {
                     const uint32_t ni = n_nodes + pos;
                     hot_st(ni, ux4{0u, 0u, __float_as_uint(mine), (uint32_t)ca << 27});
-                    nodes[ni].q1 = make_uint4((uint32_t)c.board, (uint32_t)(c.board >> 32), idx, (uint32_t)c.depth);
+                    brdq[ni] = make_uint4((uint32_t)c.board, (uint32_t)(c.board >> 32), idx, (uint32_t)c.depth);
                 }
                 if (lane == 0) hot_st_link(idx, (idx_link & ~(LK_CB | (7u << 24))) | n_nodes | (cnt << 24));
                 // priors in child order (uniform)
@@ -379,7 +426,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     while (idx != DNONE && idx != 0u) {
                         const ux4 hq = hot_ld(idx);
                         hot_st_stats(idx, __uint_as_float(hq.x) + val, hq.y + 1u);
-                        idx = nodes[idx].q1.z;
+                        idx = brdq[idx].z;
                     }
                 }
                 root_vs = root_vs + val; root_visit += 1u;
@@ -512,7 +559,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                                 lp[0] = unif(po[0]); lp[1] = unif(po[1]); lp[2] = unif(po[2]); lp[3] = unif(po[3]); lv = unif(po[4]);
                                 if (lane == ps) pidx[ps] = DNONE;
                             } else {
-                                const uint4 o2 = nodes[node].q2; const uint4 o3 = nodes[node].q3;
+                                const ux4 o2 = __builtin_nontemporal_load(outs + 2 * node), o3 = __builtin_nontemporal_load(outs + 2 * node + 1);
                                 lp[0] = unif(__uint_as_float(o2.x)); lp[1] = unif(__uint_as_float(o2.y)); lp[2] = unif(__uint_as_float(o2.z));
                                 lp[3] = unif(__uint_as_float(o2.w)); lv = unif(__uint_as_float(o3.x));
                             }
@@ -556,9 +603,12 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         TW_DS(z3);
         TW_DA(c_tree, z2, z3);
         assemble();
+        live = phase != DP_DEAD ? 1 : 0;
+        park();
         TW_DS(z4);
         TW_DA(c_asm, z3, z4);
     }
+    unpark();
     if (lane == 0) { atomicAdd(a.eval_count, evals); atomicAdd(a.eval_count + 1, spec_evals); }
 #ifdef TW_ABLATE
     if (lane == 0) {
@@ -576,11 +626,11 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
 // The deep shape serves AlphaZero self-play of up to CUs x 16 episodes (4,096 on an MI355X: the reference's per-GPU batch; CUs x
-// 24 from 100 searches per move on) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
+// 32 from 100 searches per move on) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
 // runs the lane-per-episode kernel of tw_mcts.hip.  Measured (scripts/bench_az.py, Puzzle-15, 512/256 policy, difficulty 8;
 // walker kernel vs lane-per-episode kernel, end of round 2):
-//   1,024 x 100: 16.6 vs 48.9 ms    1,024 x 1,000: 146 vs 498 ms    4,096 x 100: 34.2 vs 42.3 ms    4,096 x 1,000: 227 vs 509 ms
-//   6,144 x 100: 47.2 vs 60.4 ms    8,192 x 100: 61.5 vs 60.9 ms    8,192 x 32: 24.8 vs 17.8 ms
+//   1,024 x 100: 16.3 vs 48.9 ms    1,024 x 1,000: 146 vs 498 ms    4,096 x 100: 31.6 vs 42.3 ms    4,096 x 1,000: 218 vs 509 ms
+//   6,144 x 100: 43.3 vs 60.4 ms    8,192 x 100: 57.5 vs 60.9 ms    8,192 x 32: 24.8 vs 17.8 ms
 // One episode's chain of searches runs about 3x faster here (2 - 3 evaluations consumed per forward and walker instead of one),
 // but at most CUs x 8 episodes are in flight: beyond that many the lane-per-episode kernel's 16+ columns of distinct episodes win.
 
@@ -590,8 +640,9 @@ bool mcts_deep_applies(const MctsArgs &a)
     if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
     if (force == 8 || force == 1 || (launch_options().az_variant & 7) == 2) return false;     // diagnostic: pin the lane-per-episode shapes
     if ((launch_options().az_variant & 7) >= 3) return true;                              // diagnostic: a pinned walker shape, whatever the batch
-    // (6,144 x 100: 47.2 ms with eight walkers per workgroup against 60.4 lane-per-episode; 8,192 x 100: 61.5 / 60.9; 8,192 x 32: 24.8 / 17.8)
-    return a.num_episodes <= (uint64_t)device_cus() * (a.num_searches >= 100 ? 24u : 16u);
+    // (eight walkers per workgroup against lane-per-episode: 6,144 x 100 43.3 / 60.4 ms, 8,192 x 100 57.5 / 60.9, 16,384 x 100 105 / 76.9,
+    //  8,192 x 50 32.0 / 29.2, 8,192 x 32 24.8 / 17.8)
+    return a.num_episodes <= (uint64_t)device_cus() * (a.num_searches >= 100 ? 32u : 16u);
 }
 
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
@@ -599,9 +650,10 @@ bool mcts_deep_applies(const MctsArgs &a)
 // forward (misses of a demand: 38 % with three columns of look-ahead, 22 % with seven, 13 % with fifteen); more episodes than
 // walkers go through the episode queue in rounds.  Beyond four episodes per CU four walkers share the 32-column engine (8
 // columns each: the forward costs 1.45x the 16-column one and serves twice the look-ahead); beyond twelve, with short searches,
-// EIGHT walkers do (four waves that only walk beside the four that also run the forward, two waves per SIMD, 4 columns each:
-// 4,096 x 100 34.3 ms against 38.5, 3,072 x 100 30.9 / 31.2, 4,096 x 1,000 236 / 229 -- the kernel then has 256 registers per
-// lane instead of 512 and a third of the tree statistics in LDS).  Measured (256 CUs, ms per collect,
+// EIGHT walkers do (four waves that only walk beside the four that also run the forward, two waves per SIMD, 4 columns each; the
+// kernel then has 256 registers per lane instead of 512 and a third of the tree statistics in LDS).  Eight against four
+// walkers: 4,096 x 100 31.6 / 37.3 ms, 3,072 x 100 29.0 / 30.5, 2,560 x 100 27.9 / 25.0, 4,096 x 200 58.6 / 64.0, 3,072 x 200
+// 56.4 / 48.1, 4,096 x 400 108 / 102, 4,096 x 1,000 243 / 218.  Measured (256 CUs, ms per collect,
 // 16-column engine with 1 / 2 / 4 walkers | 32-column engine with 1 / 2 / 4; scripts/az_shape_grid.sh, profiles/r02_az_shape_grid.txt):
 //   100 searches    256 episodes 11.0 13.8 18.6 | 13.0 13.6 16.6     512: 13.8 14.0 19.2 | 16.5 13.9 17.2
 //                   1,024: 23.8 17.1 19.6 | 28.3 17.4 17.8            2,048: 41.2 29.7 22.9 | 48.9 30.1 21.6
@@ -615,7 +667,7 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     const uint64_t avail = (uint64_t)(cus - r);
     DeepShape sh;
     sh.walkers = num_episodes <= avail + avail / 2 ? 1 : (num_episodes <= 4 * avail ? 2 : 4);
-    if (num_episodes > 12 * avail && num_searches < 256) sh.walkers = 8;
+    if (num_searches < 256 && num_episodes > (num_searches <= 128 ? 11u : 14u) * avail) sh.walkers = 8;
     sh.wide = sh.walkers >= 4;
     // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 / 5 pin two / one / four walkers per workgroup, + 16 / + 32 the 16- / 32-column engine
     const int v = launch_options().az_variant;
