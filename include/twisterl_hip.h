@@ -77,6 +77,7 @@ int tw_release_cached_memory(void);
 enum {
     TW_OPT_FORCE_GEOM = 0,  /* 8: the 256-episode workgroup shape, 32: the 32-episode shape, 1: small-batch, 0: automatic */
     TW_OPT_NO_PERSIST = 1,  /* 1: never use persistent lanes + episode queue                                               */
+    TW_OPT_AZ_TREE_BUDGET_MIN = 4, /* walker kernel: cycles of tree walk after which a walker yields once another one waits; 0: auto */
     TW_OPT_AZ_TREE_BUDGET = 3, /* walker kernel: cycles of tree walk per forward before a walker yields; 0: automatic           */
     TW_OPT_AZ_VARIANT = 2   /* self-play with few deep searches: 0 automatic (walker-per-wave kernel where it applies),    */
                             /* 2 always the lane-per-episode kernel; walker kernel with a pinned shape: 3 / 4 / 5 / 6 =    */

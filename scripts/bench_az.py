@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--geom", type=int, default=0, help="diagnostic: tw_set_launch_option(TW_OPT_FORCE_GEOM)")
 ap.add_argument("--variant", type=int, default=0, help="diagnostic: tw_set_launch_option(TW_OPT_AZ_VARIANT)")
 ap.add_argument("--tree-budget", type=int, default=0, help="diagnostic: tw_set_launch_option(TW_OPT_AZ_TREE_BUDGET)")
+ap.add_argument("--tree-budget-min", type=int, default=0, help="diagnostic: tw_set_launch_option(TW_OPT_AZ_TREE_BUDGET_MIN)")
 args = ap.parse_args()
 
 import twisterl_amd
@@ -25,6 +26,7 @@ from twisterl_amd import _lib, twisterl
 _lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_FORCE_GEOM, args.geom))
 _lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_AZ_VARIANT, args.variant))
 _lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_AZ_TREE_BUDGET, args.tree_budget))
+_lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_AZ_TREE_BUDGET_MIN, args.tree_budget_min))
 policy = build_policy(synthetic_weights(16, seed=0), [], [])      # AZ clears the twists (rl/az.py:24-26)
 env = twisterl.env.Puzzle(4, 4, args.difficulty, 2, 256)
 coll = twisterl.collector.AZCollector(args.envs, args.searches, 1.41, 1, 32)

@@ -489,10 +489,10 @@ def _assert_same_az(g, o, n_cells):
     (3, 3, 2, 32, 128, 1500, 6, 1, False),   #   more episodes than walkers: the episode queue, arenas reused (32-column engine, hidden 128)
     (3, 3, 0, 32, 128, 10, 5, 1, False),     #   difficulty 0: every root is final
     (3, 3, 4, 32, 256, 16, 0, 1, False),     #   zero searches
-    (3, 3, 3, 32, 128, 400, 10, 1, False),   #   two walkers per workgroup (1.5 to 4 episodes per CU), 8 columns each
-    (3, 3, 4, 64, 256, 700, 8, 1, True),     #   two walkers per workgroup and the episode queue
-    (3, 3, 4, 64, 256, 1300, 5, 1, True),    #   four walkers per workgroup on the 32-column engine (more than 4 episodes per CU), 8 columns each
-    (3, 3, 3, 32, 128, 3300, 4, 2, True),    #   eight walkers per workgroup (more than 11 episodes per CU, short searches), 4 columns each
+    (3, 3, 3, 32, 128, 400, 10, 1, False),   #   one walker per workgroup and the episode queue (up to 2 episodes per CU), 16 columns
+    (3, 3, 4, 64, 256, 700, 8, 1, True),     #   two walkers per workgroup on the 32-column engine (2 to 4.5 episodes per CU), 16 columns each
+    (3, 3, 4, 64, 256, 1300, 5, 1, True),    #   four walkers per workgroup on the 32-column engine (more than 4.5 episodes per CU), 8 columns each
+    (3, 3, 3, 32, 128, 3300, 4, 2, True),    #   eight walkers per workgroup (more than 12 episodes per CU, short searches), 4 columns each
 ])
 def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
     n2 = w * h
@@ -685,20 +685,18 @@ def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, h
 
 
 def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_busy(tw, oracle):
-    """tw_mcts_deep.hip: one walker x 16 columns per workgroup up to 1.5 episodes per CU, two x 8 up to four, beyond that four x 8
-    on the 32-column engine, beyond eleven (short searches) eight x 4 in workgroups of eight waves (and at most one workgroup per
-    CU: the rest of the episodes comes off the queue).  The parity cases of test_az_collect_bit_exact_vs_oracle run all of them;
-    this pins the launches the workgroup shape tells apart, and every pinned shape (TW_OPT_AZ_VARIANT: 4 / 3 / 5 / 6 = one /
-    two / four / eight walkers, + 16 / + 32 = 16- / 32-column engine) gives the same bytes as the automatic choice."""
+    """tw_mcts_deep.hip: one walker x 16 columns per workgroup up to 2 episodes per CU; on the 32-column engine two x 16 up to 4.5
+    (8 for long searches), four x 8 beyond, and beyond twelve (short searches) eight x 4 in workgroups of eight waves -- at most
+    one workgroup per CU, the rest of the episodes comes off the queue.  The parity cases of test_az_collect_bit_exact_vs_oracle
+    run all of them; this pins the launches the workgroup shape tells apart, and every pinned shape (TW_OPT_AZ_VARIANT: 4 / 3 /
+    5 / 6 = one / two / four / eight walkers, + 16 / + 32 = 16- / 32-column engine) gives the same bytes as the automatic choice."""
     import twisterl_amd
     cus = twisterl_amd.device_info()["compute_units"]
     gp, _ = _pair(oracle, 9, 2, 32, 128)
     env = tw.env.Puzzle(3, 3, 2, 2, 256)
-    for E, want in ((cus // 2, cus // 2), (cus, cus), (cus + cus // 2, cus), (cus + 3 * cus // 4, (cus + 3 * cus // 4 + 1) // 2), (3 * cus, cus), (6 * cus, cus)):
+    for E, want in ((cus // 2, (cus // 2, 256)), (cus, (cus, 256)), (2 * cus, (cus, 256)), (3 * cus, (cus, 256)), (6 * cus, (cus, 256)), (13 * cus, (cus, 512))):
         d = tw.collector.AZCollector(E, 4, 1.41, 1, 1).collect(env, gp, seed=3)
-        assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == (want, 256), (E, d.stats["rollout_blocks"], want)
-    d = tw.collector.AZCollector(13 * cus, 4, 1.41, 1, 1).collect(env, gp, seed=3)
-    assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == (cus, 512)
+        assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == want, (E, d.stats["rollout_blocks"], d.stats["rollout_threads"])
     E = 3 * cus
     auto = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
     from twisterl_amd import _lib

@@ -45,8 +45,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 hipStream_t current_stream() { return g_stream; }
 
 // ---------------------------------------------------------------------------------- launch options / per-device caches
-static std::atomic<int> g_force_geom{0}, g_no_persist{0}, g_az_variant{0}, g_az_tree_budget{0};
-LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load(), g_az_variant.load(), g_az_tree_budget.load()}; }
+static std::atomic<int> g_force_geom{0}, g_no_persist{0}, g_az_variant{0}, g_az_tree_budget{0}, g_az_tree_budget_min{0};
+LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load(), g_az_variant.load(), g_az_tree_budget.load(), g_az_tree_budget_min.load()}; }
 
 static std::mutex g_dev_mutex;
 
@@ -217,6 +217,9 @@ extern "C" int tw_set_launch_option(int option, int value)
         case TW_OPT_AZ_TREE_BUDGET:
             if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }
             g_az_tree_budget.store(value); return TW_OK;
+        case TW_OPT_AZ_TREE_BUDGET_MIN:
+            if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET_MIN: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }
+            g_az_tree_budget_min.store(value); return TW_OK;
         default: set_error("tw_set_launch_option: unknown option %d", option); return TW_ERR_INVALID;
     }
 }

@@ -30,7 +30,7 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
 hipStream_t current_stream();
 
 // Diagnostic launch overrides (tw_set_launch_option; the tests pin launch shapes with them).  Read once per collect.
-struct LaunchOptions { int force_geom; int no_persist; int az_variant; int az_tree_budget; };
+struct LaunchOptions { int force_geom; int no_persist; int az_variant; int az_tree_budget; int az_tree_budget_min; };
 LaunchOptions launch_options();
 // Raises a kernel's dynamic-LDS limit above the 64 KiB default; cached per (kernel, device), thread-safe.
 int ensure_dynamic_lds(const void *kernel, size_t bytes);
@@ -481,6 +481,7 @@ struct MctsArgs {
     int32_t         reserve_cus;
     uint32_t        lds_nodes;     // deep shape: nodes per tree whose statistics live in LDS (set by the launcher)
     uint32_t        tree_budget;   // deep shape: cycles of tree walk per trip after which a walker stops at the next search boundary (launcher)
+    uint32_t        tree_budget_min;   // ... after which it stops there as soon as another walker of the workgroup waits for a forward
 };
 size_t mcts_node_bytes();
 // the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue

@@ -44,15 +44,19 @@ constexpr int DEEP_WAVES = 4;            // waves that run the forward; the firs
 constexpr int DEEP_POOL = 40;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
 constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
-// MctsArgs::tree_budget: cycles of tree walk per trip after which a walker stops at the next search boundary (all its columns
-// then carry frontier nodes): the other walkers and the engine do not wait for one long streak of stored outputs.  Measured
-// (profiles/r02_az_param_sweep.txt; 32,000 / 48,000 / 72,000 / 100,000 cycles): 4,096 x 100 38.9 / 37.3 / 37.9 / 38.6 ms, 1,024 x 100
-// 18.1 / 17.1 / 16.6 / 16.5, 4,096 x 1,000 279 / 233 / 218 / 221, 512 x 1,000 146 / 131 / 126 / 125
-static uint32_t deep_tree_budget(uint32_t num_searches, int walkers)
+// MctsArgs::tree_budget_min / tree_budget: cycles of tree walk per trip after which a walker stops at the next search boundary
+// -- once another walker of the workgroup waits for a forward (its demand, or the root of a new move) / unconditionally; all
+// its columns then carry frontier nodes.  A waiting walker is not kept waiting for long streaks of stored outputs, and as long
+// as nobody waits no forward is run for look-ahead alone.  Measured (scripts/az_budget_sweep.sh, ms per collect; fixed budget of
+// 48,000 / 72,000 cycles against min 48,000 + max 300,000): 4,096 x 100 33.0 / 33.3 / 32.3, 2,048 x 100 21.6 / - / 20.7,
+// 256 x 100 10.7 / 9.7 / 9.3, 4,096 x 1,000 244 / 222 / 202, 512 x 1,000 133 / 128 / 117.5; a minimum of 16,000: 35.4, 8,000: 38.5
+// at 4,096 x 100 (the forward costs more than a tree phase: long tree phases amortise it).
+static void deep_tree_budgets(uint32_t *min_cycles, uint32_t *max_cycles)
 {
-    const int pinned = launch_options().az_tree_budget;             // diagnostic (TW_OPT_AZ_TREE_BUDGET)
-    if (pinned > 0) return (uint32_t)pinned;
-    return (walkers >= 4 && num_searches < 256) ? 48000u : 72000u;
+    const LaunchOptions o = launch_options();                       // diagnostic: TW_OPT_AZ_TREE_BUDGET(_MIN)
+    *max_cycles = o.az_tree_budget > 0 ? (uint32_t)o.az_tree_budget : 300000u;
+    *min_cycles = o.az_tree_budget_min > 0 ? (uint32_t)o.az_tree_budget_min : 48000u;
+    if (*min_cycles > *max_cycles) *min_cycles = *max_cycles;
 }
 
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_uniform); }
@@ -66,8 +70,8 @@ __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >
 // floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | pool idx [POOL] | pool outputs [POOL][8]
 __host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers)
 {
-    // (+ 16: the walkers' alive flags; eight walkers: + 64 dwords each, where the wave-uniform walker state waits during a forward)
-    return (size_t)columns * 10 + 16 + (walkers > DEEP_WAVES ? (size_t)walkers * 64 : 0) +
+    // (+ 24: the walkers' alive flags and waiting flags; eight walkers: + 64 dwords each, where the wave-uniform walker state waits during a forward)
+    return (size_t)columns * 10 + 24 + (walkers > DEEP_WAVES ? (size_t)walkers * 64 : 0) +
            (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);
 }
 
@@ -108,7 +112,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
     const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
     int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][TWV waves]: walker still has an episode
-    float *park_base = res + 8 * C + 16;                                         // [TWV][64] parked walker state (eight-walker shape)
+    volatile int *wait_f = reinterpret_cast<volatile int *>(res + 8 * C + 16);   // [8]: walker w has stopped in front of a forward it needs (demand / new root)
+    float *park_base = res + 8 * C + 24;                                         // [TWV][64] parked walker state (eight-walker shape)
     float *wbase = park_base + (TWV > DEEP_WAVES ? TWV * 64 : 0) + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
     lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 4);                         // pool: node index (DNONE = free)
@@ -171,7 +176,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     if (walker && slot < E) take(slot);
     if (walker && lane < DEEP_POOL) pidx[lane] = DNONE;
     if (!walker) more = false;
-    if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[TWV + wave] = phase != DP_DEAD ? 1 : 0; }
+    if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[TWV + wave] = phase != DP_DEAD ? 1 : 0; wait_f[wave] = 0; if (wave + 4 < 8) wait_f[wave + 4] = 0; }
     __syncthreads();
 
     uint32_t obs_base[4];
@@ -187,7 +192,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         my_take = false; n_spec = 0;
         // publish whether this walker still has an episode (read by everybody one trip later: a walker that ran out THIS trip
         // keeps its columns for one more forward and fills them with the identity board)
-        if (lane == 0) alive_f[(trip & 1u) * TWV + wave] = (walker && phase != DP_DEAD) ? 1 : 0;
+        alive_f[(trip & 1u) * TWV + wave] = (walker && phase != DP_DEAD) ? 1 : 0;      // (every lane stores the same value)
         const int *af = alive_f + ((trip & 1u) ^ 1u) * TWV;
         ++trip;
         int n_alive = 0, rank_me = 0;
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     volatile lds_u32 *pkw = (volatile lds_u32 *)(park_base + wave * 64);
     auto park = [&]() {
         if constexpr (TWV > DEEP_WAVES) {
-            if (lane == 0) {
+            {   // (every lane stores the same dword: no lane-0 branch in the walker's scalar control flow)
                 pkw[0] = (uint32_t)st.board; pkw[1] = (uint32_t)(st.board >> 32); pkw[2] = (uint32_t)st.zx; pkw[3] = (uint32_t)st.zy; pkw[4] = (uint32_t)st.depth;
                 pkw[5] = (uint32_t)cur.board; pkw[6] = (uint32_t)(cur.board >> 32); pkw[7] = (uint32_t)cur.zx; pkw[8] = (uint32_t)cur.zy; pkw[9] = (uint32_t)cur.depth;
                 pkw[10] = (uint32_t)e_local; pkw[11] = (uint32_t)(e_local >> 32);
@@ -354,6 +359,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         // ---- tree phase of this wave's walker ------------------------------------------------------------------------
         if (phase != DP_DEAD) {
             TW_DS(y0);
+            wait_f[wave] = 0;                                  // (every lane stores: a lane-0 branch here costs the walk its scalar branches)
             // outputs evaluated ahead of the search -> their nodes (arena) and the LDS pool; the node's hot quad gets the flag
             if (my_take) {
                 const float4 *src = reinterpret_cast<const float4 *>(res + (my_base + my_rank) * 8);
@@ -458,7 +464,17 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 bool need_nn = false;
                 TW_DS(y2);
                 if (!resume) {
-                    if (it != S && __builtin_readcyclecounter() - tree_t0 > (unsigned long long)a.tree_budget) { yielded = true; dem_idx = DNONE; break; }
+                    if (it != S) {
+                        const unsigned long long walked = __builtin_readcyclecounter() - tree_t0;
+                        bool stop = walked > (unsigned long long)a.tree_budget;
+                        if (!stop && walked > (unsigned long long)a.tree_budget_min) {        // somebody waits for a forward: do not keep it waiting
+                            int w8 = 0;
+#pragma unroll
+                            for (int w = 0; w < 8; ++w) w8 |= wait_f[w];
+                            stop = uni(w8) != 0;
+                        }
+                        if (stop) { yielded = true; dem_idx = DNONE; break; }
+                    }
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) ------------------------------
                         float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -599,6 +615,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 ++it;
                 TW_DS(y7); TW_DA(c_bp, y6, y7);
             }
+            wait_f[wave] = (phase != DP_DEAD && !yielded) ? 1 : 0;                        // stopped in front of a forward it needs
         }
         TW_DS(z3);
         TW_DA(c_tree, z2, z3);
@@ -648,17 +665,19 @@ bool mcts_deep_applies(const MctsArgs &a)
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
 // owns more of the forward's columns, i.e. more of its tree is evaluated ahead of the search and fewer searches wait for a
 // forward (misses of a demand: 38 % with three columns of look-ahead, 22 % with seven, 13 % with fifteen); more episodes than
-// walkers go through the episode queue in rounds.  Beyond four episodes per CU four walkers share the 32-column engine (8
-// columns each: the forward costs 1.45x the 16-column one and serves twice the look-ahead); beyond twelve, with short searches,
-// EIGHT walkers do (four waves that only walk beside the four that also run the forward, two waves per SIMD, 4 columns each; the
-// kernel then has 256 registers per lane instead of 512 and a third of the tree statistics in LDS).  Eight against four
-// walkers: 4,096 x 100 31.6 / 37.3 ms, 3,072 x 100 29.0 / 30.5, 2,560 x 100 27.9 / 25.0, 4,096 x 200 58.6 / 64.0, 3,072 x 200
-// 56.4 / 48.1, 4,096 x 400 108 / 102, 4,096 x 1,000 243 / 218.  Measured (256 CUs, ms per collect,
-// 16-column engine with 1 / 2 / 4 walkers | 32-column engine with 1 / 2 / 4; scripts/az_shape_grid.sh, profiles/r02_az_shape_grid.txt):
-//   100 searches    256 episodes 11.0 13.8 18.6 | 13.0 13.6 16.6     512: 13.8 14.0 19.2 | 16.5 13.9 17.2
-//                   1,024: 23.8 17.1 19.6 | 28.3 17.4 17.8            2,048: 41.2 29.7 22.9 | 48.9 30.1 21.6
-//                   4,096: 75.9 50.9 40.4 | 90.0 51.8 37.4
-//   1,000 searches  512: 134 132 162 | 159 137 150    1,024: 178 154 163 | 209 159 150    4,096: 465 313 243 | 548 330 235
+// walkers go through the episode queue in rounds.  From two walkers on they share the 32-column engine (its forward costs 1.45x
+// the 16-column one and carries twice the columns).  With many episodes and short searches EIGHT walkers do: four waves that
+// only walk beside the four that also run the forward, two waves per SIMD, 4 columns each -- the kernel then has 256
+// registers per lane instead of 512 and a third of the tree statistics in LDS.
+// Measured (256 CUs, ms per collect; 16-column engine with 1 / 2 / 4 walkers | 32-column engine with 1 / 2 / 4 / 8;
+// scripts/az_shape_grid.sh, profiles/r02_az_shape_grid.txt):
+//   100 searches    256 episodes  9.3 13.3 18.3 |  9.3 12.3 16.2 22.5     512: 11.5 13.5 18.8 | 11.7 12.5 16.9 23.0
+//                   768: 17.3 14.7 19.3 | 17.7 13.5 17.5 24.5              1,024: 19.8 16.4 19.3 | 20.1 15.1 17.5 26.6
+//                   1,536: 27.5 23.7 20.9 | 27.8 23.1 18.9 26.9            2,048: 34.1 28.8 22.6 | 34.8 27.1 21.0 27.6
+//                   3,072: 48.3 39.5 31.9 | 49.3 36.8 29.5 29.8            4,096: 62.7 49.5 41.3 | 64.0 46.1 37.3 32.7
+//   1,000 searches  512: 102 118 154 | 100 105 134 151    1,024: 132 141 155 | 132 123 134 163    2,048: 205 172 177 | 204 161 162 167
+//                   4,096: 341 272 235 | 341 250 210 236
+//   4,096 x 200: 102 82 68 | 102 74 59.8 58.0     3,072 x 200: 79 63 52 | 79 58 46.7 54.5     4,096 x 400: 168 134 110 | 167 121 98 102
 struct DeepShape { int walkers; bool wide; };
 static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num_searches)
 {
@@ -666,9 +685,10 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
     const uint64_t avail = (uint64_t)(cus - r);
     DeepShape sh;
-    sh.walkers = num_episodes <= avail + avail / 2 ? 1 : (num_episodes <= 4 * avail ? 2 : 4);
-    if (num_searches < 256 && num_episodes > (num_searches <= 128 ? 11u : 14u) * avail) sh.walkers = 8;
-    sh.wide = sh.walkers >= 4;
+    const uint64_t two_up_to = num_searches >= 256 ? 8 * avail : 4 * avail + avail / 2;
+    sh.walkers = num_episodes <= 2 * avail ? 1 : (num_episodes <= two_up_to ? 2 : 4);
+    if (num_searches < 256 && num_episodes > (num_searches <= 128 ? 12u : 14u) * avail) sh.walkers = 8;
+    sh.wide = sh.walkers >= 2;
     // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 / 5 pin two / one / four walkers per workgroup, + 16 / + 32 the 16- / 32-column engine
     const int v = launch_options().az_variant;
     if ((v & 7) == 3) sh.walkers = 2;
@@ -705,7 +725,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK)) / ((size_t)NWK * 4);
     if (nl > a.node_cap) nl = a.node_cap;
     b.lds_nodes = (uint32_t)nl;
-    b.tree_budget = deep_tree_budget(a.num_searches, NWK);
+    deep_tree_budgets(&b.tree_budget_min, &b.tree_budget);
     const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK)) * sizeof(float);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
