@@ -47,7 +47,7 @@ enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
 // MctsArgs::tree_budget_min / tree_budget: cycles of tree walk per trip after which a walker stops at the next search boundary
 // -- once another walker of the workgroup waits for a forward (its demand, or the root of a new move) / unconditionally; all
 // its columns then carry frontier nodes.  A waiting walker is not kept waiting for long streaks of stored outputs, and as long
-// as nobody waits no forward is run for look-ahead alone.  Measured (scripts/az_budget_sweep.sh, ms per collect; fixed budget of
+// as nobody waits no forward is run for look-ahead alone.  Measured (scripts/az_budget_sweep.sh, profiles/r02_az_budget_sweep.txt; ms; fixed budget of
 // 48,000 / 72,000 cycles against min 48,000 + max 300,000): 4,096 x 100 33.0 / 33.3 / 32.3, 2,048 x 100 21.6 / - / 20.7,
 // 256 x 100 10.7 / 9.7 / 9.3, 4,096 x 1,000 244 / 222 / 202, 512 x 1,000 133 / 128 / 117.5; a minimum of 16,000: 35.4, 8,000: 38.5
 // at 4,096 x 100 (the forward costs more than a tree phase: long tree phases amortise it).
