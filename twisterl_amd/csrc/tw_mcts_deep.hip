@@ -41,7 +41,10 @@ size_t mcts_deep_node_bytes() { return DEEP_NODE_BYTES; }
 constexpr uint32_t DNONE = 0xffffffffu;
 constexpr int DEEP_WAVES = 4;            // waves that run the forward; the first NWK (1, 2, 4) of them are walkers -- or, with NWK = 8 on the
                                          // 32-column engine, four more waves that only walk (eight waves per workgroup, two per SIMD)
-constexpr int DEEP_POOL = 40;            // outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: global)
+// outputs evaluated ahead and not consumed yet, kept in LDS per walker (older ones: the arena); eight walkers have three columns
+// of look-ahead each and little LDS: a shorter pool leaves room for a third more tree statistics (40 / 24 / 12 entries: 32.7 /
+// 31.9 / 32.1 ms at 4,096 x 100)
+__host__ __device__ constexpr int deep_pool(int walkers) { return walkers > 4 ? 24 : 40; }
 constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
 // MctsArgs::tree_budget_min / tree_budget: cycles of tree walk per trip after which a walker stops at the next search boundary
@@ -72,7 +75,7 @@ __host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_no
 {
     // (+ 24: the walkers' alive flags and waiting flags; eight walkers: + 64 dwords each, where the wave-uniform walker state waits during a forward)
     return (size_t)columns * 10 + 24 + (walkers > DEEP_WAVES ? (size_t)walkers * 64 : 0) +
-           (size_t)walkers * ((size_t)lds_nodes * 4 + DEEP_POOL + DEEP_POOL * 8);
+           (size_t)walkers * ((size_t)lds_nodes * 4 + deep_pool(walkers) + deep_pool(walkers) * 8);
 }
 
 #ifdef TW_ABLATE
@@ -92,6 +95,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     typedef __attribute__((address_space(3))) float lds_f32;
     constexpr int C = Eng::EPB, CPW = C / NWK;             // MFMA columns of the workgroup, columns per walker
     constexpr int TWV = NWK > DEEP_WAVES ? NWK : DEEP_WAVES;   // waves per workgroup
+    constexpr int DEEP_POOL = deep_pool(NWK);
     static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WAVES && NWK >= 1 && NWK <= 8 && CPW >= 2 && CPW <= 64, "one walker per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
