@@ -35,6 +35,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.tw_abi_version() == _lib.ABI_VERSION == 3
 
 
+def test_launch_options_are_validated():
+    """tw_set_launch_option (diagnostic launch overrides, include/twisterl_hip.h): values outside an option's set are refused with a
+    message, accepted ones can be set back to automatic.  Needs no device."""
+    from twisterl_amd import _lib
+    lib = _lib.lib()
+    ok = [(_lib.TW_OPT_FORCE_GEOM, 8), (_lib.TW_OPT_FORCE_GEOM, 32), (_lib.TW_OPT_NO_PERSIST, 1), (_lib.TW_OPT_AZ_VARIANT, 2),
+          (_lib.TW_OPT_AZ_VARIANT, 16 + 5), (_lib.TW_OPT_AZ_VARIANT, 32 + 6), (_lib.TW_OPT_AZ_TREE_BUDGET, 72000), (_lib.TW_OPT_AZ_TREE_BUDGET_MIN, 8000)]
+    bad = [(_lib.TW_OPT_FORCE_GEOM, 5), (_lib.TW_OPT_AZ_VARIANT, 7), (_lib.TW_OPT_AZ_VARIANT, 48 + 3), (_lib.TW_OPT_AZ_VARIANT, 64), (_lib.TW_OPT_AZ_VARIANT, -1),
+           (_lib.TW_OPT_AZ_TREE_BUDGET, 10), (_lib.TW_OPT_AZ_TREE_BUDGET_MIN, -5), (99, 0)]
+    try:
+        for opt, v in ok:
+            assert lib.tw_set_launch_option(opt, v) == 0, (opt, v)
+        for opt, v in bad:
+            assert lib.tw_set_launch_option(opt, v) != 0, (opt, v)
+            assert lib.tw_last_error()
+    finally:
+        for opt in (_lib.TW_OPT_FORCE_GEOM, _lib.TW_OPT_NO_PERSIST, _lib.TW_OPT_AZ_VARIANT, _lib.TW_OPT_AZ_TREE_BUDGET, _lib.TW_OPT_AZ_TREE_BUDGET_MIN):
+            assert lib.tw_set_launch_option(opt, 0) == 0
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Without a device every compute entry point must fail with a clear error (this container
     has no GPU; on the GPU box the test is skipped)."""
