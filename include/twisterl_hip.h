@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 3
+#define TW_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -312,6 +312,9 @@ typedef struct {
                             /* twists) = what the reference computes                            */
     uint64_t speculative_evals; /* AZ, few deep searches: frontier nodes evaluated on otherwise */
                             /* idle MFMA columns before a search asked for them (x twists)      */
+    uint64_t reused_evals;  /* AZ, few deep searches: of forward_evals, the outputs a node took  */
+                            /* from its grandparent (its move took the parent's move back: same */
+                            /* board, same output) instead of a column of a forward (x twists)  */
 } tw_collect_stats;
 int  tw_collected_stats(const tw_collected *c, tw_collect_stats *out);
 void tw_collected_free(tw_collected *c);

@@ -38,6 +38,6 @@ for i in range(args.steps):
 dt = time.perf_counter() - t0
 print(json.dumps({"metric": "MCTS leaf evaluations/s (Puzzle-15 AlphaZero self-play, 1 GPU)", "value": ev / dt,
                   "records_per_s": rec / dt, "episodes": args.envs, "num_mcts_searches": args.searches,
-                  "difficulty": args.difficulty, "mcts_kernel_ms": sum(ms) / len(ms), "speculative_evals": d.stats["speculative_evals"],
+                  "difficulty": args.difficulty, "mcts_kernel_ms": sum(ms) / len(ms), "speculative_evals": d.stats["speculative_evals"], "reused_evals": d.stats["reused_evals"],
                   "threads": d.stats["rollout_threads"], "blocks": d.stats["rollout_blocks"],
                   "mfma_tflops": ev / len(ms) * 272896 / (sum(ms) / len(ms) * 1e-3) / 1e12}))

@@ -1264,8 +1264,8 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     rc = launch_scan(ma.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
     if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[2], s));
-    uint64_t host_tot[3] = {0, 0, 0};
-    TW_HIP(hipMemcpyAsync(host_tot, ws + o_total, 24, hipMemcpyDeviceToHost, s));
+    uint64_t host_tot[4] = {0, 0, 0, 0};
+    TW_HIP(hipMemcpyAsync(host_tot, ws + o_total, 32, hipMemcpyDeviceToHost, s));
     TW_HIP(hipStreamSynchronize(s));
     const uint64_t total = host_tot[0];
     if (total == 0 || total > R) { set_error("az collect: inconsistent record count %llu (max %llu)", (unsigned long long)total, (unsigned long long)R); return TW_ERR_HIP; }
@@ -1300,6 +1300,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     st.records = total; st.episodes = E; st.padded_bytes = cur;
     st.forward_evals = host_tot[1] * (uint64_t)(ma.pol.n_perms > 0 ? ma.pol.n_perms : 1);
     st.speculative_evals = host_tot[2] * (uint64_t)(ma.pol.n_perms > 0 ? ma.pol.n_perms : 1);
+    st.reused_evals = host_tot[3] * (uint64_t)(ma.pol.n_perms > 0 ? ma.pol.n_perms : 1);
     c->stats = st;
     *out = c;
     return TW_OK;

@@ -472,7 +472,8 @@ struct MctsArgs {
     float        C;
     MctsNode    *arena;        // [num_episodes][node_cap]
     uint32_t     node_cap;
-    unsigned long long *eval_count;   // [0] policy evaluations the searches consumed (leaf + root), [1] speculative ones (deep shape)
+    unsigned long long *eval_count;   // [0] policy evaluations the searches consumed (leaf + root), [1] speculative ones (deep shape),
+                                      // [2] of [0]: outputs taken from the grandparent (a move taken back: same board; deep shape)
     MctsSolve    solve;        // on == 0: AlphaZero self-play (records into `out`)
     // persistent-lane mode (self-play with more episodes than resident lanes, see RolloutArgs): the arena is then
     // [resident lanes][node_cap], a lane reuses its arena for every episode it takes

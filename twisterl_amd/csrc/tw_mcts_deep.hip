@@ -21,7 +21,10 @@
 //   * the tree walk is wave-parallel instead of lane-serial: the (up to four) children of a node are scored by four lanes,
 //     expanded by four lanes, the search path lives one level per lane (back-propagation is ONE store instruction);
 //   * workgroups are persistent: a walker whose episode is over takes the next one from the queue (start boards from
-//     init_boards_kernel), its tree arena is reused.
+//     init_boards_kernel), its tree arena is reused;
+//   * a child whose move takes its parent's move back (every expanded node below the root's children has one: the blank can
+//     always go back) holds its GRANDPARENT's board, and the network output is a function of the board alone: such a node takes
+//     the grandparent's stored output instead of a column of a forward -- the same bits the reference computes a second time.
 // 64 bytes per node in the walker's arena, as separate arrays: statistics (touched only beyond the nodes kept in LDS), boards,
 // and the stored network outputs (written once and read at most once -- non-temporal): what a walk re-reads stays small enough
 // for the weights and the trees of the 32 CUs of an XCD to share its 4 MB L2 (eight walkers per CU: 105 M L2 misses per
@@ -45,7 +48,7 @@ constexpr int DEEP_WAVES = 4;            // waves that run the forward; the firs
 // of look-ahead each and little LDS: a shorter pool leaves room for a third more tree statistics (40 / 24 / 12 entries: 32.7 /
 // 31.9 / 32.1 ms at 4,096 x 100)
 __host__ __device__ constexpr int deep_pool(int walkers) { return walkers > 4 ? 24 : 40; }
-constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29;
+constexpr uint32_t LK_CB = 0x00ffffffu, LK_OUT = 1u << 29, LK_UNDO = 1u << 30;   // LK_UNDO: the node's move takes its parent's move back
 enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
 // MctsArgs::tree_budget_min / tree_budget: cycles of tree walk per trip after which a walker stops at the next search boundary
 // -- once another walker of the workgroup waits for a forward (its demand, or the root of a new move) / unconditionally; all
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     float    value = 0.0f;
     float    root_vs = 0.0f; uint32_t root_visit = 0, root_cb = 0, root_nc = 0;
     uint32_t dem_idx = 0;
-    unsigned long long evals = 0, spec_evals = 0;
+    unsigned long long evals = 0, spec_evals = 0, reused = 0;      // outputs consumed | columns evaluated ahead | outputs taken from a grandparent
     bool more = true;
     // search path, one level per lane: node index, value_sum and visit_count read on the way down
     uint32_t p_idx = 0, p_vis = 0; float p_vs = 0.0f; int plen = 0; bool overflow = false;
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         if (in_tree) { c1 = brdq[idx]; ch = hot_ld(idx); }
         const uint64_t cb64 = ((uint64_t)c1.y << 32) | c1.x;
         // a node needs the network if it is not final (search.rs:149), not expanded and holds no output yet
-        const bool valid = in_tree && !(ch.w & LK_OUT) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && (yielded || idx != dem_idx);
+        const bool valid = in_tree && !(ch.w & (LK_OUT | LK_UNDO)) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && (yielded || idx != dem_idx);
         const int quota = my_share - col0;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
         const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -262,6 +265,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 pkw[26] = (uint32_t)evals; pkw[27] = (uint32_t)(evals >> 32); pkw[28] = (uint32_t)spec_evals; pkw[29] = (uint32_t)(spec_evals >> 32);
                 pkw[30] = (more ? 1u : 0u) | (overflow ? 2u : 0u) | (yielded ? 4u : 0u);
                 pkw[31] = (uint32_t)plen; pkw[32] = pool_head; pkw[33] = (uint32_t)n_spec; pkw[34] = (uint32_t)my_base; pkw[35] = (uint32_t)my_share; pkw[36] = trip;
+                pkw[37] = (uint32_t)reused; pkw[38] = (uint32_t)(reused >> 32);
             }
         }
     };
@@ -280,6 +284,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             more = (fl & 1u) != 0; overflow = (fl & 2u) != 0; yielded = (fl & 4u) != 0;
             plen = (int)uniu(pkw[31]); pool_head = uniu(pkw[32]); n_spec = (int)uniu(pkw[33]); my_base = (int)uniu(pkw[34]); my_share = (int)uniu(pkw[35]);
             trip = uniu(pkw[36]);
+            reused = ((unsigned long long)uniu(pkw[38]) << 32) | uniu(pkw[37]);
         }
     };
 
@@ -386,6 +391,12 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 const float4 pr = src[0]; const float4 vv = src[1];
                 probs[0] = unif(pr.x); probs[1] = unif(pr.y); probs[2] = unif(pr.z); probs[3] = unif(pr.w); nn_value = unif(vv.x);
             }
+            // every node that gets expanded keeps its output in the arena: its grandchildren by a move taken back read it
+            auto keep_output = [&](uint32_t idx, const float (&pb)[4], float v) {      // (every lane stores the same 32 bytes)
+                __builtin_nontemporal_store(ux4{__float_as_uint(pb[0]), __float_as_uint(pb[1]), __float_as_uint(pb[2]), __float_as_uint(pb[3])}, outs + 2 * idx);
+                __builtin_nontemporal_store(ux4{__float_as_uint(v), 0u, 0u, 0u}, outs + 2 * idx + 1);
+            };
+            if (!yielded) keep_output(phase == DP_ROOT ? 0u : node, probs, nn_value);
 
             const int ca = lane & 3;                               // the child / action this lane works on
             // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step; four lanes, one child each
@@ -401,7 +412,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 puzzle_step(c, env, ca);
                 if (has && lane < 4) {
                     const uint32_t ni = n_nodes + pos;
-                    hot_st(ni, ux4{0u, 0u, __float_as_uint(mine), (uint32_t)ca << 27});
+                    const uint32_t undo = (idx != 0u && (uint32_t)ca == (((idx_link >> 27) & 3u) ^ 2u)) ? LK_UNDO : 0u;   // 0 left, 1 up, 2 right, 3 down
+                    hot_st(ni, ux4{0u, 0u, __float_as_uint(mine), ((uint32_t)ca << 27) | undo});
                     brdq[ni] = make_uint4((uint32_t)c.board, (uint32_t)(c.board >> 32), idx, (uint32_t)c.depth);
                 }
                 if (lane == 0) hot_st_link(idx, (idx_link & ~(LK_CB | (7u << 24))) | n_nodes | (cnt << 24));
@@ -423,9 +435,10 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 int act = 0, seen = 0;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) if ((act_mask >> x) & 1u) { if (seen == k) act = x; ++seen; }
+                const uint32_t undo = (node != 0u && (uint32_t)act == (((cur_link >> 27) & 3u) ^ 2u)) ? LK_UNDO : 0u;
                 node = cb + (uint32_t)k;
                 puzzle_step(cur, env, act);
-                cur_link = (uint32_t)act << 27;
+                cur_link = ((uint32_t)act << 27) | undo;
                 push(node, 0.0f, 0u);
             };
             // backpropagate (search.rs:45-53): value_sum += v, visit_count += 1 on every node of the path -- one store per level
@@ -567,10 +580,20 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     while (expanded < MED) {
                         value = puzzle_reward(cur, env);                                  // :146
                         if (puzzle_final(cur, env)) break;                                // :149
-                        if (!(cur_link & LK_OUT)) { need_nn = true; break; }              // :154 needs the network: demand it
-                        // the node was evaluated ahead of this search: take its output (LDS pool, else the arena) and go on
+                        const bool from_grandparent = !(cur_link & LK_OUT) && (cur_link & LK_UNDO) && !overflow && plen >= 3;
+                        if (!(cur_link & LK_OUT) && !from_grandparent) { need_nn = true; break; }   // :154 needs the network: demand it
                         float lp[4]; float lv;
-                        {
+                        if (from_grandparent) {
+                            // this node's move took its parent's move back: it holds the board of its grandparent (path level plen - 3),
+                            // whose output is in the arena -- the network would compute the same bits again
+                            const uint32_t g = rdl(p_idx, plen - 3);
+                            const ux4 o2 = outs[2 * g], o3 = outs[2 * g + 1];
+                            lp[0] = unif(__uint_as_float(o2.x)); lp[1] = unif(__uint_as_float(o2.y)); lp[2] = unif(__uint_as_float(o2.z));
+                            lp[3] = unif(__uint_as_float(o2.w)); lv = unif(__uint_as_float(o3.x));
+                            keep_output(node, lp, lv);
+                            ++reused;
+                        } else {
+                            // the node was evaluated ahead of this search: take its output (LDS pool, else the arena) and go on
                             const bool hit = lane < DEEP_POOL && pidx[lane < DEEP_POOL ? lane : 0] == node;
                             const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
                             if (hm != 0ull) {
@@ -630,7 +653,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         TW_DA(c_asm, z3, z4);
     }
     unpark();
-    if (lane == 0) { atomicAdd(a.eval_count, evals); atomicAdd(a.eval_count + 1, spec_evals); }
+    if (lane == 0) { atomicAdd(a.eval_count, evals); atomicAdd(a.eval_count + 1, spec_evals); atomicAdd(a.eval_count + 2, reused); }
 #ifdef TW_ABLATE
     if (lane == 0) {
         atomicAdd(&g_deep_stamps[0], c_fwd); atomicAdd(&g_deep_stamps[1], c_tree); atomicAdd(&g_deep_stamps[2], c_bar);
