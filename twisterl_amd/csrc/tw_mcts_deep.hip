@@ -669,12 +669,12 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
-// The deep shape serves AlphaZero self-play of up to CUs x 16 episodes (4,096 on an MI355X: the reference's per-GPU batch; CUs x
-// 32 from 100 searches per move on) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
+// The deep shape serves AlphaZero self-play of up to CUs x 16 episodes (4,096 on an MI355X: the reference's per-GPU batch; up to
+// CUs x 48 with longer searches) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
 // runs the lane-per-episode kernel of tw_mcts.hip.  Measured (scripts/bench_az.py, Puzzle-15, 512/256 policy, difficulty 8;
 // walker kernel vs lane-per-episode kernel, end of round 2):
-//   1,024 x 100: 16.3 vs 48.9 ms    1,024 x 1,000: 146 vs 498 ms    4,096 x 100: 31.6 vs 42.3 ms    4,096 x 1,000: 218 vs 509 ms
-//   6,144 x 100: 43.3 vs 60.4 ms    8,192 x 100: 57.5 vs 60.9 ms    8,192 x 32: 24.8 vs 17.8 ms
+//   1,024 x 100: 14.1 vs 48.9 ms    1,024 x 1,000: 115 vs 498 ms    4,096 x 100: 26.4 vs 42.3 ms    4,096 x 1,000: 174 vs 509 ms
+//   8,192 x 100: 45.9 vs 61.1 ms    12,288 x 100: 64.1 vs 68.0 ms   8,192 x 32: 19.7 vs 17.8 ms
 // One episode's chain of searches runs about 3x faster here (2 - 3 evaluations consumed per forward and walker instead of one),
 // but at most CUs x 8 episodes are in flight: beyond that many the lane-per-episode kernel's 16+ columns of distinct episodes win.
 
@@ -684,9 +684,10 @@ bool mcts_deep_applies(const MctsArgs &a)
     if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
     if (force == 8 || force == 1 || (launch_options().az_variant & 7) == 2) return false;     // diagnostic: pin the lane-per-episode shapes
     if ((launch_options().az_variant & 7) >= 3) return true;                              // diagnostic: a pinned walker shape, whatever the batch
-    // (eight walkers per workgroup against lane-per-episode: 6,144 x 100 43.3 / 60.4 ms, 8,192 x 100 57.5 / 60.9, 16,384 x 100 105 / 76.9,
-    //  8,192 x 50 32.0 / 29.2, 8,192 x 32 24.8 / 17.8)
-    return a.num_episodes <= (uint64_t)device_cus() * (a.num_searches >= 100 ? 32u : 16u);
+    // (eight walkers per workgroup against lane-per-episode: 8,192 x 100 45.9 / 61.1 ms, 12,288 x 100 64.1 / 68.0, 16,384 x 100 81.4 / 78.6,
+    //  8,192 x 50 26.8 / 28.9, 6,144 x 50 22.9 / 29.0, 8,192 x 32 19.7 / 17.8, 6,144 x 32 16.4 / 17.9)
+    const uint32_t S = a.num_searches;
+    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 48u : (S >= 48 ? 32u : (S >= 32 ? 24u : 16u)));
 }
 
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
@@ -698,13 +699,13 @@ bool mcts_deep_applies(const MctsArgs &a)
 // registers per lane instead of 512 and a third of the tree statistics in LDS.
 // Measured (256 CUs, ms per collect; 16-column engine with 1 / 2 / 4 walkers | 32-column engine with 1 / 2 / 4 / 8;
 // scripts/az_shape_grid.sh, profiles/r02_az_shape_grid.txt):
-//   100 searches    256 episodes  9.3 13.3 18.3 |  9.3 12.3 16.2 22.5     512: 11.5 13.5 18.8 | 11.7 12.5 16.9 23.0
-//                   768: 17.3 14.7 19.3 | 17.7 13.5 17.5 24.5              1,024: 19.8 16.4 19.3 | 20.1 15.1 17.5 26.6
-//                   1,536: 27.5 23.7 20.9 | 27.8 23.1 18.9 26.9            2,048: 34.1 28.8 22.6 | 34.8 27.1 21.0 27.6
-//                   3,072: 48.3 39.5 31.9 | 49.3 36.8 29.5 29.8            4,096: 62.7 49.5 41.3 | 64.0 46.1 37.3 32.7
-//   1,000 searches  512: 102 118 154 | 100 105 134 151    1,024: 132 141 155 | 132 123 134 163    2,048: 205 172 177 | 204 161 162 167
-//                   4,096: 341 272 235 | 341 250 210 236
-//   4,096 x 200: 102 82 68 | 102 74 59.8 58.0     3,072 x 200: 79 63 52 | 79 58 46.7 54.5     4,096 x 400: 168 134 110 | 167 121 98 102
+//   100 searches    256 episodes  8.5 11.5 15.0 |  8.9 11.3 13.5 18.2     512: 10.5 11.6 15.4 | 11.0 11.5 14.2 18.4
+//                   768: 15.9 12.6 16.3 | 16.9 12.6 14.5 19.6              1,024: 18.2 14.1 16.3 | 19.1 14.1 14.8 21.1
+//                   1,536: 25.2 20.7 17.2 | 26.4 21.5 15.8 21.3            2,048: 31.3 24.6 18.8 | 33.2 25.1 17.7 21.6
+//                   3,072: 44.4 34.0 27.1 | 46.9 34.0 26.1 23.6            4,096: 57.7 42.3 33.7 | 60.8 42.3 31.3 26.4
+//   1,000 searches  512: 96 103 129 | 97 97 115 129    1,024: 126 123 130 | 127 115 116 136    2,048: 195 153 157 | 197 148 139 140
+//                   4,096: 324 241 197 | 330 225 174 187
+//   4,096 x 200: 94 70 58 | 97 67 51.9 47.3     3,072 x 200: 73 54 43 | 75 52 39.4 41.0     4,096 x 400: 157 114 91 | 160 110 84.0 82.5
 struct DeepShape { int walkers; bool wide; };
 static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num_searches)
 {
@@ -712,9 +713,8 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
     const uint64_t avail = (uint64_t)(cus - r);
     DeepShape sh;
-    const uint64_t two_up_to = num_searches >= 256 ? 8 * avail : 4 * avail + avail / 2;
-    sh.walkers = num_episodes <= 2 * avail ? 1 : (num_episodes <= two_up_to ? 2 : 4);
-    if (num_searches < 256 && num_episodes > (num_searches <= 128 ? 12u : 14u) * avail) sh.walkers = 8;
+    sh.walkers = num_episodes <= 2 * avail ? 1 : (num_episodes <= 4 * avail + avail / 2 ? 2 : 4);
+    if (num_searches <= 128 ? num_episodes > 10 * avail : (num_searches < 512 && num_episodes > 14 * avail)) sh.walkers = 8;
     sh.wide = sh.walkers >= 2;
     // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 / 5 pin two / one / four walkers per workgroup, + 16 / + 32 the 16- / 32-column engine
     const int v = launch_options().az_variant;
