@@ -455,6 +455,16 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 root_vs = root_vs + val; root_visit += 1u;
             };
 
+            // root node of a move's tree (search.rs:120-129): visit_count 1, expanded with the root priors
+            auto start_move = [&](const float (&pb)[4]) {
+                ++evals;
+                n_nodes = 1; cursor = 1;
+                pidx[lane < DEEP_POOL ? lane : 0] = DNONE;               // outputs of the previous move's tree (every lane stores: no lane branch in the walk)
+                root_vs = 0.0f; root_visit = 1u; root_cb = 1u;
+                root_nc = expand(0u, 0u, st, pb);
+                it = 0;
+                phase = DP_LEAF;
+            };
             bool resume = false;
             TW_DS(y1);
             TW_DA(c_pre, y0, y1);
@@ -462,14 +472,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             if (yielded) {
                 yielded = false;                                 // stopped between two searches: go on searching
             } else if (phase == DP_ROOT) {
-                // root node (search.rs:120-129): visit_count 1, expanded with the root priors
-                ++evals;
-                n_nodes = 1; cursor = 1;
-                if (lane < DEEP_POOL) pidx[lane] = DNONE;                // outputs of the previous move's tree
-                root_vs = 0.0f; root_visit = 1u; root_cb = 1u;
-                root_nc = expand(0u, 0u, st, probs);
-                it = 0;
-                phase = DP_LEAF;
+                start_move(probs);
             } else {
                 resume = true;                                   // the leaf `node` just got its output
             }
@@ -495,15 +498,20 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) ------------------------------
                         float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        uint32_t exp_child[4] = {DNONE, DNONE, DNONE, DNONE};   // per action: the root's child, if it was expanded
                         if (root_nc > 0) {
                             const ux4 rq = hot_ld(root_cb + ((uint32_t)ca < root_nc ? (uint32_t)ca : root_nc - 1u));
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 if ((uint32_t)c >= root_nc) continue;
-                                const int act = lk_act(rdl(rq.w, c));
+                                const uint32_t lk = rdl(rq.w, c);
+                                const int act = lk_act(lk);
                                 const float vis = (float)rdl(rq.y, c);
                                 mp[0] = act == 0 ? vis : mp[0]; mp[1] = act == 1 ? vis : mp[1];
                                 mp[2] = act == 2 ? vis : mp[2]; mp[3] = act == 3 ? vis : mp[3];
+                                const uint32_t ci = lk_nch(lk) > 0u ? root_cb + (uint32_t)c : DNONE;
+                                exp_child[0] = act == 0 ? ci : exp_child[0]; exp_child[1] = act == 1 ? ci : exp_child[1];
+                                exp_child[2] = act == 2 ? ci : exp_child[2]; exp_child[3] = act == 3 ? ci : exp_child[3];
                             }
                         }
                         float sum = 0.0f;
@@ -538,6 +546,21 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                         }
                         puzzle_step(st, env, action);                                                   // az.rs:89
                         ++t;
+                        // The next move's root holds the board of the child just chosen.  If a search expanded that child, its
+                        // output is in the arena: the new tree starts from it at once instead of waiting for a forward.
+                        const uint32_t cidx = action == 0 ? exp_child[0] : (action == 1 ? exp_child[1] : (action == 2 ? exp_child[2] : exp_child[3]));
+                        if (cidx != DNONE) {
+                            const ux4 o2 = outs[2 * cidx], o3 = outs[2 * cidx + 1];
+                            float rp[4];
+                            rp[0] = unif(__uint_as_float(o2.x)); rp[1] = unif(__uint_as_float(o2.y)); rp[2] = unif(__uint_as_float(o2.z));
+                            rp[3] = unif(__uint_as_float(o2.w));
+                            const float rv = unif(__uint_as_float(o3.x));
+                            start_move(rp);
+                            keep_output(0u, rp, rv);
+                            ++reused;
+                            TW_DS(y9); TW_DA(c_fin, y2, y9);
+                            continue;
+                        }
                         phase = DP_ROOT;
                         TW_DS(y9); TW_DA(c_fin, y2, y9);
                         break;
