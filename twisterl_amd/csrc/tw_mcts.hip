@@ -27,11 +27,16 @@ struct __attribute__((aligned(16))) MctsNode {   // MCTSNode + Node<T> (search.r
     uint32_t parent;       // 0xffffffff = None
     uint32_t child_base;   // children are contiguous in the arena (expand adds them together)
     uint8_t  n_children;
-    uint8_t  action;       // action_taken (0xff = None)
+    uint8_t  action;       // action_taken (0xff = None); | ACT_UNDO: this move takes the parent's move back
     uint16_t depth;
 };
 static_assert(sizeof(MctsNode) == 32, "MctsNode must be 32 bytes");
-size_t mcts_node_bytes() { return sizeof(MctsNode); }
+// An episode's arena: MctsNode nodes[node_cap] | uint4 outs[node_cap][2] -- the network output every expanded node was expanded
+// with (probs[4] | value).  A node whose move takes its parent's move back holds its GRANDPARENT's board, and the output is a
+// function of the board alone: it takes the grandparent's stored output instead of asking for a forward (same bits as the
+// evaluation the reference repeats; see tw_mcts_deep.hip).
+constexpr uint8_t ACT_UNDO = 4;
+size_t mcts_node_bytes() { return sizeof(MctsNode) + 32; }
 
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr int PATH_DEPTH = 8;     // levels of the search path kept in LDS per episode (deeper paths fall back to parent chasing)
@@ -65,7 +70,8 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
     const uint64_t sv_ep    = sv.on ? a.episode_offset + e_local / sv.num_searches : 0;
     uint64_t       e_global = sv.on ? sv_ep * (uint64_t)sv.num_searches + e_local % sv.num_searches : a.episode_offset + e_local;
     const bool     owner    = valid && h == 0 && eng.owns_lane();   // the lane that walks / mutates the tree
-    MctsNode *nodes = a.arena + (valid ? slot : 0) * (uint64_t)a.node_cap;
+    MctsNode *nodes = reinterpret_cast<MctsNode *>(reinterpret_cast<uint8_t *>(a.arena) + (valid ? slot : 0) * (uint64_t)a.node_cap * (sizeof(MctsNode) + 32));
+    uint4    *outs  = reinterpret_cast<uint4 *>(nodes + a.node_cap);
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
 
@@ -92,7 +98,7 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
     uint32_t len = 0;
     float    value = 0.0f;
     PuzzleLane leaf = st;                                 // state whose evaluation is pending
-    unsigned long long evals = 0;
+    unsigned long long evals = 0, reused = 0;
     bool more = PERSIST;                                  // the episode queue may still hold work
 
     uint32_t obs_base[4];
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
             ++evals;
             // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step
             float pri[4] = {0.0f, 0.0f, 0.0f, 0.0f};        // priors of the children just created, in child order
-            auto expand = [&](uint32_t idx, const PuzzleLane &s) -> uint32_t {
+            auto expand = [&](uint32_t idx, const PuzzleLane &s, uint32_t pact) -> uint32_t {
                 uint32_t cnt = 0;
 #pragma unroll
                 for (int act = 0; act < 4; ++act) {
@@ -188,7 +194,8 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
                     puzzle_step(c, env, act);
                     MctsNode nn;
                     nn.board = c.board; nn.value_sum = 0.0f; nn.visit = 0; nn.prior = probs[act];
-                    nn.parent = idx; nn.child_base = 0; nn.n_children = 0; nn.action = (uint8_t)act;
+                    nn.parent = idx; nn.child_base = 0; nn.n_children = 0;
+                    nn.action = (uint8_t)(act | ((idx != 0u && (uint32_t)act == ((pact & 3u) ^ 2u)) ? ACT_UNDO : 0));   // 0 left, 1 up, 2 right, 3 down
                     nn.depth = (uint16_t)c.depth;
                     nodes[n_nodes + cnt] = nn;
                     ++cnt;
@@ -196,6 +203,10 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
                 nodes[idx].child_base = n_nodes; nodes[idx].n_children = (uint8_t)cnt;
                 n_nodes += cnt;
                 return cnt;
+            };
+            auto keep_output = [&](uint32_t idx, float v) {       // the output node idx is expanded with (probs[], v)
+                outs[2 * idx] = make_uint4(__float_as_uint(probs[0]), __float_as_uint(probs[1]), __float_as_uint(probs[2]), __float_as_uint(probs[3]));
+                outs[2 * idx + 1] = make_uint4(__float_as_uint(v), 0u, 0u, 0u);
             };
             // backpropagate (search.rs:45-53): value_sum += v, visit_count += 1 on every node of the path
             auto backprop = [&](uint32_t idx, float val) {
@@ -220,13 +231,15 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
                 r.child_base = 0; r.n_children = 0; r.action = 0xff; r.depth = (uint16_t)st.depth;
                 nodes[0] = r; n_nodes = 1;
                 root_vs = 0.0f; root_visit = 1u; root_cb = 1u;
-                root_nc = expand(0, st);
+                root_nc = expand(0, st, 0xffu);
+                keep_output(0u, nn_value);
                 it = 0;
             } else {
                 // the leaf just evaluated (search.rs:154-159): expand, sample a child by the priors (the children were
                 // written a moment ago: their priors are still in registers)
                 const uint32_t cb = n_nodes;
-                const uint32_t nch = expand(node, leaf);
+                const uint32_t nch = expand(node, leaf, (uint32_t)nodes[node].action);
+                keep_output(node, nn_value);
                 if (nch > 0) {
                     const u32x4 w = rng_draw(a.seed, e_global, it * MED + expanded, STREAM_MCTS | ((uint32_t)t << 8));
                     node = cb + (uint32_t)sample_weighted4(pri, (int)nch, u32_to_unit(w.x));
@@ -258,7 +271,7 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 if ((uint32_t)c >= root_nc) continue;
-                                const int act = chs[c].action;     // (a chain of selects instead of a dynamically indexed register array)
+                                const int act = chs[c].action & 3; // (a chain of selects instead of a dynamically indexed register array)
                                 const float vis = (float)chs[c].visit;
                                 mp[0] = act == 0 ? vis : mp[0]; mp[1] = act == 1 ? vis : mp[1];
                                 mp[2] = act == 2 ? vis : mp[2]; mp[3] = act == 3 ? vis : mp[3];
@@ -361,13 +374,37 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
                 }
                 resume_expand = false;
                 // leaf phase (search.rs:143-160)
-                if (expanded < MED) {
+                bool need_nn = false;
+                while (expanded < MED) {
                     const MctsNode n = have_cur ? cur : nodes[node];
                     have_cur = false;
                     const PuzzleLane s = lane_of(n, env);
                     value = puzzle_reward(s, env);                                   // :146
-                    if (!puzzle_final(s, env)) { phase = PH_LEAF; leaf = s; break; } // :149-155 needs the network
+                    if (puzzle_final(s, env)) break;                                 // :149
+                    // a node whose move took its parent's move back holds the board of its grandparent (verified: parent chain
+                    // and boards are read back), whose output is stored: expand with it, sample a child, go on (search.rs:154-159)
+                    uint32_t g = NONE;
+                    if (n.action != 0xffu && (n.action & ACT_UNDO) && n.parent != NONE && n.parent != 0u) {
+                        const uint32_t gp = nodes[n.parent].parent;
+                        if (gp != NONE && nodes[gp].board == n.board && nodes[gp].n_children != 0) g = gp;
+                    }
+                    if (g == NONE) { phase = PH_LEAF; leaf = s; need_nn = true; break; }       // :154 needs the network
+                    const uint4 o2 = outs[2 * g], o3 = outs[2 * g + 1];
+                    probs[0] = __uint_as_float(o2.x); probs[1] = __uint_as_float(o2.y); probs[2] = __uint_as_float(o2.z); probs[3] = __uint_as_float(o2.w);
+                    const float gv = __uint_as_float(o3.x);
+                    ++evals; ++reused;
+                    const uint32_t cb = n_nodes;
+                    const uint32_t nch = expand(node, s, n.action);
+                    keep_output(node, gv);
+                    if (nch > 0) {
+                        const u32x4 w = rng_draw(a.seed, e_global, it * MED + expanded, STREAM_MCTS | ((uint32_t)t << 8));
+                        node = cb + (uint32_t)sample_weighted4(pri, (int)nch, u32_to_unit(w.x));
+                        push(node, 0.0f, 0u);
+                    }
+                    value = gv;
+                    ++expanded;
                 }
+                if (need_nn) break;
                 TW_MS(m_b0);
                 backprop(node, value);                                               // :163
                 ++it;
@@ -412,6 +449,7 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
             sv.n_steps[e_local] = (uint32_t)t;
         } else if constexpr (!PERSIST) a.out.ep_len[e_local] = len;
         atomicAdd(a.eval_count, evals);
+        if (!sv.on && reused) atomicAdd(a.eval_count + 2, reused);
     }
 #ifdef TW_ABLATE
     {   // wave-level: cycles from lane 0; per-lane counters: sum and max over the wave's owners
