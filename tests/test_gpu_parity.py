@@ -492,7 +492,7 @@ def _assert_same_az(g, o, n_cells):
     (3, 3, 3, 32, 128, 400, 10, 1, False),   #   one walker per workgroup and the episode queue (up to 2 episodes per CU), 16 columns
     (3, 3, 4, 64, 256, 700, 8, 1, True),     #   two walkers per workgroup on the 32-column engine (2 to 4.5 episodes per CU), 16 columns each
     (3, 3, 4, 64, 256, 1300, 5, 1, True),    #   four walkers per workgroup on the 32-column engine (more than 4.5 episodes per CU), 8 columns each
-    (3, 3, 3, 32, 128, 3300, 4, 2, True),    #   eight walkers per workgroup (more than 10 episodes per CU, short searches), 4 columns each
+    (3, 3, 3, 32, 128, 3300, 24, 2, True),   #   eight walkers per workgroup (more than 10 episodes per CU, short searches), 4 columns each
 ])
 def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
     n2 = w * h
@@ -695,7 +695,7 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
     gp, _ = _pair(oracle, 9, 2, 32, 128)
     env = tw.env.Puzzle(3, 3, 2, 2, 256)
     for E, want in ((cus // 2, (cus // 2, 256)), (cus, (cus, 256)), (2 * cus, (cus, 256)), (3 * cus, (cus, 256)), (6 * cus, (cus, 256)), (13 * cus, (cus, 512))):
-        d = tw.collector.AZCollector(E, 4, 1.41, 1, 1).collect(env, gp, seed=3)
+        d = tw.collector.AZCollector(E, 4 if E <= 8 * cus else 24, 1.41, 1, 1).collect(env, gp, seed=3)     # (very short searches: walker kernel up to 8 episodes per CU)
         assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == want, (E, d.stats["rollout_blocks"], d.stats["rollout_threads"])
     # outputs taken from a grandparent / the chosen child (same board) are part of forward_evals, and counted in reused_evals
     # (walker kernel; the lane-per-episode kernel -- hidden 32 here -- takes the grandparent's only)

@@ -708,9 +708,10 @@ bool mcts_deep_applies(const MctsArgs &a)
     if (force == 8 || force == 1 || (launch_options().az_variant & 7) == 2) return false;     // diagnostic: pin the lane-per-episode shapes
     if ((launch_options().az_variant & 7) >= 3) return true;                              // diagnostic: a pinned walker shape, whatever the batch
     // (eight walkers per workgroup against lane-per-episode: 8,192 x 100 45.9 / 61.1 ms, 12,288 x 100 64.1 / 68.0, 16,384 x 100 81.4 / 78.6,
-    //  8,192 x 50 26.8 / 28.9, 6,144 x 50 22.9 / 29.0, 8,192 x 32 19.7 / 17.8, 6,144 x 32 16.4 / 17.9)
+    //  8,192 x 50 25.3 / 28.4, 6,144 x 50 21.7 / 28.1, 8,192 x 32 19.7 / 17.8, 6,144 x 32 14.9 / 17.5, 4,096 x 24 9.2 / 9.5,
+    //  4,096 x 16 6.9 / 6.4, 4,096 x 8 4.4 / 3.5, 2,048 x 16 5.3 / 6.4, 2,048 x 8 3.4 / 3.4)
     const uint32_t S = a.num_searches;
-    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 48u : (S >= 48 ? 32u : (S >= 32 ? 24u : 16u)));
+    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 48u : (S >= 48 ? 32u : (S >= 32 ? 24u : (S >= 24 ? 16u : 8u))));
 }
 
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
