@@ -79,11 +79,16 @@ enum {
     TW_OPT_NO_PERSIST = 1,  /* 1: never use persistent lanes + episode queue                                               */
     TW_OPT_AZ_TREE_BUDGET_MIN = 4, /* walker kernel: cycles of tree walk after which a walker yields once another one waits; 0: auto */
     TW_OPT_AZ_TREE_BUDGET = 3, /* walker kernel: cycles of tree walk per forward before a walker yields; 0: automatic           */
+    TW_OPT_AZ_REUSE = 5,    /* lane-per-episode self-play kernel, how a node whose move takes its parent's move back finds   */
+                            /* the stored output of its grandparent (same board): 0 product, 1 no reuse, 2 / 3 / 4 see      */
+                            /* tw_mcts.hip (diagnostic forms kept for the record of DESIGN 5.5)                             */
     TW_OPT_AZ_VARIANT = 2   /* self-play with few deep searches: 0 automatic (walker-per-wave kernel where it applies),    */
                             /* 2 always the lane-per-episode kernel; walker kernel with a pinned shape: 3 / 4 / 5 / 6 =    */
                             /* two / one / four / eight walkers per workgroup, + 16 / + 32 = the 16- / 32-column engine    */
 };
 int tw_set_launch_option(int option, int value);
+/* Diagnostic counters of the last self-play launch of this process (MctsArgs::eval_count[0..15]); test hook. */
+int tw_debug_counters(uint64_t *out, int n);
 
 /* ---------------------------------------------------------------------------------------- */
 /* Env: host object with the PyBaseEnv / Puzzle surface.  Collectors only read its          */
@@ -349,6 +354,12 @@ typedef struct tw_comm tw_comm;
 int  tw_comm_get_unique_id(tw_comm_id *out);
 int  tw_comm_init(int rank, int world, const tw_comm_id *id, tw_comm **out);   /* collective; binds the current device */
 void tw_comm_destroy(tw_comm *c);
+/* How long tw_gather_finish waits for the transfers before it gives up, aborts the communicator (ncclCommAbort) and
+ * returns TW_ERR_HIP; 0 (default) = for ever.  Error behaviour of the exchange: whatever a rank can find wrong with the
+ * numbers of a step (layout, capacity, the root's allocation) travels with the step's count exchange, so ALL ranks return
+ * the error from the same call and nobody is left inside a collective; a failure of an RCCL / HIP call itself aborts
+ * that rank's communicator (every later call on it fails) and the peers leave through this timeout. */
+int  tw_comm_set_timeout_ms(tw_comm *c, uint32_t ms);
 int  tw_comm_rank(const tw_comm *c);
 int  tw_comm_world(const tw_comm *c);
 /* every rank holds a policy created from the same shapes; afterwards all hold the root's weights */
@@ -364,6 +375,19 @@ int  tw_comm_broadcast_policy(tw_comm *c, tw_policy *p, int root);
  * The submitted objects must stay alive until tw_gather_finish, which waits, frees the gather and (root only) returns the
  * merged result -- an ordinary tw_collected. */
 typedef struct tw_gather tw_gather;
+/* Placement of one step's chunks in the root's result -- pure host arithmetic (no device, no RCCL; tw_gather_submit calls
+ * it with the counts it has exchanged).  counts[world][TW_GATHER_COUNTS]: records, records of the chunk's last episode,
+ * episodes, first global episode, bytes per obs id, actions, status, 0.  *st: steps / max_records / max_episode_records
+ * set by the caller, step 0 at the start; front, cap, pos, tail are maintained by the function (front / cap decided in step
+ * 0: one step = exact size with the records of episode E-1 first, several = max_records + max_episode_records with that
+ * much slack in front).  Out: n_pieces[r] in {0, 1, 2} and pieces[r][2] = records [src_lo, src_hi) of rank r's chunk ->
+ * record offset dst of the root's buffers; *tail_rank = the rank whose chunk ends with episode E-1 (last step, else -1).
+ * The merged result is records [front - tail, front + pos) once every step is planned. */
+enum { TW_GATHER_COUNTS = 8 };
+typedef struct { uint64_t src_lo, src_hi, dst; } tw_gather_piece;
+typedef struct { uint32_t steps, step; uint64_t max_records, max_episode_records, pos, front, cap, tail; } tw_gather_state;
+int tw_gather_plan(tw_gather_state *st, int world, const uint64_t *counts, int32_t *tail_rank, uint32_t *n_pieces,
+                   tw_gather_piece *pieces);
 int tw_gather_begin(tw_comm *c, int root, uint32_t steps, uint64_t max_records, uint32_t max_episode_records,
                     uint64_t total_episodes, int is_ppo, uint32_t n_cells, tw_gather **out);
 int tw_gather_submit(tw_gather *g, const tw_collected *local, uint64_t episode_offset);

@@ -4,7 +4,7 @@ import sys
 sys.path.insert(0, ".")
 import torch
 import bench
-from tests.util import puzzle_transpose_twist
+from tests.util import amd_policy, puzzle_transpose_twist
 from twisterl_amd import twisterl
 
 def digest(d):
@@ -56,8 +56,29 @@ for E, S, rep, p in ((256, 60, n, pol0), (800, 40, n, pol), (1024, 50, n, pol0),
         elif dg != ref: bad += 1
     print("self-play E", E, "searches", S, "twists" if p is pol else "no twists", "launch", d.stats["rollout_blocks"], "x", d.stats["rollout_threads"],
           "repeats", rep, "mismatching repeats", bad, flush=True)
+# lane-per-episode kernel with the reused outputs active (>= 32 searches; hidden 32 / 64 / 256; plain, persistent, every pinned
+# geometry, deep trees whose search path outgrows the LDS levels)
+from twisterl_amd import _lib
+from tests.util import make_policy_arrays
+small = {h: amd_policy(make_policy_arrays(16, seed=3, emb=64, hidden=h)) for h in (32, 64)}
+for E, S, MED, p, fg, nop, rep in ((65536, 32, 1, pol, 0, 0, max(2, n // 3)), (16384, 100, 1, pol, 0, 0, max(2, n // 3)), (70000, 32, 2, pol0, 0, 0, max(2, n // 3)),
+                                    (70000, 32, 1, pol0, 0, 1, max(2, n // 3)), (3000, 48, 1, small[32], 0, 0, n), (3000, 48, 1, small[64], 0, 0, n),
+                                    (2000, 64, 1, pol0, 1, 0, n), (2000, 64, 1, pol0, 8, 0, n), (2000, 64, 1, pol, 32, 0, n), (70, 400, 2, pol0, 0, 0, n),
+                                    (300, 2000, 1, small[64], 0, 0, max(2, n // 3))):
+    env = twisterl.env.Puzzle(4, 4, 8, 2, 256)
+    coll = twisterl.collector.AZCollector(E, S, 1.41, MED, 1)
+    ref = None; bad = 0
+    with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, 2), _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, fg), _lib.launch_option(_lib.TW_OPT_NO_PERSIST, nop):
+        for i in range(rep):
+            d = coll.collect(env, p, seed=7)
+            dg = digest(d)
+            if ref is None: ref = dg
+            elif dg != ref: bad += 1
+    print("self-play, lane per episode: E", E, "searches", S, "max_expand_depth", MED, "hidden", p.common.layers[0].out_features,
+          "force_geom", fg, "no_persist", nop, "launch", d.stats["rollout_blocks"], "x", d.stats["rollout_threads"], "reused", d.stats["reused_evals"], "of", d.stats["forward_evals"],
+          "repeats", rep, "mismatching repeats", bad, flush=True)
 # policies of any depth (EngineV: inline-asm MFMA chains, weights and activations prefetched through running pointers)
-from tests.util import amd_policy, make_deep_policy_arrays
+from tests.util import make_deep_policy_arrays
 for kw, E, rep in ((dict(emb=508, common=(256,)), 65536, n), (dict(emb=512, common=(256, 256), policy_layers=(64,), value_layers=(64,)), 20000, n),
                    (dict(emb=96, common=(96, 32)), 4096, 4 * n)):
     polg = amd_policy(make_deep_policy_arrays(16, seed=0, **kw))

@@ -135,3 +135,54 @@ def test_config5_selfplay_full_size_vs_oracle(tw, oracle, searches, n_sample):
         assert np.array_equal(sl("obs").astype(np.int64), o.obs), e
         assert np.array_equal(f32_bits(sl("logits")), f32_bits(o.logits)), e
         assert np.array_equal(f32_bits(sl("remaining_values")), f32_bits(o.additional_data["remaining_values"])), e
+
+
+@pytest.mark.parametrize("E,searches,n_sample,threads", [(65_536, 32, 26, 512), (16_384, 100, 24, 256)])
+def test_selfplay_lane_per_episode_kernel_full_size_vs_oracle(tw, oracle, E, searches, n_sample, threads):
+    """`mcts_f32_kernel` (one lane pair per episode, tw_mcts.hip) at the sizes its numbers are quoted on: 65,536 x 32 (every
+    episode resident: 256 workgroups of 8 waves x 32 episodes) and 16,384 x 100 (four waves share 32 episodes, one persistent
+    workgroup per CU, episode queue), Puzzle-15, 512/256 policy, transpose twist.  A node whose move takes its parent's move
+    back takes its grandparent's stored output (reused_evals): same bits as the evaluation the reference repeats
+    (rust/src/rl/search.rs:132-164, collector/az.rs:51-109)."""
+    import twisterl_amd
+    from twisterl_amd import _lib
+    gp, op = _bench_policy(oracle, twists=True)
+    D = 8
+    env, oenv = tw.env.Puzzle(4, 4, D, 2, 256), oracle.Puzzle(4, 4, D, 2, 256)
+    coll = tw.collector.AZCollector(E, searches, 1.41, 1, 32)
+    g = coll.collect(env, gp, seed=900)
+    assert g.stats["rollout_threads"] == threads
+    assert g.stats["rollout_blocks"] == twisterl_amd.device_info()["compute_units"]
+    assert g.stats["speculative_evals"] == 0                      # (the walker kernel would report its look-ahead here)
+    assert 0 < g.stats["reused_evals"] < g.stats["forward_evals"]
+    assert _lib.debug_counters(13)[12] == 0                       # no stored output was ever offered for another board
+    t = g.to_torch()
+    n = len(g)
+    L = t["ep_len"].cpu().numpy().astype(np.int64)
+    S = t["ep_start"].cpu().numpy().astype(np.int64)
+    assert L.sum() == n and L.min() >= 1 and L.max() <= 2 * D + 1
+    order = np.concatenate([[E - 1], np.arange(E - 1)])
+    assert np.array_equal(S[order], np.concatenate([[0], np.cumsum(L[order])[:-1]]))
+    probs = t["logits"]
+    assert bool((probs >= 0).all()) and bool(((probs.sum(dim=1) - 1.0).abs() < 1e-5).all())
+    assert 2 * n <= g.stats["forward_evals"] <= 2 * n * (searches + 1)
+    h = coll.collect(env, gp, seed=900).to_torch()                # determinism (the queue: which lanes run an episode must not matter)
+    for k in t:
+        assert torch.equal(t[k], h[k]), k
+    del h
+    with _lib.launch_option(_lib.TW_OPT_AZ_REUSE, 1):             # and the same bytes when every output comes out of a forward
+        h = coll.collect(env, gp, seed=900)
+        assert h.stats["reused_evals"] == 0
+        h = h.to_torch()
+    for k in t:
+        assert torch.equal(t[k], h[k]), k
+    del h
+    for e in _sample_episodes(E, n_sample - 4, seed=11):
+        s, ln = int(S[e]), int(L[e])
+        o = oracle.az_collect(oenv, op, 1, searches, 1.41, 1, seed=900, episode_offset=e, arith=oracle.ARITH_CHAIN, merge_order=False,
+                              det_math=True)
+        assert ln == int(o.ep_len[0]), e
+        sl = lambda k: t[k][s:s + ln].cpu().numpy()
+        assert np.array_equal(sl("obs").astype(np.int64), o.obs), e
+        assert np.array_equal(f32_bits(sl("logits")), f32_bits(o.logits)), e
+        assert np.array_equal(f32_bits(sl("remaining_values")), f32_bits(o.additional_data["remaining_values"])), e

@@ -508,6 +508,34 @@ def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, 
         assert g.stats["forward_evals"] >= len(o.obs)      # at least the root evaluation of every move
 
 
+def test_az_output_reuse_below_the_search_path_kept_in_lds(tw, oracle):
+    """The lane-per-episode kernel keeps PATH_DEPTH = 8 levels of the search path in LDS; a node whose move takes its parent's
+    move back finds its grandparent (whose stored output it reuses) at level plen-3 of that path -- while the path fits.  Below
+    8 levels `push` stops recording and level plen-3 is an ancestor further up: the grandparent then comes from the parent
+    links.  (Round 2's first form read the path level at any depth -- TW_OPT_AZ_REUSE = 2 -- and so took the output of the wrong
+    node in deep trees: the "schedule-dependent" results of DESIGN 5.5.)  Deep trees (400 searches, max_expand_depth 2) with
+    every way of finding the grandparent: the bytes of the oracle; the diagnostic form counts the disagreements."""
+    import bench
+    arrs = bench.synthetic_weights(16, seed=0)                   # the benchmark's 512 / 256 policy (as scripts/az_reuse_probe.py)
+    gp, op = bench.build_policy(arrs, [], []), oracle.Policy(*arrs, [], [])
+    E, S, MED = 70, 400, 2
+    genv, oenv = tw.env.Puzzle(4, 4, 8, 2, 256), oracle.Puzzle(4, 4, 8, 2, 256)
+    coll = tw.collector.AZCollector(num_episodes=E, num_mcts_searches=S, C=1.41, max_expand_depth=MED, num_cores=32)
+    o = oracle.az_collect(oenv, op, E, S, 1.41, MED, seed=7, arith=oracle.ARITH_CHAIN, det_math=True, num_threads=8)
+    with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, 2):
+        for mode in (0, 1, 3, 4):
+            with _lib.launch_option(_lib.TW_OPT_AZ_REUSE, mode):
+                g = coll.collect(genv, gp, seed=7)
+                cnt = _lib.debug_counters(13)
+            _assert_same_az(g, o, 16)
+            assert (g.stats["reused_evals"] == 0) == (mode == 1)
+            assert cnt[12] == 0
+            if mode == 4:
+                # candidates; below PATH_DEPTH; there -- and only there -- the path level is not the grandparent
+                assert cnt[3] == g.stats["reused_evals"] > 0 and cnt[4] > 0 and cnt[5] == 0
+                assert cnt[6] == 0 and cnt[7] > 0 and cnt[8] == 0 and cnt[10] == 0 and cnt[11] == 0
+
+
 def test_az_reference_style_consumer(tw, oracle):
     """AZ.data_to_torch reads obs, logits (= MCTS probs) and additional_data['remaining_values']
     (src/twisterl/rl/az.py:30-34); values / rewards / actions stay empty (az.rs:97-104)."""

@@ -15,7 +15,7 @@ from . import build as _build
 TW_OK, TW_ERR_INVALID, TW_ERR_UNSUPPORTED, TW_ERR_NO_DEVICE, TW_ERR_HIP, TW_ERR_EMPTY = range(6)
 TW_PREC_F32_EXACT, TW_PREC_F16, TW_PREC_F16X2 = 0, 1, 2
 TW_EVAL_FORWARD, TW_EVAL_PREDICT, TW_EVAL_FULL_PREDICT = 0, 1, 2
-TW_OPT_FORCE_GEOM, TW_OPT_NO_PERSIST, TW_OPT_AZ_VARIANT, TW_OPT_AZ_TREE_BUDGET, TW_OPT_AZ_TREE_BUDGET_MIN = 0, 1, 2, 3, 4
+TW_OPT_FORCE_GEOM, TW_OPT_NO_PERSIST, TW_OPT_AZ_VARIANT, TW_OPT_AZ_TREE_BUDGET, TW_OPT_AZ_TREE_BUDGET_MIN, TW_OPT_AZ_REUSE = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 4
 (TW_F_OBS, TW_F_LOGITS, TW_F_PERMS, TW_F_VALUES, TW_F_REWARDS, TW_F_ACTIONS, TW_F_ADVS, TW_F_RETS,
  TW_F_REMAINING, TW_F_EP_LEN, TW_F_EP_START, TW_F_COUNT) = range(12)
@@ -101,6 +101,7 @@ SYMBOLS = {
     "tw_get_device_info": (C.c_int, [C.POINTER(DeviceInfo)]),
     "tw_release_cached_memory": (C.c_int, []),
     "tw_set_launch_option": (C.c_int, [C.c_int, C.c_int]),
+    "tw_debug_counters": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "tw_puzzle_create": (_VP, [C.c_uint32] * 5),
     "tw_puzzle_clone": (_VP, [_VP]),
     "tw_puzzle_destroy": (None, [_VP]),
@@ -160,6 +161,8 @@ SYMBOLS = {
     "tw_comm_rank": (C.c_int, [_VP]),
     "tw_comm_world": (C.c_int, [_VP]),
     "tw_comm_broadcast_policy": (C.c_int, [_VP, _VP, C.c_int]),
+    "tw_comm_set_timeout_ms": (C.c_int, [_VP, C.c_uint32]),
+    "tw_gather_plan": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), _VP]),
     "tw_gather_begin": (C.c_int, [_VP, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(_VP)]),
     "tw_gather_submit": (C.c_int, [_VP, _VP, C.c_uint64]),
     "tw_gather_finish": (C.c_int, [_VP, C.POINTER(_VP)]),
@@ -230,6 +233,13 @@ class launch_option:
     def __exit__(self, *exc):
         check(lib().tw_set_launch_option(self.option, 0))
         return False
+
+
+def debug_counters(n: int = 16) -> list:
+    """Diagnostic counters of this process's last self-play launch (tw_debug_counters)."""
+    buf = (C.c_uint64 * n)()
+    check(lib().tw_debug_counters(buf, n))
+    return [int(x) for x in buf]
 
 
 def device_count() -> int:

@@ -45,8 +45,11 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 hipStream_t current_stream() { return g_stream; }
 
 // ---------------------------------------------------------------------------------- launch options / per-device caches
-static std::atomic<int> g_force_geom{0}, g_no_persist{0}, g_az_variant{0}, g_az_tree_budget{0}, g_az_tree_budget_min{0};
-LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load(), g_az_variant.load(), g_az_tree_budget.load(), g_az_tree_budget_min.load()}; }
+static std::atomic<int> g_force_geom{0}, g_no_persist{0}, g_az_variant{0}, g_az_tree_budget{0}, g_az_tree_budget_min{0}, g_az_reuse{0};
+LaunchOptions launch_options() { return LaunchOptions{g_force_geom.load(), g_no_persist.load(), g_az_variant.load(), g_az_tree_budget.load(), g_az_tree_budget_min.load(), g_az_reuse.load()}; }
+// counters of the last self-play launch (eval_count[0..15], see MctsArgs): tw_debug_counters
+static std::mutex g_dbg_mutex;
+static unsigned long long g_dbg_counters[16];
 
 static std::mutex g_dev_mutex;
 
@@ -220,8 +223,19 @@ extern "C" int tw_set_launch_option(int option, int value)
         case TW_OPT_AZ_TREE_BUDGET_MIN:
             if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET_MIN: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }
             g_az_tree_budget_min.store(value); return TW_OK;
+        case TW_OPT_AZ_REUSE:
+            if (value < 0 || value > 4) { set_error("TW_OPT_AZ_REUSE: value %d not in {0 .. 4}", value); return TW_ERR_INVALID; }
+            g_az_reuse.store(value); return TW_OK;
         default: set_error("tw_set_launch_option: unknown option %d", option); return TW_ERR_INVALID;
     }
+}
+
+extern "C" int tw_debug_counters(uint64_t *out, int n)
+{
+    if (!out || n < 0) { set_error("tw_debug_counters: null argument"); return TW_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(g_dbg_mutex);
+    for (int i = 0; i < n; ++i) out[i] = i < 16 ? g_dbg_counters[i] : 0;
+    return TW_OK;
 }
 
 extern "C" int tw_release_cached_memory(void)
@@ -1222,7 +1236,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     const bool persist = deep || (E > resident && !launch_options().no_persist && !ma.pol.generic);
     const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
-                 o_total = seg(32), o_scan = seg(scan_scratch_bytes(E)),
+                 o_total = seg(136), o_scan = seg(scan_scratch_bytes(E)),
                  o_arena = seg(arenas * cap64 * (deep ? mcts_deep_node_bytes() : mcts_node_bytes())),
                  o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     size_t free_b = 0, total_b = 0;
@@ -1247,7 +1261,8 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
 
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
-    TW_HIP(hipMemsetAsync(ws + o_total, 0, 32, s));
+    TW_HIP(hipMemsetAsync(ws + o_total, 0, 136, s));
+    ma.reuse_mode = (uint32_t)launch_options().az_reuse;
     if (persist) {
         ma.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
         ma.queue = reinterpret_cast<unsigned int *>(ws + o_queue);
@@ -1264,10 +1279,18 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     rc = launch_scan(ma.out.ep_len, E, prm->merge_order ? 1 : 0, ep_start_ws, total_d, ws + o_scan, scan_scratch_bytes(E), s);
     if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[2], s));
-    uint64_t host_tot[4] = {0, 0, 0, 0};
-    TW_HIP(hipMemcpyAsync(host_tot, ws + o_total, 32, hipMemcpyDeviceToHost, s));
+    uint64_t host_tot[17] = {0};
+    TW_HIP(hipMemcpyAsync(host_tot, ws + o_total, 136, hipMemcpyDeviceToHost, s));
     TW_HIP(hipStreamSynchronize(s));
     const uint64_t total = host_tot[0];
+    {
+        std::lock_guard<std::mutex> dl(g_dbg_mutex);
+        for (int i = 0; i < 16; ++i) g_dbg_counters[i] = host_tot[1 + i];
+    }
+    if (host_tot[1 + 12] != 0) {       // eval_count[12]: a stored output offered for a board it was not computed for (never, by construction)
+        set_error("az collect: %llu reused network outputs failed the board check", (unsigned long long)host_tot[1 + 12]);
+        return TW_ERR_HIP;
+    }
     if (total == 0 || total > R) { set_error("az collect: inconsistent record count %llu (max %llu)", (unsigned long long)total, (unsigned long long)R); return TW_ERR_HIP; }
 
     tw_collected *c = new tw_collected();
@@ -1355,7 +1378,7 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
         set_error("solve: MCTS arenas of %llu attempts x %llu nodes do not fit", (unsigned long long)A, (unsigned long long)node_cap);
         return TW_ERR_UNSUPPORTED;
     }
-    const size_t o_cnt = seg(mcts ? 8 : 0), o_arena = seg(mcts ? (size_t)(A * node_cap) * mcts_node_bytes() : 0);
+    const size_t o_cnt = seg(mcts ? 128 : 0), o_arena = seg(mcts ? (size_t)(A * node_cap) * mcts_node_bytes() : 0);
     uint8_t *buf = nullptr;
     TW_HIP(hipMalloc((void **)&buf, cur ? cur : 256));
     sa.success = reinterpret_cast<float *>(buf + o_s); sa.total = reinterpret_cast<float *>(buf + o_r);
@@ -1372,7 +1395,8 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
         ma.solve.start_zy = sa.start_zy; ma.solve.start_depth = sa.start_depth;
         ma.solve.success = sa.success; ma.solve.total = sa.total; ma.solve.n_steps = sa.n_steps; ma.solve.actions = sa.actions;
         ma.solve.act_pad = sa.t_pad;
-        hipError_t me = hipMemsetAsync(buf + o_cnt, 0, 8, s);
+        ma.reuse_mode = (uint32_t)launch_options().az_reuse;
+        hipError_t me = hipMemsetAsync(buf + o_cnt, 0, 128, s);
         if (me != hipSuccess) { (void)hipFree(buf); return hip_fail(me, "hipMemsetAsync(eval counter)", __FILE__, __LINE__); }
         rc = launch_mcts_f32(ma, s, nullptr, nullptr);
     } else rc = launch_solve_f32(sa, s);

@@ -30,7 +30,7 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
 hipStream_t current_stream();
 
 // Diagnostic launch overrides (tw_set_launch_option; the tests pin launch shapes with them).  Read once per collect.
-struct LaunchOptions { int force_geom; int no_persist; int az_variant; int az_tree_budget; int az_tree_budget_min; };
+struct LaunchOptions { int force_geom; int no_persist; int az_variant; int az_tree_budget; int az_tree_budget_min; int az_reuse; };
 LaunchOptions launch_options();
 // Raises a kernel's dynamic-LDS limit above the 64 KiB default; cached per (kernel, device), thread-safe.
 int ensure_dynamic_lds(const void *kernel, size_t bytes);
@@ -473,7 +473,8 @@ struct MctsArgs {
     MctsNode    *arena;        // [num_episodes][node_cap]
     uint32_t     node_cap;
     unsigned long long *eval_count;   // [0] policy evaluations the searches consumed (leaf + root), [1] speculative ones (deep shape),
-                                      // [2] of [0]: outputs taken from the grandparent (a move taken back: same board; deep shape)
+                                      // [2] of [0]: outputs taken from the grandparent (a move taken back: same board)
+                                      // [3..11] TW_OPT_AZ_REUSE = 4 diagnostics, [12] reused outputs that failed the board check (16 entries)
     MctsSolve    solve;        // on == 0: AlphaZero self-play (records into `out`)
     // persistent-lane mode (self-play with more episodes than resident lanes, see RolloutArgs): the arena is then
     // [resident lanes][node_cap], a lane reuses its arena for every episode it takes
@@ -483,6 +484,7 @@ struct MctsArgs {
     uint32_t        lds_nodes;     // deep shape: nodes per tree whose statistics live in LDS (set by the launcher)
     uint32_t        tree_budget;   // deep shape: cycles of tree walk per trip after which a walker stops at the next search boundary (launcher)
     uint32_t        tree_budget_min;   // ... after which it stops there as soon as another walker of the workgroup waits for a forward
+    uint32_t        reuse_mode;        // lane-per-episode kernel: how a node that takes its parent's move back finds its grandparent's output (TW_OPT_AZ_REUSE)
 };
 size_t mcts_node_bytes();
 // the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue

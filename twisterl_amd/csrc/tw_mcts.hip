@@ -381,12 +381,35 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
                     const PuzzleLane s = lane_of(n, env);
                     value = puzzle_reward(s, env);                                   // :146
                     if (puzzle_final(s, env)) break;                                 // :149
-                    // a node whose move took its parent's move back holds the board of its grandparent (verified: parent chain
-                    // and boards are read back), whose output is stored: expand with it, sample a child, go on (search.rs:154-159)
+                    // a node whose move took its parent's move back holds the board of its grandparent, whose output is stored:
+                    // expand with it, sample a child, go on (search.rs:154-159).  The grandparent is level plen-3 of the search path
+                    // (level plen-1 is `node`) while the path fits its PATH_DEPTH levels; below that `push` stops recording -- plen
+                    // stays at PATH_DEPTH and level plen-3 is an ancestor further up -- so it is found through the parent links.
+                    // a.reuse_mode (TW_OPT_AZ_REUSE, diagnostic): 0 as described, 1 no reuse, 2 the path level whatever the depth
+                    // (round 2's first form: WRONG below PATH_DEPTH levels, kept to show it), 3 parent links only, 4 counts how the
+                    // two ways of finding the grandparent disagree (eval_count[3..11]) and goes by the parent links
                     uint32_t g = NONE;
-                    if (n.action != 0xffu && (n.action & ACT_UNDO) && n.parent != NONE && n.parent != 0u) {
-                        const uint32_t gp = nodes[n.parent].parent;
-                        if (gp != NONE && nodes[gp].board == n.board && nodes[gp].n_children != 0) g = gp;
+                    if (n.action != 0xffu && (n.action & ACT_UNDO) && a.reuse_mode != 1u) {
+                        uint32_t g_path = NONE, g_link = NONE;
+                        const bool deep_path = overflow;
+                        if (a.reuse_mode == 2u || a.reuse_mode == 4u || (a.reuse_mode == 0u && !deep_path))
+                            if (plen >= 3) g_path = p_idx[(plen - 3) * Eng::EPB];
+                        if (a.reuse_mode == 3u || a.reuse_mode == 4u || (a.reuse_mode == 0u && deep_path))
+                            if (n.parent != NONE && n.parent != 0u) g_link = nodes[n.parent].parent;
+                        if (a.reuse_mode == 4u) {
+                            atomicAdd(a.eval_count + 3, 1ull);
+                            if (deep_path) atomicAdd(a.eval_count + 4, 1ull);
+                            if (plen < 3) atomicAdd(a.eval_count + 5, 1ull);
+                            if (g_path != g_link) atomicAdd(a.eval_count + (deep_path ? 7 : 6), 1ull);
+                            if (g_link == NONE || nodes[g_link].board != n.board || nodes[g_link].n_children == 0) atomicAdd(a.eval_count + 8, 1ull);
+                            if (g_path == NONE || nodes[g_path].board != n.board || nodes[g_path].n_children == 0) atomicAdd(a.eval_count + 9, 1ull);
+                            if (!deep_path && (plen < 1 || p_idx[(plen - 1) * Eng::EPB] != node)) atomicAdd(a.eval_count + 10, 1ull);
+                            if (!deep_path && (plen < 2 || p_idx[(plen - 2) * Eng::EPB] != n.parent)) atomicAdd(a.eval_count + 11, 1ull);
+                        }
+                        g = (a.reuse_mode == 2u || (a.reuse_mode == 0u && !deep_path)) ? g_path : g_link;
+                        // tripwire, not a filter: the grandparent's board IS this node's board (every child is a legal move, so the
+                        // move back restores it) and it was expanded on the way down; a failure is counted and fails the collect
+                        if (g != NONE && a.reuse_mode != 2u && (nodes[g].board != n.board || nodes[g].n_children == 0)) { atomicAdd(a.eval_count + 12, 1ull); g = NONE; }
                     }
                     if (g == NONE) { phase = PH_LEAF; leaf = s; need_nn = true; break; }       // :154 needs the network
                     const uint4 o2 = outs[2 * g], o3 = outs[2 * g + 1];

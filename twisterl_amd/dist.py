@@ -69,6 +69,33 @@ def chunk_range(bounds: List[int], step: int, rank: int, world: int) -> Tuple[in
     return a + lo, a + hi
 
 
+def plan_step(counts: List[int], lasts: List[int], last_step: bool, front: int, pos: int):
+    """Placement of one step's chunks in the root's buffers (pure arithmetic; the C ABI's twin is tw_gather_plan, and
+    tests/test_gather_plan.py holds the two against each other).  counts[r] / lasts[r]: records of rank r's chunk / of its
+    last episode.  Returns (tail, tail_rank, pieces, pos_after): pieces[r] = [(src_lo, src_hi, dst_lo), ..] with dst_lo
+    relative to the start of the output buffers; episode E-1 -- the last episode of the last NON-EMPTY chunk of the last
+    step -- goes in front of everything else (collector.rs:40-46)."""
+    world = len(counts)
+    tail, tail_rank = 0, -1
+    if last_step:
+        for r in range(world - 1, -1, -1):
+            if counts[r] > 0:
+                tail, tail_rank = lasts[r], r
+                break
+    pieces, p = [], pos
+    for r in range(world):
+        n = counts[r]
+        if n == 0:
+            pieces.append([])
+        elif r == tail_rank:
+            body = n - tail
+            pieces.append([(body, n, front - tail)] + ([(0, body, front + p)] if body > 0 else []))
+        else:
+            pieces.append([(0, n, front + p)])
+        p += n - (tail if r == tail_rank else 0)
+    return tail, tail_rank, pieces, p
+
+
 class TrajectoryGather:
     """Gathers compact trajectories to `dst` in the reference merge order, step by step (see the module docstring).
 
@@ -120,47 +147,27 @@ class TrajectoryGather:
         dist.all_gather(allc, mine, group=self.group)
         counts = [int(c[0].item()) for c in allc]
         lasts = [int(c[1].item()) for c in allc]
-        # episode E-1 is the last episode of the last NON-EMPTY chunk of the last step (with E >= 1 there is one)
-        tail, tail_rank = 0, -1
-        if last_step:
-            for r in range(self.world - 1, -1, -1):
-                if counts[r] > 0:
-                    tail, tail_rank = lasts[r], r
-                    break
+        tail, tail_rank, pieces, _ = plan_step(counts, lasts, last_step, 0, self.pos)       # (the tail: front is not known yet)
         if self.rank == self.dst and self.step == 0:
             self._alloc(fields, names, sum(counts), tail)
         if last_step:
             self.tail = tail
-
         # (src_lo, src_hi, dst_lo) pieces per rank for this step; dst_lo relative to the start of the output buffers
-        def pieces(r):
-            n = counts[r]
-            if r == tail_rank:
-                body = n - tail
-                out = [(body, n, self.front - tail)]
-                if body > 0:
-                    out.append((0, body, self.front + pos_of[r]))
-                return out
-            return [(0, n, self.front + pos_of[r])] if n > 0 else []
-
-        pos_of, p = [], self.pos
-        for r in range(self.world):
-            pos_of.append(p)
-            p += counts[r] - (tail if r == tail_rank else 0)
+        tail, tail_rank, pieces, p = plan_step(counts, lasts, last_step, self.front, self.pos)
         if self.rank == self.dst and self.front + p > next(iter(self.buf.values())).shape[0]:
             raise RuntimeError(f"TrajectoryGather: {p} records exceed max_records={self.max_records}")
 
         ops = []
         if self.rank == self.dst:
             for r in range(self.world):
-                for (lo, hi, d) in pieces(r):
+                for (lo, hi, d) in pieces[r]:
                     for n in names:
                         if r == self.rank:
                             self.buf[n][d:d + hi - lo].copy_(fields[n][lo:hi])
                         else:
                             ops.append(dist.P2POp(dist.irecv, self.buf[n][d:d + hi - lo], r, self.group))
         else:
-            for (lo, hi, _) in pieces(self.rank):
+            for (lo, hi, _) in pieces[self.rank]:
                 for n in names:
                     t = fields[n][lo:hi].contiguous()
                     self.keep.append(t)
