@@ -221,7 +221,9 @@ typedef struct {
 typedef struct {
     void    *prototype;
     uint32_t num_actions;                 /* Env::num_actions (<= 31)                                   */
-    uint32_t n_obs, obs_size;             /* observe() returns n_obs ids, each < obs_size (<= 65535)    */
+    uint32_t n_obs, obs_size;             /* observe() returns EXACTLY n_obs ids for every state, each  */
+                                          /* < obs_size (<= 65535): fixed-length observations only; an  */
+                                          /* id >= obs_size fails the collect (the reference panics)    */
     void  *(*clone)(void *env);
     void   (*destroy)(void *env);
     void   (*reset)(void *env, uint64_t seed, uint64_t episode);

@@ -169,3 +169,47 @@ def test_conv1d_embeddingbag_dense_table_matches_reference_rule():
         twisterl.nn.EmbeddingBag(vec.tolist(), [0.0] * 5, True, [4, 4], 0).dense_table()
     with pytest.raises(ValueError):
         twisterl.nn.EmbeddingBag(vec.tolist(), [0.0], True, [4, 4, 4], 0)
+
+
+def test_pyenv_bridge_refuses_observations_that_do_not_fit_the_buffers():
+    """The C side hands the env callbacks buffers of n_obs ids / num_actions flags (tw_env_vtable): an observe() of another
+    length, an id outside obs_shape or a masks() of another length must raise instead of writing past the buffer or leaving
+    stale ids in it (the callbacks are exercised directly: no device needed)."""
+    import ctypes as C
+    from tests.gridworld_env import GridWorld
+    from twisterl_amd.collector import _PyEnvBridge
+    from twisterl_amd.env import PyEnv
+
+    class Odd(GridWorld):
+        mode = "ok"
+
+        def copy(self):
+            c = Odd(self.width, self.height, self.max_steps)
+            c.steps_left, c.agent, c.goal, c.trap, c.mode = self.steps_left, self.agent, self.goal, self.trap, self.mode
+            return c
+
+        def observe(self):
+            o = super().observe()
+            return {"long": o + [0], "short": o[:-1], "range": o[:-1] + [10 ** 6]}.get(self.mode, o)
+
+        def masks(self):
+            m = super().masks()
+            return m + [True] if self.mode == "masks" else m
+
+    for mode, exc in (("ok", None), ("long", ValueError), ("short", ValueError), ("range", IndexError), ("masks", ValueError)):
+        env = Odd(3, 3, 5)
+        br = _PyEnvBridge(PyEnv(env))
+        n_obs = br.vt.n_obs
+        env.mode = mode                                             # the prototype (handle 1) now misbehaves
+        obs = (C.c_int32 * (n_obs + 4))(*([-7] * (n_obs + 4)))
+        msk = (C.c_uint8 * 8)(*([9] * 8))
+        br.vt.observe(1, obs)
+        br.vt.masks(1, msk)
+        assert list(obs[n_obs:]) == [-7] * 4 and list(msk[4:]) == [9] * 4      # nothing was written past the buffers
+        if exc is None:
+            assert not br.err and all(0 <= v < 81 for v in obs[:n_obs])
+            br.finish(0)
+        else:
+            assert br.err and isinstance(br.err[0], exc)
+            with pytest.raises(exc):
+                br.finish(0)

@@ -368,14 +368,27 @@ class _PyEnvBridge:
         def f_step(h, a):
             envs[h].next(int(a))
 
+        # The C side hands out buffers of exactly n_obs ids / num_actions flags per state (tw_env_vtable): an environment whose
+        # observe() changes length (legal for the reference's EmbeddingBag, layers.rs:56-62) is refused here instead of writing
+        # past the buffer or leaving stale ids in it -- see PyEnv's docstring.
         @guard()
         def f_observe(h, out_p):
-            for i, v in enumerate(envs[h].observe()):
-                out_p[i] = int(v)
+            obs = envs[h].observe()
+            if len(obs) != n_obs:
+                raise ValueError(f"PyEnv: observe() returned {len(obs)} ids, the prototype returned {n_obs}; this collector needs a "
+                                 "fixed number of obs ids per state")
+            for i, v in enumerate(obs):
+                v = int(v)
+                if not 0 <= v < obs_size:
+                    raise IndexError(f"PyEnv: obs id {v} outside the obs_shape's {obs_size} ids")      # (the reference panics: layers.rs:61)
+                out_p[i] = v
 
         @guard()
         def f_masks(h, out_p):
-            for i, v in enumerate(envs[h].masks()):
+            masks = envs[h].masks()
+            if len(masks) != n_actions:
+                raise ValueError(f"PyEnv: masks() returned {len(masks)} flags for {n_actions} actions")
+            for i, v in enumerate(masks):
                 out_p[i] = 1 if v else 0
 
         @guard(0.0)
@@ -390,13 +403,13 @@ class _PyEnvBridge:
         def f_success(h):
             return 1 if envs[h].success() else 0         # PyEnvImpl::success (pyenv.rs:141-149)
 
-        n_obs = len(proto.observe())
+        n_obs, n_actions = len(proto.observe()), int(proto.num_actions())
         obs_size = 1
         for x in proto.obs_shape():
             obs_size *= int(x)
         fields = dict(V._fields_)
         self._keep = (f_clone, f_destroy, f_reset, f_step, f_observe, f_masks, f_reward, f_final, f_success)
-        self.vt = V(1, int(proto.num_actions()), n_obs, obs_size, fields["clone"](f_clone), fields["destroy"](f_destroy), fields["reset"](f_reset),
+        self.vt = V(1, n_actions, n_obs, obs_size, fields["clone"](f_clone), fields["destroy"](f_destroy), fields["reset"](f_reset),
                     fields["step"](f_step), fields["observe"](f_observe), fields["masks"](f_masks), fields["reward"](f_reward),
                     fields["is_final"](f_final), fields["success"](f_success))
         self.max_records = int(getattr(proto, "max_records", 1 << 16))

@@ -141,7 +141,11 @@ class PyEnv:
     obs_shape(), reset(difficulty), next(action), masks(), is_final(), value(), success(), observe(), set_state(state).
     Its code runs on the host -- as in the reference -- while the policy forward of all live episodes of a time step is one
     batched launch on the GPU (tw_ppo_collect_env).  Build extension: if `pyenv` has seed_episode(seed, episode) it is
-    called before every reset(), so that a collect is reproducible (the reference's envs draw from OS entropy)."""
+    called before every reset(), so that a collect is reproducible (the reference's envs draw from OS entropy).
+    Restriction: observe() must return the SAME NUMBER of ids for every state (the prototype's) and masks() one flag per
+    action -- the C side's per-state buffers have that size (tw_env_vtable.n_obs); the reference's EmbeddingBag would also
+    take observations of varying length (layers.rs:56-62).  A different length, or an id outside obs_shape, raises from
+    collect() / evaluate() / solve()."""
 
     def __init__(self, pyenv):
         for m in ("copy", "num_actions", "obs_shape", "reset", "next", "masks", "is_final", "value", "observe"):
