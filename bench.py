@@ -36,15 +36,15 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0, "fp16x2": 2500.0}     # MI355X_MIC
 def measured_traffic_per_record(kernel="rollout_f32"):
     """HBM bytes per record of the rollout kernel from the committed rocprofv3 PMC passes (the latest round's
     profiles/rNN_hbm_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)."""
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             for k, v in d.items():
                 if isinstance(v, dict) and (k.endswith(kernel) or (kernel == "rollout_f32" and kernel in k)):
-                    return float(v["bytes_per_record"])
+                    return float(v["bytes_per_record"]), "profiles/" + name
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def synthetic_weights(n2: int, seed: int = 0):
@@ -97,6 +97,60 @@ def cpu_baseline(arrs, obs_perms, act_perms, side, difficulty, target_seconds, t
     return {"value": len(d.values) / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{E} episodes ({len(d.values)} records) of the same Puzzle workload, reference-order f32 "
                       f"arithmetic, {cores} threads, {dt:.1f} s"}
+
+
+def side_configs(twisterl, torch):
+    """BASELINE.json configs 1, 2 and 5 at full size, N = 1 only: Puzzle-8 PPO rollouts (1,024 envs exact f32 = config 1's batch on
+    the GPU; 65,536 envs with the f16-input forward = config 2), AlphaZero self-play on Puzzle-15 at the reference's per-GPU batch
+    (4,096 episodes x 100 and x 1,000 searches, src/twisterl/defaults.py:84-91) and at the reference's default (512 x 1,000).
+    Median of three collects each after one warm-up; every entry carries its own roofline fraction."""
+    out = {}
+
+    def timed(c, env, pol):
+        c.collect(env, pol, seed=1)
+        rs = []
+        for i in range(3):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            d = c.collect(env, pol, seed=2 + i)
+            torch.cuda.synchronize()
+            rs.append((time.perf_counter() - t1, len(d), dict(d.stats)))
+            del d
+        rs.sort(key=lambda r: r[0])
+        return rs[1]
+
+    try:
+        arrs8 = synthetic_weights(9, seed=0)
+        pol8 = build_policy(arrs8, [], [])
+        env8 = twisterl.env.Puzzle(3, 3, 32, 2, 256)                      # examples/ppo_puzzle8_v1.json at diff_max 32: <= 65 records
+        for key, E, prec in (("config1_puzzle8_1k_f32", 1024, "fp32"), ("config2_puzzle8_65k_fp16", 65_536, "fp16"), ("config2_puzzle8_65k_f32", 65_536, "fp32")):
+            c = twisterl.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32}, precision=prec)
+            dt1, n, st = timed(c, env8, pol8)
+            k = st["ms_rollout"] * 1e-3
+            tf = n * FLOP_PER_RECORD[9] / k / 1e12
+            out[key] = {"value": n / dt1, "unit": "env-steps/s", "ms_per_step": dt1 * 1e3, "kernel_ms": k * 1e3, "records": n, "envs": E,
+                        "dtype": "f16" if prec == "fp16" else "f32",
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS[prec]}}
+    except Exception as e:           # the headline line must not depend on a side measurement
+        out["config2_error"] = str(e)
+    try:
+        arrs = synthetic_weights(16, seed=0)
+        pol = build_policy(arrs, [], [])                                  # the reference's AZ clears the twists (src/twisterl/rl/az.py:23-25)
+        env = twisterl.env.Puzzle(4, 4, 8, 2, 256)
+        for key, E, S in (("config5_az_4096x100", 4096, 100), ("config5_az_4096x1000", 4096, 1000), ("config5_az_512x1000_reference_default", 512, 1000)):
+            c = twisterl.collector.AZCollector(E, S, 1.41, 1, 32)
+            dt1, n, st = timed(c, env, pol)
+            k = st["ms_rollout"] * 1e-3
+            consumed, fwd_only = st["forward_evals"], st["forward_evals"] - st["reused_evals"]
+            tf = consumed * FLOP_PER_RECORD[16] / k / 1e12
+            out[key] = {"value": consumed / dt1, "unit": "leaf evaluations/s (Policy::full_predict calls the searches consume = what the reference evaluates)",
+                        "ms_per_step": dt1 * 1e3, "kernel_ms": k * 1e3, "records": n, "episodes": E, "searches": S,
+                        "forward_evals": consumed, "reused_evals": st["reused_evals"], "speculative_evals": st["speculative_evals"],
+                        "launch": [st["rollout_blocks"], st["rollout_threads"]],
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["fp32"],
+                                     "frac_outputs_of_a_forward_only": fwd_only * FLOP_PER_RECORD[16] / k / 1e12 / PEAK_TFLOPS["fp32"]}}
+    except Exception as e:
+        out["config5_error"] = str(e)
+    return out
 
 
 STRONG_TOTAL_ENVS = 2_097_152      # BASELINE.json config 4: "2M envs sharded over 8 x MI355X"
@@ -276,7 +330,7 @@ def main():
     if rank == 0:
         kern_s = float(np.mean(ms_rollout)) * 1e-3
         rec_per_launch = records / args.steps
-        tpr = measured_traffic_per_record({"fp32": "rollout_f32", "fp16": "rollout_f16", "fp16x2": "rollout_f16x2"}[args.precision]) if args.puzzle == 15 else None
+        tpr, tpr_file = measured_traffic_per_record({"fp32": "rollout_f32", "fp16": "rollout_f16", "fp16x2": "rollout_f16x2"}[args.precision]) if args.puzzle == 15 else None
         achieved = rec_per_launch * FLOP_PER_RECORD[n2] / kern_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
         out = {
@@ -306,9 +360,12 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "tw::rollout_f32_kernel" if args.precision == "fp32" else "tw::rollout_f16_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                # HBM bytes per launch: PMC-measured bytes/record (profiles/r01_hbm_traffic.json) x records of this launch
+                # HBM bytes per launch -- NOT a counter read in this run (PMC passes need rocprofv3 around the process): the
+                # PMC-measured bytes per record of the committed profile x the records of this launch
                 "traffic": (tpr * rec_per_launch) if tpr is not None else None,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in profiles/ (FETCH x2 per the gfx950 note)",
+                "traffic_from_profile": True,
+                "traffic_source": f"{tpr_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (FETCH x2 per the gfx950 note), "
+                                  "bytes per record x the records of this run's launch; not measured in this run",
                 "kernel_ms": kern_s * 1e3, "flop_per_record": FLOP_PER_RECORD[n2],
                 "hbm_bytes_per_record": BYTES_PER_RECORD[n2],
                 "hbm_frac": rec_per_launch * BYTES_PER_RECORD[n2] / kern_s / 8e12,
@@ -339,6 +396,8 @@ def main():
                     return {"error": str(e)}
             out["f16x2_mode_f32_equivalent"] = side_mode("fp16x2")
             out["f16_input_mode"] = side_mode("fp16")
+            # BASELINE.json's other single-GPU configurations on the same clock (side entries, outside the headline's timed region)
+            out.update(side_configs(twisterl, torch))
         if not args.no_cpu_baseline and world == 1 and not use_dist:     # timed on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(arrs, obs_perms, act_perms, side, args.difficulty, args.cpu_seconds, args.cpu_threads)
         sys.stdout.flush()

@@ -50,3 +50,44 @@ def test_self_launch_relays_the_childs_failure():
         pytest.skip("GPU present")
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and '"metric"' not in r.stdout
+
+
+def test_side_config_schema():
+    """bench.py's side entries (BASELINE.json configs 1, 2 and 5 on the driver's clock): the keys and fields the line carries,
+    checked against a stand-in collector (no GPU here; on the GPU box the real line is produced by bench.py itself)."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+
+    class _Data:
+        def __init__(self, n, stats):
+            self._n, self.stats = n, stats
+
+        def __len__(self):
+            return self._n
+
+    class _Coll:
+        def __init__(self, *a, **k):
+            self.E = a[0] if a else k["num_episodes"]
+
+        def collect(self, env, pol, seed=None):
+            return _Data(10 * self.E, {"ms_rollout": 1.0, "forward_evals": 40 * self.E, "reused_evals": 10 * self.E, "speculative_evals": 0,
+                                       "rollout_blocks": 256, "rollout_threads": 512})
+
+    fake = types.SimpleNamespace(collector=types.SimpleNamespace(PPOCollector=_Coll, AZCollector=_Coll), env=types.SimpleNamespace(Puzzle=lambda *a: None))
+    real_build, real_sync = bench.build_policy, torch.cuda.synchronize
+    bench.build_policy, torch.cuda.synchronize = (lambda *a: None), (lambda: None)
+    try:
+        out = bench.side_configs(fake, torch)
+    finally:
+        bench.build_policy, torch.cuda.synchronize = real_build, real_sync
+    assert set(out) == {"config1_puzzle8_1k_f32", "config2_puzzle8_65k_fp16", "config2_puzzle8_65k_f32", "config5_az_4096x100", "config5_az_4096x1000",
+                        "config5_az_512x1000_reference_default"}
+    for k, v in out.items():
+        assert {"value", "unit", "ms_per_step", "kernel_ms", "records", "roofline"} <= set(v), k
+        assert {"bound", "achieved", "peak", "unit", "frac"} <= set(v["roofline"]) and 0 < v["roofline"]["frac"]
+        if k.startswith("config5"):
+            assert {"forward_evals", "reused_evals", "episodes", "searches", "launch"} <= set(v)
+            assert v["roofline"]["frac_outputs_of_a_forward_only"] < v["roofline"]["frac"]
+    json.dumps(out)
