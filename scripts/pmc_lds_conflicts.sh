@@ -5,7 +5,8 @@
 set -e
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/lds; mkdir -p $out
-TW_ABLATE=1 python3 -m twisterl_amd.build --force > $out/build.log 2>&1
+export TW_ABLATE=1   # the instrumented library lives in twisterl_amd/lib/ablate/ and is loaded only while this is set
+python3 -m twisterl_amd.build > $out/build.log 2>&1
 for dbg in 0 1 2 4 8; do
   (cd /tmp && TW_ROLLOUT_DBG=$dbg rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d $out/d$dbg -o p -f csv -- python3 $OLDPWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --envs 65536 > $out/d$dbg.log 2>&1) || echo "dbg $dbg: rocprofv3 failed"
   f=$(ls $out/d$dbg/*counter_collection.csv 2>/dev/null | head -1)

@@ -17,8 +17,12 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-LIB_DIR = os.path.join(PKG, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libtwisterl_hip.so")
+# The diagnostic variant (TW_ABLATE=1 in the environment: -DTW_ABLATE, cycle stamps and knock-out switches) is a DIFFERENT
+# library in its own directory: the product library is never overwritten by an instrumented build, and a process loads the
+# instrumented one only while TW_ABLATE is set.
+ABLATE = bool(os.environ.get("TW_ABLATE"))
+LIB_DIR = os.path.join(PKG, "lib", "ablate") if ABLATE else os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtwisterl_hip_ablate.so" if ABLATE else "libtwisterl_hip.so")
 SOURCES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip")))
 # every header is a dependency of every object (an edited header must never leave a stale object behind)
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
@@ -48,7 +52,7 @@ def _stale(target: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     flags = list(FLAGS)
-    if os.environ.get("TW_ABLATE"):      # timing-only ablation variants of the rollout kernel (profiling aid)
+    if ABLATE:                           # timing-only ablation variants of the kernels (profiling aid)
         flags.append("-DTW_ABLATE")
     if os.environ.get("TW_EXTRA_FLAGS"):
         flags += os.environ["TW_EXTRA_FLAGS"].split()
@@ -85,6 +89,8 @@ def build_c_example() -> str:
     if _stale(exe, [src, LIB_PATH, os.path.join(ROOT, "include", "twisterl_hip.h")]):
         cmd = ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-L", LIB_DIR, "-ltwisterl_hip",
                "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,$ORIGIN/../twisterl_amd/lib", "-lm", "-o", exe]
+        if ABLATE:
+            return exe                   # (the example links the product library only)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"gcc failed on collect_from_c.c:\n{r.stdout}")

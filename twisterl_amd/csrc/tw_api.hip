@@ -1239,6 +1239,9 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
                  o_total = seg(136), o_scan = seg(scan_scratch_bytes(E)),
                  o_arena = seg(arenas * cap64 * (deep ? mcts_deep_node_bytes() : mcts_node_bytes())),
                  o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
+    const uint32_t tbl_entries = deep ? mcts_deep_table_entries(ma.num_searches, ma.max_expand_depth) : 0;
+    const size_t tbl_bytes = (size_t)arenas * tbl_entries * 32;
+    const size_t o_tbl = seg(tbl_bytes);
     size_t free_b = 0, total_b = 0;
     TW_HIP(hipMemGetInfo(&free_b, &total_b));
     {   // what can actually be had: free memory plus the cached workspace this call would replace
@@ -1263,6 +1266,10 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     tw_collect_stats st{};
     TW_HIP(hipMemsetAsync(ws + o_total, 0, 136, s));
     ma.reuse_mode = (uint32_t)launch_options().az_reuse;
+    if (deep) {          // the walkers' board-keyed output tables start empty (the policy may have changed since the last collect)
+        ma.tbl = ws + o_tbl; ma.tbl_entries = tbl_entries;
+        TW_HIP(hipMemsetAsync(ws + o_tbl, 0, tbl_bytes, s));
+    }
     if (persist) {
         ma.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
         ma.queue = reinterpret_cast<unsigned int *>(ws + o_queue);

@@ -484,6 +484,8 @@ struct MctsArgs {
     uint32_t        lds_nodes;     // deep shape: nodes per tree whose statistics live in LDS (set by the launcher)
     uint32_t        tree_budget;   // deep shape: cycles of tree walk per trip after which a walker stops at the next search boundary (launcher)
     uint32_t        tree_budget_min;   // ... after which it stops there as soon as another walker of the workgroup waits for a forward
+    void           *tbl;               // deep shape: board-keyed output tables, [walkers][tbl_entries][32 bytes], zeroed before the launch
+    uint32_t        tbl_entries;       // ... entries per walker (a power of two)
     uint32_t        reuse_mode;        // lane-per-episode kernel: how a node that takes its parent's move back finds its grandparent's output (TW_OPT_AZ_REUSE)
 };
 size_t mcts_node_bytes();
@@ -491,6 +493,7 @@ size_t mcts_node_bytes();
 bool     mcts_deep_applies(const MctsArgs &a);
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches);   // tree arenas = episodes in flight
 size_t   mcts_deep_node_bytes();
+uint32_t mcts_deep_table_entries(uint32_t num_searches, uint32_t max_expand_depth);     // per walker, 32 bytes each
 int      launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_finalize_az(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,

@@ -22,9 +22,13 @@
 //     expanded by four lanes, the search path lives one level per lane (back-propagation is ONE store instruction);
 //   * workgroups are persistent: a walker whose episode is over takes the next one from the queue (start boards from
 //     init_boards_kernel), its tree arena is reused;
-//   * a child whose move takes its parent's move back (every expanded node below the root's children has one: the blank can
-//     always go back) holds its GRANDPARENT's board, and the network output is a function of the board alone: such a node takes
-//     the grandparent's stored output instead of a column of a forward -- the same bits the reference computes a second time.
+//   * the network output is a function of the BOARD alone, and a search meets the same boards over and over: a child whose move
+//     takes its parent's move back holds its grandparent's board, that child's children hold the boards of the grandparent's
+//     children, the tree of the next move is the tree of this one seen from a neighbouring root ...  Every output a search
+//     expands a node with is therefore kept in a per-walker table keyed by the packed board (direct-mapped, overwritten on
+//     collision, kept across the walker's episodes: MctsArgs::tbl), and a leaf that holds no output asks the table before it
+//     asks for a forward -- the same bits the reference computes again (CPU count, 100 searches: 31 % of the leaf evaluations
+//     repeat the grandparent's board, 27 % another board of the same tree, 28 % a board of an earlier move's tree).
 // 64 bytes per node in the walker's arena, as separate arrays: statistics (touched only beyond the nodes kept in LDS), boards,
 // and the stored network outputs (written once and read at most once -- non-temporal): what a walk re-reads stays small enough
 // for the weights and the trees of the 32 CUs of an XCD to share its 4 MB L2 (eight walkers per CU: 105 M L2 misses per
@@ -40,6 +44,16 @@ namespace tw {
 //   out: masked-softmax probs[4] of full_predict (f32 bits) | network value (f32 bits), 0, 0, 0 -- once evaluated ahead of the search
 constexpr size_t DEEP_NODE_BYTES = 64;
 size_t mcts_deep_node_bytes() { return DEEP_NODE_BYTES; }
+// Entries of a walker's board-keyed output table: about eight times the nodes one move's searches expand (an episode expands
+// ~0.15 x searches NEW boards per move, CPU count), between 1,024 and 16,384 -- 32 KiB to 512 KiB per walker.  Direct-mapped and
+// overwritten on collision: whatever the table forgets costs a column of a forward, never a bit of the result.
+uint32_t mcts_deep_table_entries(uint32_t num_searches, uint32_t max_expand_depth)
+{
+    const uint64_t want = 8ull * num_searches * (max_expand_depth ? max_expand_depth : 1u);
+    uint32_t t = 1024;
+    while (t < want && t < 16384u) t <<= 1;
+    return t;
+}
 
 constexpr uint32_t DNONE = 0xffffffffu;
 constexpr int DEEP_WAVES = 4;            // waves that run the forward; the first NWK (1, 2, 4) of them are walkers -- or, with NWK = 8 on the
@@ -132,7 +146,24 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     uint8_t *arena_w = reinterpret_cast<uint8_t *>(a.arena) + slot * (uint64_t)a.node_cap * DEEP_NODE_BYTES;
     ux4   *hotq = reinterpret_cast<ux4 *>(arena_w);                                   // [node_cap] statistics
     uint4 *brdq = reinterpret_cast<uint4 *>(arena_w + (size_t)a.node_cap * 16);       // [node_cap] boards
-    ux4   *outs = reinterpret_cast<ux4 *>(arena_w + (size_t)a.node_cap * 32);         // [node_cap][2] outputs
+    ux4   *outs = reinterpret_cast<ux4 *>(arena_w + (size_t)a.node_cap * 32);         // [node_cap][2] outputs evaluated ahead of the search
+    // board-keyed output table of this walker: entry = two quads {board.lo, board.hi, probs[0], probs[1]} {probs[2], probs[3], value, 0};
+    // zeroed by the host before the launch (no board is 0), written and read by this wave alone (program order: no races)
+    ux4   *tblq = reinterpret_cast<ux4 *>(a.tbl) + slot * (uint64_t)a.tbl_entries * 2;
+    const uint32_t tmask = a.tbl_entries - 1u;
+    auto tbl_slot = [&](uint64_t b) -> uint32_t { return (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 36) & tmask; };
+    auto tbl_get = [&](uint64_t b, float (&pb)[4], float &v) -> bool {               // b wave-uniform: one line, every lane the same answer
+        const uint32_t hs = tbl_slot(b);
+        const ux4 q0 = tblq[2 * (size_t)hs], q1 = tblq[2 * (size_t)hs + 1];
+        pb[0] = unif(__uint_as_float(q0.z)); pb[1] = unif(__uint_as_float(q0.w)); pb[2] = unif(__uint_as_float(q1.x)); pb[3] = unif(__uint_as_float(q1.y));
+        v = unif(__uint_as_float(q1.z));
+        return uniu((q0.x == (uint32_t)b && q0.y == (uint32_t)(b >> 32)) ? 1u : 0u) != 0u;
+    };
+    auto tbl_put = [&](uint64_t b, const float (&pb)[4], float v) {                  // (every lane stores the same 32 bytes)
+        const uint32_t hs = tbl_slot(b);
+        tblq[2 * (size_t)hs]     = ux4{(uint32_t)b, (uint32_t)(b >> 32), __float_as_uint(pb[0]), __float_as_uint(pb[1])};
+        tblq[2 * (size_t)hs + 1] = ux4{__float_as_uint(pb[2]), __float_as_uint(pb[3]), __float_as_uint(v), 0u};
+    };
 
     // hot quad of node idx: LDS for the first NL nodes of the tree, the arena beyond
     auto hot_ld = [&](uint32_t idx) -> ux4 { if (idx < NL) return tbl[idx]; return hotq[idx]; };
@@ -225,7 +256,11 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         if (in_tree) { c1 = brdq[idx]; ch = hot_ld(idx); }
         const uint64_t cb64 = ((uint64_t)c1.y << 32) | c1.x;
         // a node needs the network if it is not final (search.rs:149), not expanded and holds no output yet
-        const bool valid = in_tree && !(ch.w & (LK_OUT | LK_UNDO)) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && (yielded || idx != dem_idx);
+        bool valid = in_tree && !(ch.w & (LK_OUT | LK_UNDO)) && lk_nch(ch.w) == 0u && !(c1.w == 0u || cb64 == ident) && (yielded || idx != dem_idx);
+        if (valid) {                                                                   // ... and its board's output is not in the table
+            const ux4 k0 = tblq[2 * (size_t)tbl_slot(cb64)];
+            valid = !(k0.x == c1.x && k0.y == c1.y);
+        }
         const int quota = my_share - col0;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
         const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -391,12 +426,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 const float4 pr = src[0]; const float4 vv = src[1];
                 probs[0] = unif(pr.x); probs[1] = unif(pr.y); probs[2] = unif(pr.z); probs[3] = unif(pr.w); nn_value = unif(vv.x);
             }
-            // every node that gets expanded keeps its output in the arena: its grandchildren by a move taken back read it
-            auto keep_output = [&](uint32_t idx, const float (&pb)[4], float v) {      // (every lane stores the same 32 bytes)
-                __builtin_nontemporal_store(ux4{__float_as_uint(pb[0]), __float_as_uint(pb[1]), __float_as_uint(pb[2]), __float_as_uint(pb[3])}, outs + 2 * idx);
-                __builtin_nontemporal_store(ux4{__float_as_uint(v), 0u, 0u, 0u}, outs + 2 * idx + 1);
-            };
-            if (!yielded) keep_output(phase == DP_ROOT ? 0u : node, probs, nn_value);
+            // the output of every node that gets expanded goes into the table, under its board
+            if (!yielded) tbl_put(phase == DP_ROOT ? st.board : cur.board, probs, nn_value);
 
             const int ca = lane & 3;                               // the child / action this lane works on
             // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step; four lanes, one child each
@@ -498,20 +529,15 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     if (it == S) {
                         // ---- move finished: visit counts -> probs (search.rs:166-188) ------------------------------
                         float mp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                        uint32_t exp_child[4] = {DNONE, DNONE, DNONE, DNONE};   // per action: the root's child, if it was expanded
                         if (root_nc > 0) {
                             const ux4 rq = hot_ld(root_cb + ((uint32_t)ca < root_nc ? (uint32_t)ca : root_nc - 1u));
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 if ((uint32_t)c >= root_nc) continue;
-                                const uint32_t lk = rdl(rq.w, c);
-                                const int act = lk_act(lk);
+                                const int act = lk_act(rdl(rq.w, c));
                                 const float vis = (float)rdl(rq.y, c);
                                 mp[0] = act == 0 ? vis : mp[0]; mp[1] = act == 1 ? vis : mp[1];
                                 mp[2] = act == 2 ? vis : mp[2]; mp[3] = act == 3 ? vis : mp[3];
-                                const uint32_t ci = lk_nch(lk) > 0u ? root_cb + (uint32_t)c : DNONE;
-                                exp_child[0] = act == 0 ? ci : exp_child[0]; exp_child[1] = act == 1 ? ci : exp_child[1];
-                                exp_child[2] = act == 2 ? ci : exp_child[2]; exp_child[3] = act == 3 ? ci : exp_child[3];
                             }
                         }
                         float sum = 0.0f;
@@ -546,20 +572,17 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                         }
                         puzzle_step(st, env, action);                                                   // az.rs:89
                         ++t;
-                        // The next move's root holds the board of the child just chosen.  If a search expanded that child, its
-                        // output is in the arena: the new tree starts from it at once instead of waiting for a forward.
-                        const uint32_t cidx = action == 0 ? exp_child[0] : (action == 1 ? exp_child[1] : (action == 2 ? exp_child[2] : exp_child[3]));
-                        if (cidx != DNONE) {
-                            const ux4 o2 = outs[2 * cidx], o3 = outs[2 * cidx + 1];
-                            float rp[4];
-                            rp[0] = unif(__uint_as_float(o2.x)); rp[1] = unif(__uint_as_float(o2.y)); rp[2] = unif(__uint_as_float(o2.z));
-                            rp[3] = unif(__uint_as_float(o2.w));
-                            const float rv = unif(__uint_as_float(o3.x));
-                            start_move(rp);
-                            keep_output(0u, rp, rv);
-                            ++reused;
-                            TW_DS(y9); TW_DA(c_fin, y2, y9);
-                            continue;
+                        // The next move's root holds a board this episode has most likely expanded a node with (the child just
+                        // chosen, if a search went through it): the new tree then starts from the table's output at once
+                        // instead of waiting for a forward.
+                        {
+                            float rp[4]; float rv;
+                            if (tbl_get(st.board, rp, rv)) {
+                                start_move(rp);
+                                ++reused;
+                                TW_DS(y9); TW_DA(c_fin, y2, y9);
+                                continue;
+                            }
                         }
                         phase = DP_ROOT;
                         TW_DS(y9); TW_DA(c_fin, y2, y9);
@@ -599,23 +622,25 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     }
                     value = 0.0f; expanded = 0;
                     TW_DS(y3); TW_DA(c_desc, y2, y3);
-                    // leaf phase (search.rs:143-160)
+                } else {
+                    // ---- the demanded leaf's output has arrived (search.rs:154-159): expand, sample a child by the priors ---
+                    resume = false;
+                    ++evals;
+                    const uint32_t cb = n_nodes;
+                    const uint32_t nch = expand(node, cur_link, cur, probs);
+                    if (nch > 0) sample_child(cb, nch);
+                    value = nn_value;
+                    ++expanded;
+                    TW_DS(y5); TW_DA(c_res, y2, y5);
+                }
+                {
+                    TW_DS(y3);
+                    // leaf phase (search.rs:143-160); after a demand: the further expansion levels of the same search (max_expand_depth > 1)
                     while (expanded < MED) {
                         value = puzzle_reward(cur, env);                                  // :146
                         if (puzzle_final(cur, env)) break;                                // :149
-                        const bool from_grandparent = !(cur_link & LK_OUT) && (cur_link & LK_UNDO) && !overflow && plen >= 3;
-                        if (!(cur_link & LK_OUT) && !from_grandparent) { need_nn = true; break; }   // :154 needs the network: demand it
                         float lp[4]; float lv;
-                        if (from_grandparent) {
-                            // this node's move took its parent's move back: it holds the board of its grandparent (path level plen - 3),
-                            // whose output is in the arena -- the network would compute the same bits again
-                            const uint32_t g = rdl(p_idx, plen - 3);
-                            const ux4 o2 = outs[2 * g], o3 = outs[2 * g + 1];
-                            lp[0] = unif(__uint_as_float(o2.x)); lp[1] = unif(__uint_as_float(o2.y)); lp[2] = unif(__uint_as_float(o2.z));
-                            lp[3] = unif(__uint_as_float(o2.w)); lv = unif(__uint_as_float(o3.x));
-                            keep_output(node, lp, lv);
-                            ++reused;
-                        } else {
+                        if (cur_link & LK_OUT) {
                             // the node was evaluated ahead of this search: take its output (LDS pool, else the arena) and go on
                             const bool hit = lane < DEEP_POOL && pidx[lane < DEEP_POOL ? lane : 0] == node;
                             const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
@@ -629,6 +654,13 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                                 lp[0] = unif(__uint_as_float(o2.x)); lp[1] = unif(__uint_as_float(o2.y)); lp[2] = unif(__uint_as_float(o2.z));
                                 lp[3] = unif(__uint_as_float(o2.w)); lv = unif(__uint_as_float(o3.x));
                             }
+                            tbl_put(cur.board, lp, lv);
+                        } else {
+                            // a board this walker has expanded a node with before (the grandparent's, when the move took the parent's
+                            // move back; a sibling subtree's; an earlier move's; an earlier episode's): the network would compute the
+                            // same bits again
+                            if (!tbl_get(cur.board, lp, lv)) { need_nn = true; break; }       // :154 needs the network: demand it
+                            ++reused;
                         }
                         ++evals;
 #ifdef TW_ABLATE
@@ -642,22 +674,6 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                         ++expanded;
                     }
                     TW_DS(y4); TW_DA(c_leaf, y3, y4);
-                } else {
-                    // ---- the demanded leaf's output has arrived (search.rs:154-159): expand, sample a child by the priors ---
-                    resume = false;
-                    ++evals;
-                    const uint32_t cb = n_nodes;
-                    const uint32_t nch = expand(node, cur_link, cur, probs);
-                    if (nch > 0) sample_child(cb, nch);
-                    value = nn_value;
-                    ++expanded;
-                    // further expansion levels of the same search (max_expand_depth > 1): the child sampled a moment ago holds no
-                    // output yet, so unless it is a final state it is the next demand
-                    if (expanded < MED) {
-                        value = puzzle_reward(cur, env);
-                        need_nn = !puzzle_final(cur, env);
-                    }
-                    TW_DS(y5); TW_DA(c_res, y2, y5);
                 }
                 if (need_nn) { dem_idx = node; break; }
                 TW_DS(y6);
@@ -839,7 +855,7 @@ int launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_
     const uint64_t need = 5ull + 4ull * a.num_searches * (a.max_expand_depth ? a.max_expand_depth : 1u);
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.obs_size > 256 ||
         a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 || a.out.t_pad < a.env.depth0 + 1 || a.node_cap < need ||
-        !a.arena || !a.eval_count || !a.queue || !a.init_boards || a.solve.on) {
+        !a.arena || !a.eval_count || !a.queue || !a.init_boards || a.solve.on || !a.tbl || a.tbl_entries == 0 || (a.tbl_entries & (a.tbl_entries - 1u))) {
         set_error("mcts (deep): unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d node_cap=%u need=%llu)",
                   a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad, a.node_cap, (unsigned long long)need);
         return TW_ERR_UNSUPPORTED;
