@@ -1237,7 +1237,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(136), o_scan = seg(scan_scratch_bytes(E)),
-                 o_arena = seg(arenas * cap64 * (deep ? mcts_deep_node_bytes() : mcts_node_bytes())),
+                 o_arena = seg(deep ? arenas * mcts_deep_arena_bytes(cap64) : arenas * cap64 * mcts_node_bytes()),
                  o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
     const uint32_t tbl_entries = deep ? mcts_deep_table_entries(ma.num_searches, ma.max_expand_depth) : 0;
     const size_t tbl_bytes = (size_t)arenas * tbl_entries * 32;

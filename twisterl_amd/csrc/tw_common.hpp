@@ -493,6 +493,8 @@ size_t mcts_node_bytes();
 bool     mcts_deep_applies(const MctsArgs &a);
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches);   // tree arenas = episodes in flight
 size_t   mcts_deep_node_bytes();
+// bytes of one walker's tree arena (72 per node, see tw_mcts_deep.hip), a multiple of 16
+__host__ __device__ inline size_t mcts_deep_arena_bytes(uint64_t node_cap) { return (size_t)((node_cap * 72 + 15) / 16 * 16); }
 uint32_t mcts_deep_table_entries(uint32_t num_searches, uint32_t max_expand_depth);     // per walker, 32 bytes each
 int      launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);

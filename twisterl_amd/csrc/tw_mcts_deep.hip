@@ -37,12 +37,16 @@
 
 namespace tw {
 
-// arena of one walker: uint4 hot[node_cap] | uint4 brd[node_cap] | uint4 out[node_cap][2]
+// arena of one walker: uint4 hot[node_cap] | uint4 brd[node_cap] | uint4 out[node_cap][2] | uint2 hot2[node_cap]
 //   hot: value_sum (f32 bits), visit_count, prior (f32 bits), link = child_base | n_children << 24 | action << 27 | has_output << 29
 //        -- for the first `lds_nodes` nodes of a tree this quad lives in LDS instead (same layout), its arena slot is never touched
 //   brd: board.lo, board.hi, parent, depth
 //   out: masked-softmax probs[4] of full_predict (f32 bits) | network value (f32 bits), 0, 0, 0 -- once evaluated ahead of the search
-constexpr size_t DEEP_NODE_BYTES = 64;
+//   hot2: q = value_sum / visit_count (0 while unvisited) and sqrt(visit_count), both f32 bits, written by whoever writes the
+//        statistics (back-propagation, one lane per path level): the UCB of a child is then ONE division per level -- the very
+//        operations of search.rs:29-39 on the very operands, computed when the operands change instead of when they are read;
+//        like `hot`, in LDS for the first `lds_nodes` nodes
+constexpr size_t DEEP_NODE_BYTES = 72;
 size_t mcts_deep_node_bytes() { return DEEP_NODE_BYTES; }
 // Entries of a walker's board-keyed output table: about eight times the nodes one move's searches expand (an episode expands
 // ~0.15 x searches NEW boards per move, CPU count), between 1,024 and 16,384 -- 32 KiB to 512 KiB per walker.  Direct-mapped and
@@ -87,12 +91,12 @@ __device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builti
 __device__ __forceinline__ uint32_t lk_nch(uint32_t link) { return (link >> 24) & 7u; }
 __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >> 27) & 3u); }
 
-// floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | pool idx [POOL] | pool outputs [POOL][8]
+// floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | q / sqrt table [lds_nodes][2] | pool idx [POOL] | pool outputs [POOL][8]
 __host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers)
 {
     // (+ 24: the walkers' alive flags and waiting flags; eight walkers: + 64 dwords each, where the wave-uniform walker state waits during a forward)
     return (size_t)columns * 10 + 24 + (walkers > DEEP_WAVES ? (size_t)walkers * 64 : 0) +
-           (size_t)walkers * ((size_t)lds_nodes * 4 + deep_pool(walkers) + deep_pool(walkers) * 8);
+           (size_t)walkers * ((size_t)lds_nodes * 6 + deep_pool(walkers) + deep_pool(walkers) * 8);
 }
 
 #ifdef TW_ABLATE
@@ -135,18 +139,20 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][TWV waves]: walker still has an episode
     volatile int *wait_f = reinterpret_cast<volatile int *>(res + 8 * C + 16);   // [8]: walker w has stopped in front of a forward it needs (demand / new root)
     float *park_base = res + 8 * C + 24;                                         // [TWV][64] parked walker state (eight-walker shape)
-    float *wbase = park_base + (TWV > DEEP_WAVES ? TWV * 64 : 0) + (size_t)(walker ? wave : 0) * ((size_t)NL * 4 + DEEP_POOL + DEEP_POOL * 8);
+    float *wbase = park_base + (TWV > DEEP_WAVES ? TWV * 64 : 0) + (size_t)(walker ? wave : 0) * ((size_t)NL * 6 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
-    lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 4);                         // pool: node index (DNONE = free)
-    lds_f32 *pout = (lds_f32 *)(wbase + (size_t)NL * 4 + DEEP_POOL);             // pool: probs[4], value, - - -
+    lds_u2  *tq   = (lds_u2 *)(wbase + (size_t)NL * 4);                          // q, sqrt(visit) of nodes 0 .. NL-1
+    lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 6);                         // pool: node index (DNONE = free)
+    lds_f32 *pout = (lds_f32 *)(wbase + (size_t)NL * 6 + DEEP_POOL);             // pool: probs[4], value, - - -
 
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     const uint64_t E = a.num_episodes;
     const uint64_t slot = (uint64_t)blockIdx.x * NWK + (uint64_t)(walker ? wave : 0);     // walker = tree arena index
-    uint8_t *arena_w = reinterpret_cast<uint8_t *>(a.arena) + slot * (uint64_t)a.node_cap * DEEP_NODE_BYTES;
+    uint8_t *arena_w = reinterpret_cast<uint8_t *>(a.arena) + slot * (uint64_t)mcts_deep_arena_bytes(a.node_cap);
     ux4   *hotq = reinterpret_cast<ux4 *>(arena_w);                                   // [node_cap] statistics
     uint4 *brdq = reinterpret_cast<uint4 *>(arena_w + (size_t)a.node_cap * 16);       // [node_cap] boards
     ux4   *outs = reinterpret_cast<ux4 *>(arena_w + (size_t)a.node_cap * 32);         // [node_cap][2] outputs evaluated ahead of the search
+    ux2   *hot2 = reinterpret_cast<ux2 *>(arena_w + (size_t)a.node_cap * 64);         // [node_cap] q, sqrt(visit)
     // board-keyed output table of this walker: entry = two quads {board.lo, board.hi, probs[0], probs[1]} {probs[2], probs[3], value, 0};
     // zeroed by the host before the launch (no board is 0), written and read by this wave alone (program order: no races)
     ux4   *tblq = reinterpret_cast<ux4 *>(a.tbl) + slot * (uint64_t)a.tbl_entries * 2;
@@ -173,6 +179,11 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         if (idx < NL) *reinterpret_cast<lds_u2 *>(tbl + idx) = w;
         else *reinterpret_cast<ux2 *>(hotq + idx) = w;
     };
+    auto hot2_ld = [&](uint32_t idx) -> ux2 { if (idx < NL) return tq[idx]; return hot2[idx]; };
+    auto hot2_st = [&](uint32_t idx, float q, float sq) {
+        ux2 w; w.x = __float_as_uint(q); w.y = __float_as_uint(sq);
+        if (idx < NL) tq[idx] = w; else hot2[idx] = w;
+    };
     auto hot_st_link = [&](uint32_t idx, uint32_t link) {
         if (idx < NL) reinterpret_cast<lds_u32 *>(tbl + idx)[3] = link;
         else reinterpret_cast<uint32_t *>(hotq + idx)[3] = link;
@@ -186,7 +197,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     int      t = 0;
     uint32_t it = 0, expanded = 0, node = 0, n_nodes = 0, cursor = 1, cur_link = 0;
     float    value = 0.0f;
-    float    root_vs = 0.0f; uint32_t root_visit = 0, root_cb = 0, root_nc = 0;
+    float    root_vs = 0.0f, root_sq = 0.0f; uint32_t root_visit = 0, root_cb = 0, root_nc = 0;     // root_sq = sqrt(root_visit)
     uint32_t dem_idx = 0;
     unsigned long long evals = 0, spec_evals = 0, reused = 0;      // outputs consumed | columns evaluated ahead | outputs taken from a grandparent
     bool more = true;
@@ -300,7 +311,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 pkw[26] = (uint32_t)evals; pkw[27] = (uint32_t)(evals >> 32); pkw[28] = (uint32_t)spec_evals; pkw[29] = (uint32_t)(spec_evals >> 32);
                 pkw[30] = (more ? 1u : 0u) | (overflow ? 2u : 0u) | (yielded ? 4u : 0u);
                 pkw[31] = (uint32_t)plen; pkw[32] = pool_head; pkw[33] = (uint32_t)n_spec; pkw[34] = (uint32_t)my_base; pkw[35] = (uint32_t)my_share; pkw[36] = trip;
-                pkw[37] = (uint32_t)reused; pkw[38] = (uint32_t)(reused >> 32);
+                pkw[37] = (uint32_t)reused; pkw[38] = (uint32_t)(reused >> 32); pkw[39] = __float_as_uint(root_sq);
             }
         }
     };
@@ -320,6 +331,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             plen = (int)uniu(pkw[31]); pool_head = uniu(pkw[32]); n_spec = (int)uniu(pkw[33]); my_base = (int)uniu(pkw[34]); my_share = (int)uniu(pkw[35]);
             trip = uniu(pkw[36]);
             reused = ((unsigned long long)uniu(pkw[38]) << 32) | uniu(pkw[37]);
+            root_sq = __uint_as_float(uniu(pkw[39]));
         }
     };
 
@@ -430,6 +442,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             if (!yielded) tbl_put(phase == DP_ROOT ? st.board : cur.board, probs, nn_value);
 
             const int ca = lane & 3;                               // the child / action this lane works on
+            const bool wrap1 = ca + 1 >= 4, wrap2 = ca + 2 >= 4, wrap3 = ca + 3 >= 4;   // the lane k places further round the quad comes BEFORE this one
             // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step; four lanes, one child each
             float pri[4] = {0.0f, 0.0f, 0.0f, 0.0f};               // priors of the children just created, in child order
             uint32_t act_mask = 0;                                 // bit a: action a got a child
@@ -445,6 +458,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     const uint32_t ni = n_nodes + pos;
                     const uint32_t undo = (idx != 0u && (uint32_t)ca == (((idx_link >> 27) & 3u) ^ 2u)) ? LK_UNDO : 0u;   // 0 left, 1 up, 2 right, 3 down
                     hot_st(ni, ux4{0u, 0u, __float_as_uint(mine), ((uint32_t)ca << 27) | undo});
+                    hot2_st(ni, 0.0f, 0.0f);                                 // unvisited: q = 0 (search.rs:31), sqrt(0)
                     brdq[ni] = make_uint4((uint32_t)c.board, (uint32_t)(c.board >> 32), idx, (uint32_t)c.depth);
                 }
                 if (lane == 0) hot_st_link(idx, (idx_link & ~(LK_CB | (7u << 24))) | n_nodes | (cnt << 24));
@@ -475,13 +489,21 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             // backpropagate (search.rs:45-53): value_sum += v, visit_count += 1 on every node of the path -- one store per level
             auto backprop = [&](uint32_t idx, float val) {
                 if (!overflow) {
-                    if (lane < plen && p_idx != 0u) hot_st_stats(p_idx, p_vs + val, p_vis + 1u);   // (the root's statistics live in registers)
-                } else if (lane == 0) {
-                    while (idx != DNONE && idx != 0u) {
-                        const ux4 hq = hot_ld(idx);
-                        hot_st_stats(idx, __uint_as_float(hq.x) + val, hq.y + 1u);
-                        idx = brdq[idx].z;
+                    // lane l = path level l: the node's new statistics and, from them, the q and sqrt(visit) the next descents read
+                    const uint32_t nv = p_vis + 1u; const float nvs = p_vs + val;
+                    const float nq = nvs / (float)nv, nsq = sqrtf((float)nv);
+                    if (lane < plen && p_idx != 0u) { hot_st_stats(p_idx, nvs, nv); hot2_st(p_idx, nq, nsq); }   // (the root's statistics live in registers)
+                    root_sq = rdlf(nsq, 0);                                                         // level 0 is the root
+                } else {
+                    if (lane == 0) {
+                        while (idx != DNONE && idx != 0u) {
+                            const ux4 hq = hot_ld(idx);
+                            const uint32_t nv = hq.y + 1u; const float nvs = __uint_as_float(hq.x) + val;
+                            hot_st_stats(idx, nvs, nv); hot2_st(idx, nvs / (float)nv, sqrtf((float)nv));
+                            idx = brdq[idx].z;
+                        }
                     }
+                    root_sq = sqrtf((float)(root_visit + 1u));
                 }
                 root_vs = root_vs + val; root_visit += 1u;
             };
@@ -491,7 +513,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 ++evals;
                 n_nodes = 1; cursor = 1;
                 pidx[lane < DEEP_POOL ? lane : 0] = DNONE;               // outputs of the previous move's tree (every lane stores: no lane branch in the walk)
-                root_vs = 0.0f; root_visit = 1u; root_cb = 1u;
+                root_vs = 0.0f; root_visit = 1u; root_cb = 1u; root_sq = 1.0f;
                 root_nc = expand(0u, 0u, st, pb);
                 it = 0;
                 phase = DP_LEAF;
@@ -592,30 +614,46 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     //      children; the state follows the chosen actions (a child's state IS step(parent state, action))
                     node = 0; plen = 0; overflow = false;
                     push(0u, root_vs, root_visit);
-                    uint32_t cur_nc = root_nc, cur_cb = root_cb, cur_visit = root_visit;
+                    uint32_t cur_nc = root_nc, cur_cb = root_cb;
+                    float cur_sq = root_sq;                    // sqrt(visit_count) of the node whose children are scored
                     cur = st; cur_link = 0u;                   // (a root without children is evaluated again, like any childless node)
                     while (cur_nc > 0) {
-                        const ux4 kq = hot_ld(cur_cb + ((uint32_t)ca < cur_nc ? (uint32_t)ca : cur_nc - 1u));
-                        const float sq = sqrtf((float)cur_visit);
-                        const float qv = kq.y == 0u ? 0.0f : __uint_as_float(kq.x) / (float)kq.y;
-                        float d = sq / ((float)kq.y + 1.0f);
+                        const uint32_t ci = cur_cb + ((uint32_t)ca < cur_nc ? (uint32_t)ca : cur_nc - 1u);
+                        ux4 kq; ux2 k2;
+                        if (cur_cb + 4u <= NL) { kq = tbl[ci]; k2 = tq[ci]; }         // (wave-uniform: the children of a node are contiguous)
+                        else { kq = hot_ld(ci); k2 = hot2_ld(ci); }
+                        // ucb = q + C * sqrt(N_parent) / (n + 1) * prior (search.rs:29-39); q and the square root are the stored ones
+                        float d = cur_sq / ((float)kq.y + 1.0f);
                         d = a.C * d;
                         d = d * __uint_as_float(kq.z);
-                        const float u = qv + d;
-                        int best = -1; float best_ucb = -__builtin_inff();
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float uc = rdlf(u, c);
-                            if ((uint32_t)c < cur_nc && uc > best_ucb) { best = c; best_ucb = uc; }
-                        }
-                        if (best < 0) break;                       // all-NaN UCB: the reference panics here
-                        best = uni(best);
+                        float u = __uint_as_float(k2.x) + d;
+                        u = (uint32_t)ca < cur_nc ? u : -__builtin_inff();
+                        // next (search.rs:77-91): the first maximum, strict '>' from -inf (a NaN never wins).  Every lane of a quad looks at
+                        // the other three through DPP: a lane before it beats it on >=, a lane after it on >
+                        const float o1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(u), 0x39, 0xf, 0xf, false));   // quad_perm [1,2,3,0]
+                        const float o2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(u), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+                        const float o3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(u), 0x93, 0xf, 0xf, false));   // quad_perm [3,0,1,2]
+                        // (bitwise on purpose: '||' and '?:' on lane-varying compares become branches over exec masks)
+                        const bool beaten = (o1 > u) | (o2 > u) | (o3 > u) | ((o1 == u) & wrap1) | ((o2 == u) & wrap2) | ((o3 == u) & wrap3);
+                        const uint32_t wm = (uint32_t)__builtin_amdgcn_ballot_w64((u > -__builtin_inff()) & !beaten) & 15u;
+                        if (wm == 0u) break;                       // all-NaN UCB: the reference panics here
+                        const int best = __builtin_ctz(wm);
                         node = cur_cb + (uint32_t)best;
                         const uint32_t bvs = rdl(kq.x, best), bvis = rdl(kq.y, best);
                         cur_link = rdl(kq.w, best);
-                        puzzle_step(cur, env, lk_act(cur_link));
+                        cur_sq = __uint_as_float(rdl(k2.y, best));
+                        {   // the child's state IS step(parent state, action), and a child exists only for a legal move (its prior is > 0
+                            // only where the mask allows the action): Env::step without the bounds checks (puzzle.rs:135-160)
+                            const int act = lk_act(cur_link);
+                            const int zi = cur.zy * env.width + cur.zx;
+                            cur.zx += (act == 2 ? 1 : 0) - (act == 0 ? 1 : 0); cur.zy += (act == 3 ? 1 : 0) - (act == 1 ? 1 : 0);
+                            const int ti = cur.zy * env.width + cur.zx;
+                            const uint64_t tile = (cur.board >> (4 * ti)) & 15ull;
+                            cur.board = (cur.board & ~(15ull << (4 * ti))) | (tile << (4 * zi));
+                            cur.depth = cur.depth > 0 ? cur.depth - 1 : 0;
+                        }
                         push(node, __uint_as_float(bvs), bvis);
-                        cur_cb = cur_link & LK_CB; cur_nc = lk_nch(cur_link); cur_visit = bvis;
+                        cur_cb = cur_link & LK_CB; cur_nc = lk_nch(cur_link);
 #ifdef TW_ABLATE
                         ++c_lvl;
 #endif
@@ -789,7 +827,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     const size_t eng_floats = G::Eng::lds_floats(a.pol.obs_size);
     const size_t budget = (size_t)159 * 1024 / sizeof(float);
     if (eng_floats + deep_extra_floats(C, 0, NWK) > budget) { set_error("mcts (deep): the policy engine alone needs %zu bytes of LDS", eng_floats * 4); return TW_ERR_UNSUPPORTED; }
-    size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK)) / ((size_t)NWK * 4);
+    size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK)) / ((size_t)NWK * 6);
     if (nl > a.node_cap) nl = a.node_cap;
     b.lds_nodes = (uint32_t)nl;
     deep_tree_budgets(&b.tree_budget_min, &b.tree_budget);
