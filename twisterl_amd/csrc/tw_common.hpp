@@ -257,6 +257,19 @@ __host__ __device__ inline void puzzle_step(PuzzleLane &s, const PuzzleConsts &c
     s.depth = s.depth > 0 ? s.depth - 1 : 0;
 }
 
+// Env::step for an action that is known to be legal (a tree child exists only where the mask allowed the move): the same
+// board / blank / depth update without the bounds checks -- about half the scalar instructions on a wave-uniform state
+__host__ __device__ inline void puzzle_step_legal(PuzzleLane &s, const PuzzleConsts &c, int action)
+{
+    const int zi = s.zy * c.width + s.zx;
+    const int sh = 2 * action;                                  // dx + 1 = {0, 1, 2, 1}, dy + 1 = {1, 0, 1, 2} for left, up, right, down
+    s.zx += ((0x64 >> sh) & 3) - 1; s.zy += ((0x91 >> sh) & 3) - 1;
+    const int ti = s.zy * c.width + s.zx;
+    const uint64_t tile = (s.board >> (4 * ti)) & 15ull;        // cell zi holds 0
+    s.board = (s.board & ~(15ull << (4 * ti))) | (tile << (4 * zi));
+    s.depth = s.depth > 0 ? s.depth - 1 : 0;
+}
+
 // Env::reset (puzzle.rs:119-133)
 __host__ __device__ inline void puzzle_reset(PuzzleLane &s, const PuzzleConsts &c, uint64_t seed, uint64_t episode)
 {

@@ -38,14 +38,16 @@
 namespace tw {
 
 // arena of one walker: uint4 hot[node_cap] | uint4 brd[node_cap] | uint4 out[node_cap][2] | uint2 hot2[node_cap]
-//   hot: value_sum (f32 bits), visit_count, prior (f32 bits), link = child_base | n_children << 24 | action << 27 | has_output << 29
+//   hot: q = value_sum / visit_count (f32 bits, 0 while unvisited), visit_count, prior (f32 bits), link = child_base | n_children << 24 | action << 27 | has_output << 29
 //        -- for the first `lds_nodes` nodes of a tree this quad lives in LDS instead (same layout), its arena slot is never touched
 //   brd: board.lo, board.hi, parent, depth
 //   out: masked-softmax probs[4] of full_predict (f32 bits) | network value (f32 bits), 0, 0, 0 -- once evaluated ahead of the search
-//   hot2: q = value_sum / visit_count (0 while unvisited) and sqrt(visit_count), both f32 bits, written by whoever writes the
-//        statistics (back-propagation, one lane per path level): the UCB of a child is then ONE division per level -- the very
-//        operations of search.rs:29-39 on the very operands, computed when the operands change instead of when they are read;
-//        like `hot`, in LDS for the first `lds_nodes` nodes
+//   hot2: value_sum (f32 bits) | best = the child `next` (search.rs:77-91) would choose, as child index | action << 27 (DNONE: no
+//        children, or no score beats -inf).  q and best are functions of statistics that only a
+//        back-propagation changes, and a back-propagation touches only the nodes of ITS search path: so the lane that updates
+//        path level l (one lane per level) also re-derives q of its node and, from the children's stored statistics, its best
+//        child -- the very operations of search.rs:29-39 on the very operands, computed when the operands change instead of
+//        every time they are read.  A descent is then a chain of `best` links.  Like `hot`, in LDS for the first `lds_nodes` nodes
 constexpr size_t DEEP_NODE_BYTES = 72;
 size_t mcts_deep_node_bytes() { return DEEP_NODE_BYTES; }
 // Entries of a walker's board-keyed output table: about eight times the nodes one move's searches expand (an episode expands
@@ -137,7 +139,9 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
     const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
     int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][TWV waves]: walker still has an episode
-    volatile int *wait_f = reinterpret_cast<volatile int *>(res + 8 * C + 16);   // [8]: walker w has stopped in front of a forward it needs (demand / new root)
+    // [8]: walker w has stopped in front of a forward it needs (demand / new root).  An LDS-typed pointer: through a generic one the
+    // eight polls of a search pass were eight serialised flat loads (hundreds of cycles each); now two 16-byte LDS reads
+    volatile lds_u32 *wait_f = (volatile lds_u32 *)(res + 8 * C + 16);
     float *park_base = res + 8 * C + 24;                                         // [TWV][64] parked walker state (eight-walker shape)
     float *wbase = park_base + (TWV > DEEP_WAVES ? TWV * 64 : 0) + (size_t)(walker ? wave : 0) * ((size_t)NL * 6 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
@@ -174,14 +178,11 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     // hot quad of node idx: LDS for the first NL nodes of the tree, the arena beyond
     auto hot_ld = [&](uint32_t idx) -> ux4 { if (idx < NL) return tbl[idx]; return hotq[idx]; };
     auto hot_st = [&](uint32_t idx, ux4 v) { if (idx < NL) tbl[idx] = v; else hotq[idx] = v; };
-    auto hot_st_stats = [&](uint32_t idx, float vs, uint32_t vis) {                // value_sum, visit_count: one 8-byte store
-        ux2 w; w.x = __float_as_uint(vs); w.y = vis;
-        if (idx < NL) *reinterpret_cast<lds_u2 *>(tbl + idx) = w;
-        else *reinterpret_cast<ux2 *>(hotq + idx) = w;
-    };
-    auto hot2_ld = [&](uint32_t idx) -> ux2 { if (idx < NL) return tq[idx]; return hot2[idx]; };
-    auto hot2_st = [&](uint32_t idx, float q, float sq) {
-        ux2 w; w.x = __float_as_uint(q); w.y = __float_as_uint(sq);
+    auto hot_ld_link = [&](uint32_t idx) -> uint32_t { if (idx < NL) return reinterpret_cast<lds_u32 *>(tbl + idx)[3]; return reinterpret_cast<const uint32_t *>(hotq + idx)[3]; };
+    auto hot2_ld_vs = [&](uint32_t idx) -> uint32_t { if (idx < NL) return reinterpret_cast<lds_u32 *>(tq + idx)[0]; return reinterpret_cast<const uint32_t *>(hot2 + idx)[0]; };
+    auto hot2_ld_best = [&](uint32_t idx) -> uint32_t { if (idx < NL) return reinterpret_cast<lds_u32 *>(tq + idx)[1]; return reinterpret_cast<const uint32_t *>(hot2 + idx)[1]; };
+    auto hot2_st = [&](uint32_t idx, float vs, uint32_t best) {
+        ux2 w; w.x = __float_as_uint(vs); w.y = best;
         if (idx < NL) tq[idx] = w; else hot2[idx] = w;
     };
     auto hot_st_link = [&](uint32_t idx, uint32_t link) {
@@ -197,12 +198,14 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     int      t = 0;
     uint32_t it = 0, expanded = 0, node = 0, n_nodes = 0, cursor = 1, cur_link = 0;
     float    value = 0.0f;
-    float    root_vs = 0.0f, root_sq = 0.0f; uint32_t root_visit = 0, root_cb = 0, root_nc = 0;     // root_sq = sqrt(root_visit)
+    float    root_vs = 0.0f; uint32_t root_visit = 0, root_cb = 0, root_nc = 0, root_best = DNONE;   // (the root's record lives in registers)
     uint32_t dem_idx = 0;
     unsigned long long evals = 0, spec_evals = 0, reused = 0;      // outputs consumed | columns evaluated ahead | outputs taken from a grandparent
     bool more = true;
-    // search path, one level per lane: node index, value_sum and visit_count read on the way down
-    uint32_t p_idx = 0, p_vis = 0; float p_vs = 0.0f; int plen = 0; bool overflow = false;
+    // search path, one level per lane: node index
+    uint32_t p_idx = 0; int plen = 0; bool overflow = false;
+    // next_sample's draws, 64 at a time: lane i holds word 0 of the draw with index rng_base + i of the current move's stream
+    uint32_t rng_buf = 0, rng_base = 0xffffffffu;
     // the request this lane issued ahead of the search in the last assembly (stored into its node when the forward is done)
     bool my_take = false; uint32_t my_idx = 0; int my_rank = 0, my_slot = 0;
     uint32_t pool_head = 0; int n_spec = 0;
@@ -231,8 +234,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     uint32_t obs_base[4];
     obs_base_words(env.n_cells, obs_base);
 
-    auto push = [&](uint32_t idx, float vs, uint32_t vis) {
-        if (plen < 64) { if (lane == plen) { p_idx = idx; p_vs = vs; p_vis = vis; } ++plen; }
+    auto push = [&](uint32_t idx) {
+        if (plen < 64) { if (lane == plen) p_idx = idx; ++plen; }
         else overflow = true;
     };
 
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 pkw[26] = (uint32_t)evals; pkw[27] = (uint32_t)(evals >> 32); pkw[28] = (uint32_t)spec_evals; pkw[29] = (uint32_t)(spec_evals >> 32);
                 pkw[30] = (more ? 1u : 0u) | (overflow ? 2u : 0u) | (yielded ? 4u : 0u);
                 pkw[31] = (uint32_t)plen; pkw[32] = pool_head; pkw[33] = (uint32_t)n_spec; pkw[34] = (uint32_t)my_base; pkw[35] = (uint32_t)my_share; pkw[36] = trip;
-                pkw[37] = (uint32_t)reused; pkw[38] = (uint32_t)(reused >> 32); pkw[39] = __float_as_uint(root_sq);
+                pkw[37] = (uint32_t)reused; pkw[38] = (uint32_t)(reused >> 32); pkw[39] = root_best;
             }
         }
     };
@@ -331,7 +334,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             plen = (int)uniu(pkw[31]); pool_head = uniu(pkw[32]); n_spec = (int)uniu(pkw[33]); my_base = (int)uniu(pkw[34]); my_share = (int)uniu(pkw[35]);
             trip = uniu(pkw[36]);
             reused = ((unsigned long long)uniu(pkw[38]) << 32) | uniu(pkw[37]);
-            root_sq = __uint_as_float(uniu(pkw[39]));
+            root_best = uniu(pkw[39]);
+            rng_base = 0xffffffffu;                                      // (the buffered draws are not kept across a forward in this shape)
         }
     };
 
@@ -426,8 +430,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 pidx[ps] = my_idx;
                 lds_f32 *po = pout + ps * 8;
                 po[0] = pr.x; po[1] = pr.y; po[2] = pr.z; po[3] = pr.w; po[4] = vv.x;
-                const ux4 hq = hot_ld(my_idx);
-                hot_st_link(my_idx, hq.w | LK_OUT);
+                hot_st_link(my_idx, hot_ld_link(my_idx) | LK_OUT);
                 my_take = false;
             }
             pool_head = (pool_head + (uint32_t)n_spec) % (uint32_t)DEEP_POOL;
@@ -442,7 +445,6 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             if (!yielded) tbl_put(phase == DP_ROOT ? st.board : cur.board, probs, nn_value);
 
             const int ca = lane & 3;                               // the child / action this lane works on
-            const bool wrap1 = ca + 1 >= 4, wrap2 = ca + 2 >= 4, wrap3 = ca + 3 >= 4;   // the lane k places further round the quad comes BEFORE this one
             // expand (search.rs:56-75): one child per action with prior > 0, state = clone + step; four lanes, one child each
             float pri[4] = {0.0f, 0.0f, 0.0f, 0.0f};               // priors of the children just created, in child order
             uint32_t act_mask = 0;                                 // bit a: action a got a child
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     const uint32_t ni = n_nodes + pos;
                     const uint32_t undo = (idx != 0u && (uint32_t)ca == (((idx_link >> 27) & 3u) ^ 2u)) ? LK_UNDO : 0u;   // 0 left, 1 up, 2 right, 3 down
                     hot_st(ni, ux4{0u, 0u, __float_as_uint(mine), ((uint32_t)ca << 27) | undo});
-                    hot2_st(ni, 0.0f, 0.0f);                                 // unvisited: q = 0 (search.rs:31), sqrt(0)
+                    hot2_st(ni, 0.0f, DNONE);                                // value_sum 0 (and q = 0: search.rs:31); no children
                     brdq[ni] = make_uint4((uint32_t)c.board, (uint32_t)(c.board >> 32), idx, (uint32_t)c.depth);
                 }
                 if (lane == 0) hot_st_link(idx, (idx_link & ~(LK_CB | (7u << 24))) | n_nodes | (cnt << 24));
@@ -475,8 +477,13 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             };
             // next_sample (search.rs:94-100): a child of `node` by its priors; `cur` follows
             auto sample_child = [&](uint32_t cb, uint32_t nch) {
-                const u32x4 w = rng_draw(a.seed, e_global, it * MED + expanded, STREAM_MCTS | ((uint32_t)t << 8));
-                const int k = sample_weighted4(pri, (int)nch, u32_to_unit(w.x));
+                // (Philox is ~110 instructions for one draw: the lanes compute 64 consecutive ones in one go)
+                const uint32_t di = it * MED + expanded;
+                if ((di & ~63u) != rng_base) {
+                    rng_base = di & ~63u;
+                    rng_buf = rng_draw(a.seed, e_global, rng_base + (uint32_t)lane, STREAM_MCTS | ((uint32_t)t << 8)).x;
+                }
+                const int k = sample_weighted4(pri, (int)nch, u32_to_unit(rdl(rng_buf, (int)(di & 63u))));
                 int act = 0, seen = 0;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) if ((act_mask >> x) & 1u) { if (seen == k) act = x; ++seen; }
@@ -484,28 +491,81 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 node = cb + (uint32_t)k;
                 puzzle_step(cur, env, act);
                 cur_link = ((uint32_t)act << 27) | undo;
-                push(node, 0.0f, 0u);
+                push(node);
             };
-            // backpropagate (search.rs:45-53): value_sum += v, visit_count += 1 on every node of the path -- one store per level
-            auto backprop = [&](uint32_t idx, float val) {
-                if (!overflow) {
-                    // lane l = path level l: the node's new statistics and, from them, the q and sqrt(visit) the next descents read
-                    const uint32_t nv = p_vis + 1u; const float nvs = p_vs + val;
-                    const float nq = nvs / (float)nv, nsq = sqrtf((float)nv);
-                    if (lane < plen && p_idx != 0u) { hot_st_stats(p_idx, nvs, nv); hot2_st(p_idx, nq, nsq); }   // (the root's statistics live in registers)
-                    root_sq = rdlf(nsq, 0);                                                         // level 0 is the root
+            // next (search.rs:77-91) of a node, from its children's stored statistics: the first maximum of
+            // ucb = q + C * sqrt(N) / (n + 1) * prior (search.rs:29-39), strict '>' from -inf (a NaN never wins), as child index | action << 27;
+            // DNONE without children or when nothing beats -inf (the reference panics there).  Per-lane arguments.
+            auto best_child = [&](uint32_t cb, uint32_t nch, float sqN) -> uint32_t {
+                if (nch == 0u) return DNONE;
+                ux4 k[4];                                                              // (the children of a node are contiguous)
+                if (cb + nch <= NL) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) k[c] = tbl[cb + ((uint32_t)c < nch ? (uint32_t)c : nch - 1u)];
+                } else if (cb >= NL) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) k[c] = hotq[cb + ((uint32_t)c < nch ? (uint32_t)c : nch - 1u)];
                 } else {
-                    if (lane == 0) {
-                        while (idx != DNONE && idx != 0u) {
-                            const ux4 hq = hot_ld(idx);
-                            const uint32_t nv = hq.y + 1u; const float nvs = __uint_as_float(hq.x) + val;
-                            hot_st_stats(idx, nvs, nv); hot2_st(idx, nvs / (float)nv, sqrtf((float)nv));
-                            idx = brdq[idx].z;
-                        }
-                    }
-                    root_sq = sqrtf((float)(root_visit + 1u));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) k[c] = hot_ld(cb + ((uint32_t)c < nch ? (uint32_t)c : nch - 1u));
                 }
+                uint32_t best = DNONE; float bu = -__builtin_inff();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float d = sqN / ((float)k[c].y + 1.0f);
+                    d = a.C * d;
+                    d = d * __uint_as_float(k[c].z);
+                    const float u = __uint_as_float(k[c].x) + d;
+                    const bool better = ((uint32_t)c < nch) & (u > bu);
+                    bu = better ? u : bu;
+                    best = better ? ((cb + (uint32_t)c) | (k[c].w & (3u << 27))) : best;
+                }
+                return best;
+            };
+            // backpropagate (search.rs:45-53): value_sum += v, visit_count += 1 on every node of the path -- lane l = path level l -- and,
+            // from the new statistics, the q and the best child the next descents read (header: hot2)
+            auto backprop = [&](uint32_t idx, float val) {
+                uint32_t b = DNONE;
+                if (!overflow) {
+                    const bool on = lane < plen, inner = on && lane != 0;                // level 0 is the root: its record lives in registers
+                    const bool in_lds = p_idx < NL;
+                    uint32_t vis = root_visit, link = root_cb | (root_nc << 24); float vs = root_vs;
+                    if (inner) {
+                        if (in_lds) { const ux4 h = tbl[p_idx]; vis = h.y; link = h.w; vs = __uint_as_float(reinterpret_cast<lds_u32 *>(tq + p_idx)[0]); }
+                        else { const ux4 h = hotq[p_idx]; vis = h.y; link = h.w; vs = __uint_as_float(reinterpret_cast<const uint32_t *>(hot2 + p_idx)[0]); }
+                    }
+                    const uint32_t nv = vis + 1u; const float nvs = vs + val;
+                    const float nq = nvs / (float)nv;
+                    ux2 w; w.x = __float_as_uint(nq); w.y = nv;
+                    if (inner) {
+                        if (in_lds) { *reinterpret_cast<lds_u2 *>(tbl + p_idx) = w; reinterpret_cast<lds_u32 *>(tq + p_idx)[0] = __float_as_uint(nvs); }
+                        else { *reinterpret_cast<ux2 *>(hotq + p_idx) = w; reinterpret_cast<uint32_t *>(hot2 + p_idx)[0] = __float_as_uint(nvs); }
+                    }
+                    // level l reads the statistics level l+1 has just stored (same wave: its memory operations stay in order)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (on) b = best_child(link & LK_CB, lk_nch(link), sqrtf((float)nv));
+                    if (inner) {
+                        if (in_lds) reinterpret_cast<lds_u32 *>(tq + p_idx)[1] = b;
+                        else reinterpret_cast<uint32_t *>(hot2 + p_idx)[1] = b;
+                    }
+                } else if (lane == 0) {
+                    // a path deeper than the 64 levels the lanes hold: bottom-up through the parent links
+                    while (idx != DNONE && idx != 0u) {
+                        const ux4 h = hot_ld(idx);
+                        const uint32_t nv = h.y + 1u; const float nvs = __uint_as_float(hot2_ld_vs(idx)) + val;
+                        hot_st(idx, ux4{__float_as_uint(nvs / (float)nv), nv, h.z, h.w});
+                        hot2_st(idx, nvs, best_child(h.w & LK_CB, lk_nch(h.w), sqrtf((float)nv)));
+                        idx = brdq[idx].z;
+                    }
+                    b = best_child(root_cb, root_nc, sqrtf((float)(root_visit + 1u)));
+                }
+                root_best = rdl(b, 0);
                 root_vs = root_vs + val; root_visit += 1u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             };
 
             // root node of a move's tree (search.rs:120-129): visit_count 1, expanded with the root priors
@@ -513,8 +573,13 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 ++evals;
                 n_nodes = 1; cursor = 1;
                 pidx[lane < DEEP_POOL ? lane : 0] = DNONE;               // outputs of the previous move's tree (every lane stores: no lane branch in the walk)
-                root_vs = 0.0f; root_visit = 1u; root_cb = 1u; root_sq = 1.0f;
+                root_vs = 0.0f; root_visit = 1u; root_cb = 1u;
+                rng_base = 0xffffffffu;                                   // (the draws are keyed by the move)
                 root_nc = expand(0u, 0u, st, pb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                root_best = rdl(best_child(root_cb, root_nc, 1.0f), 0);         // sqrt(visit_count = 1)
                 it = 0;
                 phase = DP_LEAF;
             };
@@ -541,10 +606,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                         const unsigned long long walked = __builtin_readcyclecounter() - tree_t0;
                         bool stop = walked > (unsigned long long)a.tree_budget;
                         if (!stop && walked > (unsigned long long)a.tree_budget_min) {        // somebody waits for a forward: do not keep it waiting
-                            int w8 = 0;
-#pragma unroll
-                            for (int w = 0; w < 8; ++w) w8 |= wait_f[w];
-                            stop = uni(w8) != 0;
+                            const ux4 wa = *(volatile lds_u4 *)(res + 8 * C + 16), wb = *(volatile lds_u4 *)(res + 8 * C + 20);
+                            stop = uniu(wa.x | wa.y | wa.z | wa.w | wb.x | wb.y | wb.z | wb.w) != 0u;
                         }
                         if (stop) { yielded = true; dem_idx = DNONE; break; }
                     }
@@ -612,52 +675,20 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                     }
                     // ---- descend to a leaf by UCB (search.rs:133-138, next :77-91, ucb :29-39): four lanes score the four
                     //      children; the state follows the chosen actions (a child's state IS step(parent state, action))
+                    // ---- descend to a leaf (search.rs:133-138): follow the stored `next` choices; the state follows the actions (a
+                    //      child's state IS step(parent state, action), and a child exists only for a legal move)
                     node = 0; plen = 0; overflow = false;
-                    push(0u, root_vs, root_visit);
-                    uint32_t cur_nc = root_nc, cur_cb = root_cb;
-                    float cur_sq = root_sq;                    // sqrt(visit_count) of the node whose children are scored
+                    push(0u);
                     cur = st; cur_link = 0u;                   // (a root without children is evaluated again, like any childless node)
-                    while (cur_nc > 0) {
-                        const uint32_t ci = cur_cb + ((uint32_t)ca < cur_nc ? (uint32_t)ca : cur_nc - 1u);
-                        ux4 kq; ux2 k2;
-                        if (cur_cb + 4u <= NL) { kq = tbl[ci]; k2 = tq[ci]; }         // (wave-uniform: the children of a node are contiguous)
-                        else { kq = hot_ld(ci); k2 = hot2_ld(ci); }
-                        // ucb = q + C * sqrt(N_parent) / (n + 1) * prior (search.rs:29-39); q and the square root are the stored ones
-                        float d = cur_sq / ((float)kq.y + 1.0f);
-                        d = a.C * d;
-                        d = d * __uint_as_float(kq.z);
-                        float u = __uint_as_float(k2.x) + d;
-                        u = (uint32_t)ca < cur_nc ? u : -__builtin_inff();
-                        // next (search.rs:77-91): the first maximum, strict '>' from -inf (a NaN never wins).  Every lane of a quad looks at
-                        // the other three through DPP: a lane before it beats it on >=, a lane after it on >
-                        const float o1 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(u), 0x39, 0xf, 0xf, false));   // quad_perm [1,2,3,0]
-                        const float o2 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(u), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-                        const float o3 = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(u), 0x93, 0xf, 0xf, false));   // quad_perm [3,0,1,2]
-                        // (bitwise on purpose: '||' and '?:' on lane-varying compares become branches over exec masks)
-                        const bool beaten = (o1 > u) | (o2 > u) | (o3 > u) | ((o1 == u) & wrap1) | ((o2 == u) & wrap2) | ((o3 == u) & wrap3);
-                        const uint32_t wm = (uint32_t)__builtin_amdgcn_ballot_w64((u > -__builtin_inff()) & !beaten) & 15u;
-                        if (wm == 0u) break;                       // all-NaN UCB: the reference panics here
-                        const int best = __builtin_ctz(wm);
-                        node = cur_cb + (uint32_t)best;
-                        const uint32_t bvs = rdl(kq.x, best), bvis = rdl(kq.y, best);
-                        cur_link = rdl(kq.w, best);
-                        cur_sq = __uint_as_float(rdl(k2.y, best));
-                        {   // the child's state IS step(parent state, action), and a child exists only for a legal move (its prior is > 0
-                            // only where the mask allows the action): Env::step without the bounds checks (puzzle.rs:135-160)
-                            const int act = lk_act(cur_link);
-                            const int zi = cur.zy * env.width + cur.zx;
-                            cur.zx += (act == 2 ? 1 : 0) - (act == 0 ? 1 : 0); cur.zy += (act == 3 ? 1 : 0) - (act == 1 ? 1 : 0);
-                            const int ti = cur.zy * env.width + cur.zx;
-                            const uint64_t tile = (cur.board >> (4 * ti)) & 15ull;
-                            cur.board = (cur.board & ~(15ull << (4 * ti))) | (tile << (4 * zi));
-                            cur.depth = cur.depth > 0 ? cur.depth - 1 : 0;
-                        }
-                        push(node, __uint_as_float(bvs), bvis);
-                        cur_cb = cur_link & LK_CB; cur_nc = lk_nch(cur_link);
+                    for (uint32_t b = root_best; b != DNONE; b = uniu(hot2_ld_best(node))) {
+                        node = b & LK_CB;
+                        puzzle_step_legal(cur, env, (int)((b >> 27) & 3u));
+                        push(node);
 #ifdef TW_ABLATE
                         ++c_lvl;
 #endif
                     }
+                    if (node != 0u) cur_link = uniu(hot_ld_link(node));       // the leaf's flags and action
                     value = 0.0f; expanded = 0;
                     TW_DS(y3); TW_DA(c_desc, y2, y3);
                 } else {
