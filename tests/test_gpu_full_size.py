@@ -138,7 +138,7 @@ def test_config5_selfplay_full_size_vs_oracle(tw, oracle, searches, n_sample):
 
 
 @pytest.mark.parametrize("E,searches,n_sample,threads", [(65_536, 32, 26, 512), (16_384, 100, 24, 256)])
-def test_selfplay_lane_per_episode_kernel_full_size_vs_oracle(tw, oracle, E, searches, n_sample, threads):
+def test_selfplay_lane_per_episode_kernel_full_size_vs_oracle(tw, oracle, request, E, searches, n_sample, threads):
     """`mcts_f32_kernel` (one lane pair per episode, tw_mcts.hip) at the sizes its numbers are quoted on: 65,536 x 32 (every
     episode resident: 256 workgroups of 8 waves x 32 episodes) and 16,384 x 100 (four waves share 32 episodes, one persistent
     workgroup per CU, episode queue), Puzzle-15, 512/256 policy, transpose twist.  A node whose move takes its parent's move
@@ -150,6 +150,8 @@ def test_selfplay_lane_per_episode_kernel_full_size_vs_oracle(tw, oracle, E, sea
     D = 8
     env, oenv = tw.env.Puzzle(4, 4, D, 2, 256), oracle.Puzzle(4, 4, D, 2, 256)
     coll = tw.collector.AZCollector(E, searches, 1.41, 1, 32)
+    _lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_AZ_VARIANT, 2))       # this kernel, whatever the automatic choice is at this size
+    request.addfinalizer(lambda: _lib.check(_lib.lib().tw_set_launch_option(_lib.TW_OPT_AZ_VARIANT, 0)))
     g = coll.collect(env, gp, seed=900)
     assert g.stats["rollout_threads"] == threads
     assert g.stats["rollout_blocks"] == twisterl_amd.device_info()["compute_units"]

@@ -490,8 +490,8 @@ def _assert_same_az(g, o, n_cells):
     (3, 3, 0, 32, 128, 10, 5, 1, False),     #   difficulty 0: every root is final
     (3, 3, 4, 32, 256, 16, 0, 1, False),     #   zero searches
     (3, 3, 3, 32, 128, 400, 10, 1, False),   #   one walker per workgroup and the episode queue (up to 2 episodes per CU), 16 columns
-    (3, 3, 4, 64, 256, 700, 8, 1, True),     #   two walkers per workgroup on the 32-column engine (2 to 4.5 episodes per CU), 16 columns each
-    (3, 3, 4, 64, 256, 1300, 5, 1, True),    #   four walkers per workgroup on the 32-column engine (more than 4.5 episodes per CU), 8 columns each
+    (3, 3, 4, 64, 256, 700, 8, 1, True),     #   two walkers per workgroup on the 32-column engine (2 to 3.5 episodes per CU), 16 columns each
+    (3, 3, 4, 64, 256, 1300, 5, 1, True),    #   four walkers per workgroup on the 32-column engine (more than 3.5 episodes per CU), 8 columns each
     (3, 3, 3, 32, 128, 3300, 24, 2, True),   #   eight walkers per workgroup (more than 10 episodes per CU, short searches), 4 columns each
 ])
 def test_az_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
@@ -713,7 +713,7 @@ def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, h
 
 
 def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_busy(tw, oracle):
-    """tw_mcts_deep.hip: one walker x 16 columns per workgroup up to 2 episodes per CU; on the 32-column engine two x 16 up to 4.5
+    """tw_mcts_deep.hip: one walker x 16 columns per workgroup up to 2 episodes per CU; on the 32-column engine two x 16 up to 3.5,
     four x 8 beyond, and beyond ten (short searches) eight x 4 in workgroups of eight waves -- at most
     one workgroup per CU, the rest of the episodes comes off the queue.  The parity cases of test_az_collect_bit_exact_vs_oracle
     run all of them; this pins the launches the workgroup shape tells apart, and every pinned shape (TW_OPT_AZ_VARIANT: 4 / 3 /

@@ -795,8 +795,11 @@ bool mcts_deep_applies(const MctsArgs &a)
     // (eight walkers per workgroup against lane-per-episode: 8,192 x 100 45.9 / 61.1 ms, 12,288 x 100 64.1 / 68.0, 16,384 x 100 81.4 / 78.6,
     //  8,192 x 50 25.3 / 28.4, 6,144 x 50 21.7 / 28.1, 8,192 x 32 19.7 / 17.8, 6,144 x 32 14.9 / 17.5, 4,096 x 24 9.2 / 9.5,
     //  4,096 x 16 6.9 / 6.4, 4,096 x 8 4.4 / 3.5, 2,048 x 16 5.3 / 6.4, 2,048 x 8 3.4 / 3.4)
+    // round 3 (board-keyed output table, best-child links; walker with eight per workgroup / lane-per-episode, ms): 16,384 x 100 63.7 / 75.5,
+    // 32,768 x 100 117 / 141, 8,192 x 400 96.5 / 235, 8,192 x 32 15.3 / 17.7, 16,384 x 32 27.3 / 25.2, 6,144 x 16 7.7 / 9.0, 8,192 x 16 9.6 / 9.1,
+    // 4,096 x 8 4.1 / 3.6
     const uint32_t S = a.num_searches;
-    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 48u : (S >= 48 ? 32u : (S >= 32 ? 24u : (S >= 24 ? 16u : 8u))));
+    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 128u : (S >= 48 ? 48u : (S >= 32 ? 32u : (S >= 16 ? 24u : 8u))));
 }
 
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
@@ -822,7 +825,9 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
     const uint64_t avail = (uint64_t)(cus - r);
     DeepShape sh;
-    sh.walkers = num_episodes <= 2 * avail ? 1 : (num_episodes <= 4 * avail + avail / 2 ? 2 : 4);
+    // (round 3, ms for two / four walkers: 600 x 100 11.7 / 13.1, 768 x 100 12.7 / 13.1, 900 x 100 13.2 / 13.2, 1,024 x 100 14.1 / 13.1, 768 x 1,000 93.2 / 90.6,
+    //  1,024 x 1,000 100.5 / 91.3: four as soon as they fill every CU, and always for long searches)
+    sh.walkers = num_episodes <= 2 * avail ? 1 : ((2 * num_episodes < 7 * avail && num_searches < 512) ? 2 : 4);
     if (num_searches <= 128 ? num_episodes > 10 * avail : (num_searches < 512 && num_episodes > 14 * avail)) sh.walkers = 8;
     sh.wide = sh.walkers >= 2;
     // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 / 5 pin two / one / four walkers per workgroup, + 16 / + 32 the 16- / 32-column engine
