@@ -309,6 +309,58 @@ def test_ppo_collect_of_boards_above_16_cells(tw, oracle, w, h, diff, emb, commo
     assert genv.get_state() == before
 
 
+def test_boards_of_17_to_25_cells_roll_out_on_the_device(tw, oracle):
+    """5 x 5 (and 6 x 4) PPO collects run the device kernel of tw_rollout_big.hip -- 5-bit cells in a 128-bit register, two-byte obs
+    ids, the generic engine -- not the host-stepped path: 65,536 envs of a 5 x 5 board in 4,096 workgroups of 256 threads, sampled
+    episodes bit-equal to the oracle on every field (the RNG is keyed by the global episode index); a small batch with the
+    transpose twist compared whole, in both orders; and the same bytes as the host-stepped path (pinned through TW_OPT_FORCE_GEOM)."""
+    from tests.util import make_deep_policy_arrays
+    arrs = make_deep_policy_arrays(25, seed=5, emb=64, common=(128,), scale=2.0)
+    gp, op = amd_policy(arrs), oracle_policy(oracle, arrs)
+    E, D = 65_536, 6
+    genv, oenv = tw.env.Puzzle(5, 5, D, 2, 256), oracle.Puzzle(5, 5, D, 2, 256)
+    coll = tw.collector.PPOCollector(E, 0.995, 0.995, 32)
+    g = coll.collect(genv, gp, seed=41)
+    assert (g.stats["rollout_blocks"], g.stats["rollout_threads"]) == (E // 16, 256)
+    a = g.to_numpy()
+    assert a["obs"].dtype == np.uint16 and a["obs"].shape[1] == 25
+    L, S = a["ep_len"].astype(np.int64), a["ep_start"].astype(np.int64)
+    assert L.sum() == len(g) and L.min() >= 1 and L.max() <= 2 * D + 1
+    order = np.concatenate([[E - 1], np.arange(E - 1)])
+    assert np.array_equal(S[order], np.concatenate([[0], np.cumsum(L[order])[:-1]]))
+    assert np.array_equal(a["obs"] // 25, np.broadcast_to(np.arange(25), a["obs"].shape))          # obs id of cell c in [25c, 25c + 25)
+    assert np.all((a["obs"] % 25).sum(axis=1) == 300)                                             # every board a permutation of 0..24
+    rng = np.random.default_rng(1)
+    for e in sorted(set([0, 1, E - 2, E - 1] + [int(x) for x in rng.choice(E, size=28, replace=False)])):
+        o = oracle.ppo_collect(oenv, op, 1, 0.995, 0.995, seed=41, episode_offset=e, arith=oracle.ARITH_CHAIN, det_log=True, merge_order=False)
+        s, ln = int(S[e]), int(L[e])
+        assert ln == int(o.ep_len[0]), e
+        assert np.array_equal(a["obs"][s:s + ln].astype(np.int64), o.obs), e
+        assert np.array_equal(a["actions"][s:s + ln].astype(np.int64), o.actions), e
+        for k, ok in (("logits", o.logits), ("values", o.values), ("rewards", o.rewards), ("advs", o.additional_data["advs"]), ("rets", o.additional_data["rets"])):
+            assert np.array_equal(f32_bits(a[k][s:s + ln]), f32_bits(ok)), (e, k)
+    del a, g
+    for (w, h, twists) in ((5, 5, True), (6, 4, False)):
+        n2 = w * h
+        arrs = make_deep_policy_arrays(n2, seed=6, emb=32, common=(64, 32), scale=2.0)
+        op_, ap_ = puzzle_transpose_twist(w) if twists else ((), ())
+        gp, op = amd_policy(arrs, op_, ap_), oracle_policy(oracle, arrs, op_, ap_)
+        genv, oenv = tw.env.Puzzle(w, h, 5, 2, 256), oracle.Puzzle(w, h, 5, 2, 256)
+        for merge_order in (True, False):
+            coll = tw.collector.PPOCollector(150, 0.995, 0.995, 32)
+            coll.merge_order = merge_order
+            g = coll.collect(genv, gp, seed=17)
+            assert g.stats["rollout_threads"] == 256 and g.stats["rollout_blocks"] == 10
+            o = oracle.ppo_collect(oenv, op, 150, 0.995, 0.995, seed=17, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8, merge_order=merge_order)
+            _assert_same_collect(g, o, n2)
+        with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):                  # the host-stepped path (tw_ppo_collect_env)
+            hst = coll.collect(genv, gp, seed=17)
+        assert hst.stats["rollout_blocks"] != 10
+        ga, ha = g.to_numpy(), hst.to_numpy()
+        for k in ga:
+            assert np.array_equal(ga[k], ha[k]), k
+
+
 # ------------------------------------------------------------------------------ any Sequential depth (modules.rs:28-34)
 @pytest.mark.parametrize("n2,emb,common,pl,vl,twists", [
     (9, 64, (128, 64), (), (), True),          # two common layers

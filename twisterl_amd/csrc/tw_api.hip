@@ -1011,10 +1011,10 @@ struct EventSet {
     int init() { for (; n < 5; ++n) TW_HIP(hipEventCreate(&ev[n])); return TW_OK; }
 };
 
-int make_env_consts(const tw_puzzle_desc *env, PuzzleConsts *out)
+int make_env_consts(const tw_puzzle_desc *env, PuzzleConsts *out, uint64_t max_cells = 16)
 {
     const uint64_t nc = (uint64_t)env->width * env->height;
-    if (env->width == 0 || env->height == 0 || nc > 16) {
+    if (env->width == 0 || env->height == 0 || nc > max_cells) {
         set_error("Puzzle %ux%u: the HIP path packs the board as 16 nibbles (width*height <= 16)", env->width, env->height);
         return TW_ERR_UNSUPPORTED;
     }
@@ -1027,7 +1027,7 @@ int make_env_consts(const tw_puzzle_desc *env, PuzzleConsts *out)
     out->difficulty = (int)env->difficulty; out->depth0 = (int)depth0;
     out->r_step = -0.5f / (float)env->max_depth;           // puzzle.rs:175
     uint64_t id = 0;
-    for (uint64_t i = 0; i < nc; ++i) id |= i << (4 * i);
+    for (uint64_t i = 0; i < nc && i < 16; ++i) id |= i << (4 * i);          // (boards above 16 cells have their own packing: tw_rollout_big.hip)
     out->ident = id;
     return TW_OK;
 }
@@ -1090,10 +1090,16 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     if (prm->precision > TW_PREC_F16X2) { set_error("tw_ppo_collect: unknown precision %u", prm->precision); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
 
-    if ((uint64_t)env->width * env->height > 16) return collect_big_board(env, policy, prm, nullptr, out);
+    // boards of 17 .. 25 cells roll out on the device too (tw_rollout_big.hip: 5-bit cells, two-byte obs ids, the generic engine);
+    // larger ones -- and whatever that kernel does not take -- step on the host (tw_env_generic.hip)
+    const uint64_t cells = (uint64_t)env->width * env->height;
+    const bool big = cells > 16;
+    if (big && !(cells <= 25 && policy->dev.generic && prm->precision == TW_PREC_F32_EXACT && (uint64_t)env->depth_slope * env->difficulty <= 1022 &&
+                 env->max_depth != 0 && !launch_options().force_geom))
+        return collect_big_board(env, policy, prm, nullptr, out);
 
     RolloutArgs ra{};
-    rc = make_env_consts(env, &ra.env); if (rc) return rc;
+    rc = make_env_consts(env, &ra.env, 25); if (rc) return rc;
     ra.pol = policy->dev;
     if (ra.pol.obs_size != ra.env.n_cells * ra.env.n_cells) {
         set_error("index out of bounds: policy obs_size %d != Puzzle obs ids %d", ra.pol.obs_size, ra.env.n_cells * ra.env.n_cells);
@@ -1118,9 +1124,10 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     const uint64_t resident = ra.pol.generic ? rollout_f32_resident_episodes(ra.reserve_cus) / 16
                             : prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false, ra.reserve_cus)
                                                                   : rollout_f32_resident_episodes(ra.reserve_cus);
-    const bool persist = E > resident && !launch_options().no_persist;
+    const bool persist = E > resident && !launch_options().no_persist && !big;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
-                 o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
+                 o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0),
+                 o_obs16 = seg(big ? R * cells * 2 : 0);
     void *wsp = nullptr;
     rc = ws_reserve(cur, &wsp); if (rc) return rc;
     uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
@@ -1140,7 +1147,8 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
         if (rc) return rc;
     }
     TW_HIP(hipEventRecord(ev.ev[0], s));
-    rc = prm->precision == TW_PREC_F16     ? launch_rollout_f16(ra, s, &st.rollout_blocks, &st.rollout_threads)
+    rc = big                               ? launch_rollout_big(ra, reinterpret_cast<uint16_t *>(ws + o_obs16), s, &st.rollout_blocks, &st.rollout_threads)
+         : prm->precision == TW_PREC_F16   ? launch_rollout_f16(ra, s, &st.rollout_blocks, &st.rollout_threads)
          : prm->precision == TW_PREC_F16X2 ? launch_rollout_f16x2(ra, s, &st.rollout_blocks, &st.rollout_threads)
                                            : launch_rollout_f32(ra, s, &st.rollout_blocks, &st.rollout_threads);
     if (rc) return rc;
@@ -1158,7 +1166,8 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     c->n_records = total; c->n_episodes = E; c->n_cells = (uint32_t)ra.env.n_cells; c->n_actions = 4; c->is_ppo = 1;
     size_t ccur = 0;
     auto cseg = [&](int f, size_t bytes) { c->field_bytes[f] = bytes; size_t o = ccur; ccur = align_up(ccur + bytes, 256); return o; };
-    const size_t c_obs = cseg(TW_F_OBS, total * c->n_cells), c_lg = cseg(TW_F_LOGITS, total * 16), c_prm = cseg(TW_F_PERMS, total),
+    if (big) c->obs_width = 2;
+    const size_t c_obs = cseg(TW_F_OBS, total * c->n_cells * c->obs_width), c_lg = cseg(TW_F_LOGITS, total * 16), c_prm = cseg(TW_F_PERMS, total),
                  c_val = cseg(TW_F_VALUES, total * 4), c_rew = cseg(TW_F_REWARDS, total * 4), c_act = cseg(TW_F_ACTIONS, total),
                  c_adv = cseg(TW_F_ADVS, total * 4), c_ret = cseg(TW_F_RETS, total * 4), c_len = cseg(TW_F_EP_LEN, E * 4),
                  c_start = cseg(TW_F_EP_START, E * 8);
@@ -1174,7 +1183,10 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
 
 #define TW_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { tw_collected_free(c); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
     TW_HIP_C(hipEventRecord(ev.ev[3], s));
-    rc = launch_finalize_ppo(ra.out, ep_start_ws, E, ra.env.n_cells, prm->gamma, prm->lambda, ct, s);
+    rc = launch_finalize_ppo(ra.out, ep_start_ws, E, big ? 0 : ra.env.n_cells, prm->gamma, prm->lambda, ct, s);      // (0 cells: the obs ids come from their own array)
+    if (rc == TW_OK && big)
+        rc = launch_compact_obs16(reinterpret_cast<const uint16_t *>(ws + o_obs16), ra.out.ep_len, ep_start_ws, E, t_pad, ra.env.n_cells,
+                                  reinterpret_cast<uint16_t *>(ca + c_obs), s);
     if (rc) { tw_collected_free(c); return rc; }
     TW_HIP_C(hipMemcpyAsync(ca + c_len, ra.out.ep_len, E * 4, hipMemcpyDeviceToDevice, s));
     TW_HIP_C(hipMemcpyAsync(ca + c_start, ep_start_ws, E * 8, hipMemcpyDeviceToDevice, s));

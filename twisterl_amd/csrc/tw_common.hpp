@@ -437,6 +437,10 @@ inline int waves_per_group(uint64_t n)
 
 // kernel launchers (each returns a TW_* status)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+// boards of 17 .. 25 cells (tw_rollout_big.hip): obs ids as uint16 in their own padded array [E][t_pad][n_cells]
+int launch_rollout_big(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+int launch_compact_obs16(const uint16_t *obs16, const uint32_t *ep_len, const uint64_t *ep_start, uint64_t E, int t_pad, int n_cells,
+                         uint16_t *out, hipStream_t s);
 int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s);
 uint64_t rollout_f32_resident_episodes(int reserve_cus = 0);   // episodes the f32 rollout keeps resident at once (persistent mode above that)
 // Lanes the exact-f32 kernels (rollout, self-play) keep resident for a batch: episodes beyond that wait in the queue of the

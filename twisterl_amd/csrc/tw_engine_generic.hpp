@@ -209,7 +209,7 @@ struct EngineV {
         int ro[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) ro[i] = lds_rows[col * NC + i];
-        constexpr int QT = 4;
+        constexpr int QT = NC > 16 ? 1 : 4;            // (boards above 16 cells: QT x NC row quads are in flight per lane)
         const int nq = E / 4;
         for (int q0 = ql; q0 < nq; q0 += 16 * QT) {
             int qs[QT];

@@ -1,0 +1,161 @@
+// tw_rollout_big.hip -- the fused PPO rollout for Puzzle boards of 17 .. 25 cells (5 x 5, 6 x 4, ..) on the device.
+//
+// Puzzle::new takes any width x height (reference rust/src/envs/puzzle.rs:34-42); the rollout kernels of tw_rollout.hip pack a
+// board as 16 nibbles in one 64-bit register.  Here a board is 25 x 5 bits in a 128-bit integer, obs ids (cell * n_cells + tile,
+// puzzle.rs:183-185) run up to 624 and are stored as uint16, and the policy -- any Sequential stack over an obs_size above 256 is
+// a "generic" policy (tw_policy_create) -- runs on EngineV (tw_engine_generic.hpp: every Linear on the matrix cores, the
+// EmbeddingBag gathered from global memory).  Same path otherwise: PPOCollector::single_collect (collector/ppo.rs:54-80),
+// Policy::forward_with_perm (nn/policy.rs:56-100), sample_from_logits (policy.rs:169-172), Env::step / masks / reward / is_final
+// (puzzle.rs:135-181), same RNG streams, same arithmetic: bit-equal to the oracle.  Boards above 25 cells, self-play and
+// evaluate / solve of boards above 16 cells stay on the host-stepped path (tw_env_generic.hip).
+#include "tw_engine_generic.hpp"
+
+namespace tw {
+
+typedef unsigned __int128 u128;
+constexpr int BIG_NC = 25;
+
+struct BigLane { u128 board; int32_t zx, zy, depth; };       // 5 bits per cell: cell i holds tile (board >> 5i) & 31
+
+__device__ inline uint32_t big_cell(u128 b, int i) { return (uint32_t)(b >> (5 * i)) & 31u; }
+
+__device__ inline void big_step(BigLane &s, const PuzzleConsts &c, int action)          // Env::step (puzzle.rs:135-160), as puzzle_step
+{
+    const int dx = (action == 2 ? 1 : 0) - (action == 0 ? 1 : 0), dy = (action == 3 ? 1 : 0) - (action == 1 ? 1 : 0);
+    int nx = s.zx + dx, ny = s.zy + dy;
+    const bool ok = (unsigned)nx < (unsigned)c.width && (unsigned)ny < (unsigned)c.height;
+    nx = ok ? nx : s.zx; ny = ok ? ny : s.zy;
+    const int zi = s.zy * c.width + s.zx, ti = ny * c.width + nx;
+    const u128 tile = (s.board >> (5 * ti)) & (u128)31;                     // cell zi holds 0
+    s.board = (s.board & ~((u128)31 << (5 * ti))) | (tile << (5 * zi));
+    s.zx = nx; s.zy = ny;
+    s.depth = s.depth > 0 ? s.depth - 1 : 0;
+}
+
+__device__ inline u128 big_ident(int n_cells)
+{
+    u128 id = 0;
+    for (int i = 0; i < n_cells; ++i) id |= (u128)(uint32_t)i << (5 * i);
+    return id;
+}
+
+template <int NC>
+__global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a, uint16_t *obs16)
+{
+    using Eng = EngineV<NC>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Eng eng;
+    eng.begin1(a.pol, lds);
+    const PuzzleConsts env = a.env;
+    const int j = eng.j;
+    const int nc = env.n_cells;
+    const u128 ident = big_ident(nc);
+    // every lane group of every wave carries the state of column j (the engine's mapping); lanes 0-15 of wave 0 store
+    const uint64_t e_local = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)j;
+    const bool valid  = e_local < a.num_episodes;
+    const bool writer = eng.h == 0 && eng.primary();
+    const uint64_t e_global = a.episode_offset + e_local;
+    BigLane st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;
+    if (valid) {                                                             // Env::reset (puzzle.rs:119-133)
+        for (int d = 0; d < env.difficulty; ++d) {
+            const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)d, STREAM_SCRAMBLE);
+            big_step(st, env, (int)u32_below(w.x, 4u));
+        }
+        st.depth = env.depth0;
+    }
+    bool alive = valid;
+    int  t = 0;
+    eng.begin2();
+
+    while (__syncthreads_or(alive ? 1 : 0)) {
+        // ---- observe (puzzle.rs:183-185) + twist of the obs ids (policy.rs:67-83) -------------
+        int perm = -1;
+        if (eng.pol.n_perms > 0) {
+            const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_PERM);
+            perm = (int)u32_below(w.x, (uint32_t)eng.pol.n_perms);
+        }
+        int rowoff[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int row = -1;
+            if (i < nc) {
+                const int id = i * nc + (int)big_cell(st.board, i);
+                row = perm >= 0 ? (int)eng.pol.obs_perms16[(size_t)perm * eng.pol.obs_size + id] : id;
+            }
+            rowoff[i] = row;
+        }
+        float lg[4]; float value;
+        eng.forward(rowoff, lg, value);
+        eng.act_perm(perm, lg);
+        const uint32_t mb = (st.zx > 0 ? 1u : 0u) | (st.zy > 0 ? 2u : 0u) | (st.zx < env.width - 1 ? 4u : 0u) | (st.zy < env.height - 1 ? 8u : 0u);   // puzzle.rs:162-165
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[i] = ((mb >> i) & 1u) ? lg[i] : -1e10f;       // policy.rs:62
+        const bool solved = st.board == ident;
+        const float rew = solved ? 1.0f : (st.depth == 0 ? -0.5f : env.r_step);      // puzzle.rs:171-177
+        const u32x4 gw = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_GUMBEL);
+        const int action = gumbel_argmax4(lg, gw);
+        // ---- push the record (ppo.rs:71-76), then is_final / step (ppo.rs:78-79) --------------
+        if (alive) {
+            if (writer) {
+                const uint64_t rec = e_local * (uint64_t)a.out.t_pad + (uint64_t)t;
+                const uint32_t zero4[4] = {0u, 0u, 0u, 0u};
+                store_rec(a.out.rec + rec, zero4, lg, value, rew, action, perm);
+                uint16_t *o = obs16 + rec * (uint64_t)nc;
+                for (int i = 0; i < nc; ++i) o[i] = (uint16_t)(i * nc + (int)big_cell(st.board, i));
+            }
+            if (st.depth == 0 || solved) alive = false;                      // puzzle.rs:167-169
+            else { big_step(st, env, action); ++t; }
+        }
+    }
+    if (valid && writer) a.out.ep_len[e_local] = (uint32_t)t + 1u;
+    eng.end();
+}
+
+// obs ids of the padded trajectories -> the compact result (one wave per episode, grid-stride)
+__global__ void __launch_bounds__(256) compact_obs16_kernel(const uint16_t *obs16, const uint32_t *ep_len, const uint64_t *ep_start, uint64_t E,
+                                                            int t_pad, int n_cells, uint16_t *out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t e = (uint64_t)blockIdx.x * 4 + wave; e < E; e += (uint64_t)gridDim.x * 4) {
+        const uint64_t n = (uint64_t)ep_len[e] * (uint64_t)n_cells;
+        const uint16_t *src = obs16 + e * (uint64_t)t_pad * (uint64_t)n_cells;
+        uint16_t *dst = out + ep_start[e] * (uint64_t)n_cells;
+        for (uint64_t i = lane; i < n; i += 64) dst[i] = src[i];
+    }
+}
+
+int launch_rollout_big(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    // host-side shape checks: everything the kernel indexes with is validated here
+    if (a.env.n_cells <= 16 || a.env.n_cells > BIG_NC || a.env.width * a.env.height != a.env.n_cells || !a.pol.generic ||
+        a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 || (a.pol.n_perms > 0 && !a.pol.obs_perms16) ||
+        a.out.t_pad < a.env.depth0 + 1 || !obs16 || a.queue || a.init_boards) {
+        set_error("rollout (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d generic=%d)", a.env.n_cells, a.pol.obs_size,
+                  a.pol.n_actions, a.pol.generic);
+        return TW_ERR_UNSUPPORTED;
+    }
+    using Eng = EngineV<BIG_NC>;
+    const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
+    if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
+    const size_t lds_bytes = Eng::lds_floats(a.pol.obs_size) * sizeof(float);
+    if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_big_kernel<BIG_NC>), lds_bytes)) return rc;
+    hipLaunchKernelGGL((rollout_big_kernel<BIG_NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a, obs16);
+    TW_HIP(hipGetLastError());
+    if (blocks) *blocks = (uint32_t)nb;
+    if (threads) *threads = Eng::THREADS;
+    return TW_OK;
+}
+
+int launch_compact_obs16(const uint16_t *obs16, const uint32_t *ep_len, const uint64_t *ep_start, uint64_t E, int t_pad, int n_cells,
+                         uint16_t *out, hipStream_t s)
+{
+    if (E == 0) return TW_OK;
+    uint64_t blocks = (E + 3) / 4;
+    if (blocks > 256ull * 16) blocks = 256ull * 16;
+    hipLaunchKernelGGL(compact_obs16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, obs16, ep_len, ep_start, E, t_pad, n_cells, out);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
+}  // namespace tw
