@@ -324,6 +324,9 @@ typedef struct {
                             /* board, same output) instead of a column of a forward (x twists)  */
 } tw_collect_stats;
 int  tw_collected_stats(const tw_collected *c, tw_collect_stats *out);
+/* Releases the result.  Its device memory goes to a per-process pool (freed by tw_release_cached_memory, or when the device
+ * runs out of memory inside the library) and is handed to a later collect, which waits for everything the LIBRARY's stream had
+ * queued before this call.  Work of the caller on other streams that still reads the result must be finished first. */
 void tw_collected_free(tw_collected *c);
 
 /* ---- trainer hand-off (replaces the list -> numpy -> tensor path of PPO.data_to_torch / AZ.data_to_torch,

@@ -11,9 +11,9 @@ Everything below the Python surface is hand-written HIP for gfx950 behind a C AB
 from types import SimpleNamespace as _NS
 
 from . import collector, env, nn  # noqa: F401
-from ._lib import device_count, device_info, library_path  # noqa: F401
+from ._lib import device_count, device_info, library_path, release_cached_memory  # noqa: F401
 
 # mirror of the PyO3 module tree (python_interface/python_bindings.rs:21-77)
 twisterl = _NS(nn=nn, env=env, collector=collector)
 
-__all__ = ["nn", "env", "collector", "twisterl", "device_count", "device_info", "library_path"]
+__all__ = ["nn", "env", "collector", "twisterl", "device_count", "device_info", "library_path", "release_cached_memory"]

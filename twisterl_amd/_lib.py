@@ -242,6 +242,12 @@ def debug_counters(n: int = 16) -> list:
     return [int(x) for x in buf]
 
 
+def release_cached_memory() -> None:
+    """Gives the library's cached device memory (trajectory workspace, pooled result arenas) back to the driver -- e.g. before
+    the trainer needs the GPU's memory for itself, or after a torch out-of-memory error (torch's allocator cannot see it)."""
+    check(lib().tw_release_cached_memory())
+
+
 def device_count() -> int:
     return int(lib().tw_device_count())
 

@@ -126,16 +126,24 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // Result arenas (the compact trajectories a collect hands to its caller) have the same size every iteration of the
 // trainer too: a freed arena goes to a small per-process pool instead of back to the driver (hipMalloc / hipFree of a
 // few GB cost milliseconds each and serialise with every stream).
-struct PooledArena { void *ptr; size_t cap; int device; };
+// hipFree waits for the device; the pool does not.  A released arena therefore carries an event recorded on the library's stream
+// at release, and whoever takes it out of the pool makes its stream wait for that event: work the library itself had queued on
+// the arena (a gather's copies, a pack kernel) is finished before the next collect writes into it.  Consumers on OTHER streams
+// (zero-copy torch tensors on a side stream) must be finished before tw_collected_free -- as they would have to be before a
+// hipFree they do not wait for.
+struct PooledArena { void *ptr; size_t cap; int device; hipEvent_t released; };
 static std::mutex g_pool_mutex;
 static std::vector<PooledArena> g_pool;
 constexpr size_t POOL_ENTRIES = 16;     // (a pipelined multi-GPU step keeps one arena per pipeline step alive until its gather is done)
+constexpr size_t POOL_BYTES = (size_t)48 << 30;      // memory the pool may hold back from other allocators (torch does not see it: tw_release_cached_memory frees it)
+
+static void pool_free(PooledArena &a) { (void)hipFree(a.ptr); if (a.released) (void)hipEventDestroy(a.released); }
 
 static void pool_drop()
 {
     std::vector<PooledArena> drop;
     { std::lock_guard<std::mutex> lock(g_pool_mutex); drop.swap(g_pool); }
-    for (auto &a : drop) (void)hipFree(a.ptr);
+    for (auto &a : drop) pool_free(a);
 }
 
 static int arena_acquire(size_t bytes, void **out, size_t *cap)
@@ -148,8 +156,14 @@ static int arena_acquire(size_t bytes, void **out, size_t *cap)
             if (g_pool[i].device == dev && g_pool[i].cap >= bytes && g_pool[i].cap <= 2 * bytes + (1u << 20) &&
                 (best == g_pool.size() || g_pool[i].cap < g_pool[best].cap)) best = i;
         if (best != g_pool.size()) {
-            *out = g_pool[best].ptr; *cap = g_pool[best].cap;
+            const PooledArena a = g_pool[best];
             g_pool.erase(g_pool.begin() + (long)best);
+            *out = a.ptr; *cap = a.cap;
+            if (a.released) {
+                const hipError_t e = hipStreamWaitEvent(current_stream(), a.released, 0);
+                (void)hipEventDestroy(a.released);
+                if (e != hipSuccess) { (void)hipFree(a.ptr); return hip_fail(e, "hipStreamWaitEvent(pooled arena)", __FILE__, __LINE__); }
+            }
             return TW_OK;
         }
     }
@@ -171,18 +185,28 @@ static int arena_acquire(size_t bytes, void **out, size_t *cap)
 static void arena_release(void *ptr, size_t cap, int device)
 {
     if (!ptr) return;
-    PooledArena victim{nullptr, 0, -1};
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, current_stream()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ev) (void)hipEventDestroy(ev);
+        (void)hipFree(ptr);                          // no fence to hand on: let the driver's own (synchronising) free do it
+        return;
+    }
+    std::vector<PooledArena> victims;
     {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
-        g_pool.push_back(PooledArena{ptr, cap, device});
-        if (g_pool.size() > POOL_ENTRIES) {          // evict the smallest
+        g_pool.push_back(PooledArena{ptr, cap, device, ev});
+        size_t held = 0;
+        for (auto &a : g_pool) held += a.cap;
+        while (g_pool.size() > POOL_ENTRIES || (held > POOL_BYTES && g_pool.size() > 1)) {          // evict the smallest
             size_t v = 0;
             for (size_t i = 1; i < g_pool.size(); ++i) if (g_pool[i].cap < g_pool[v].cap) v = i;
-            victim = g_pool[v];
+            held -= g_pool[v].cap;
+            victims.push_back(g_pool[v]);
             g_pool.erase(g_pool.begin() + (long)v);
         }
     }
-    if (victim.ptr) (void)hipFree(victim.ptr);
+    for (auto &a : victims) pool_free(a);
 }
 
 }  // namespace tw
