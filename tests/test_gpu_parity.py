@@ -414,17 +414,18 @@ def test_policies_of_any_depth(tw, oracle, n2, emb, common, pl, vl, twists):
 
 
 def test_generic_policy_with_more_episodes_than_lanes_uses_the_queue(tw, oracle):
-    """Policies of any depth run 16 episodes per workgroup; with more episodes than one workgroup per CU the lanes are
-    persistent and take the next episode off the queue (as the MFMA shapes do): bit-equal to the oracle, one workgroup per CU."""
+    """Policies of any depth run 16 episodes per workgroup, two workgroups per CU (their activation buffers are as large as the
+    policy's layers, not as the widest policy allowed); with more episodes than that the lanes are persistent and take the next
+    episode off the queue (as the MFMA shapes do): bit-equal to the oracle, two workgroups per CU."""
     import twisterl_amd
     from tests.util import make_deep_policy_arrays
     cus = twisterl_amd.device_info()["compute_units"]
     arrs = make_deep_policy_arrays(9, seed=3, emb=32, common=(48, 32), scale=2.0)
     gp, op = amd_policy(arrs), oracle_policy(oracle, arrs)
     genv, oenv = tw.env.Puzzle(3, 3, 4, 2, 256), oracle.Puzzle(3, 3, 4, 2, 256)
-    E = cus * 16 + 1500
+    E = cus * 32 + 1500
     g = tw.collector.PPOCollector(E, 0.995, 0.995, 32).collect(genv, gp, seed=29)
-    assert (g.stats["rollout_blocks"], g.stats["rollout_threads"]) == (cus, 256)
+    assert (g.stats["rollout_blocks"], g.stats["rollout_threads"]) == (2 * cus, 256)
     o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=29, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8)
     _assert_same_collect(g, o, 9)
 

@@ -528,6 +528,32 @@ tw_policy *create_generic_policy(const tw_policy_desc *d)
     pd.emb_relu = d->emb_apply_relu ? 1 : 0; pd.common_relu = 0;
     pd.emb_rows = reinterpret_cast<const float *>(base + o_emb);
     pd.obs_perms = base + o_op; pd.act_perms = base + o_ap;
+    {   // rows of EngineV's three activation buffers: replay the buffer choices of EngineV::stack() / forward() (tw_engine_generic.hpp)
+        int rows[3] = {(int)E, 0, 0};
+        auto need = [&](int b, uint32_t r) { if ((int)r > rows[b]) rows[b] = (int)r; };
+        auto outp = [&](uint32_t i) { return (uint32_t)(pol->gen_layers[i].nb * pol->gen_layers[i].tb * 16); };
+        auto inp = [&](uint32_t i) { return (uint32_t)(pol->gen_layers[i].kg * 4); };
+        auto run = [&](uint32_t first, uint32_t n, int src, int keep) -> int {
+            int c = src;
+            for (uint32_t l = 0; l < n; ++l) {
+                int dst = 0;
+                while (dst == c || dst == keep) ++dst;
+                need(c, inp(first + l)); need(dst, outp(first + l));
+                c = dst;
+            }
+            return c;
+        };
+        const int co = run(0, d->n_common, 0, -1);
+        if (d->n_value == 1 && d->n_action == 1) {
+            const int vo = co == 0 ? 1 : 0, ao = 3 - co - vo;
+            need(co, inp(d->n_common)); need(co, inp(d->n_common + d->n_action));
+            need(ao, outp(d->n_common)); need(vo, outp(d->n_common + d->n_action));
+        } else {
+            (void)run(d->n_common + d->n_action, d->n_value, co, co);
+            (void)run(d->n_common, d->n_action, co, co);
+        }
+        pd.gen_rows0 = rows[0] > 16 ? rows[0] : 16; pd.gen_rows1 = rows[1] > 16 ? rows[1] : 16; pd.gen_rows2 = rows[2] > 16 ? rows[2] : 16;
+    }
     pd.generic = 1; pd.n_common = (int)d->n_common; pd.n_action = (int)d->n_action; pd.n_value = (int)d->n_value; pd.value_out = (int)vw;
     pd.layers = reinterpret_cast<const LayerDev *>(base + o_tab);
     return pol;
@@ -1145,7 +1171,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     // persistent-lane mode (more episodes than resident lanes): start boards + episode queue
     ra.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
     // (generic policy stacks: one 16-episode workgroup per CU -- rollout_f32_resident_episodes counts 256 per CU)
-    const uint64_t resident = ra.pol.generic ? rollout_f32_resident_episodes(ra.reserve_cus) / 16
+    const uint64_t resident = ra.pol.generic ? rollout_generic_resident_episodes(ra.pol, ra.env.n_cells, ra.reserve_cus)
                             : prm->precision == TW_PREC_F32_EXACT ? f32_resident_episodes(E, (int)ra.pol.hidden, false, ra.reserve_cus)
                                                                   : rollout_f32_resident_episodes(ra.reserve_cus);
     const bool persist = E > resident && !launch_options().no_persist && !big;

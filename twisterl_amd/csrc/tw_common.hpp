@@ -344,6 +344,7 @@ struct PolicyDev {
     const uint8_t *t0S;       // [2*f16_nc KiB]: table tile 0, hi chunks then lo chunks
     // generic stacks (any Sequential depth; EngineV): layers = common | action | value; hidden == 0 marks such a policy
     int32_t generic, n_common, n_action, n_value, value_out;
+    int32_t gen_rows0, gen_rows1, gen_rows2;   // rows ([unit][column]) of EngineV's three activation buffers: the widest layer each one ever holds
     const LayerDev *layers;
     const uint16_t *obs_perms16;   // [n_perms][obs_size] for obs_size > 256 (environments other than Puzzle; the evaluate kernels)
 };
@@ -437,6 +438,7 @@ inline int waves_per_group(uint64_t n)
 
 // kernel launchers (each returns a TW_* status)
 int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+uint64_t rollout_generic_resident_episodes(const PolicyDev &pol, int n_cells, int reserve_cus);   // generic stacks: episodes in flight in the persistent launch
 // boards of 17 .. 25 cells (tw_rollout_big.hip): obs ids as uint16 in their own padded array [E][t_pad][n_cells]
 int launch_rollout_big(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_compact_obs16(const uint16_t *obs16, const uint32_t *ep_len, const uint64_t *ep_start, uint64_t E, int t_pad, int n_cells,

@@ -111,6 +111,7 @@ struct Engine3 {
     static constexpr bool SPLIT = false;
 
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size); }
+    __host__ __device__ static size_t lds_floats(const PolicyDev &p) { return lds_floats(p.obs_size); }
     __device__ __forceinline__ bool primary() const { return true; }           // this wave owns its episodes' stores
     __device__ __forceinline__ int  ep_lane() const { return wave * EPW + j; }  // episode index inside the workgroup
     __device__ __forceinline__ bool owns_lane() const { return true; }          // per-episode serial work (MCTS tree) of lane j runs here
@@ -475,6 +476,7 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
 #endif
 
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER; }
+    __host__ __device__ static size_t lds_floats(const PolicyDev &p) { return lds_floats(p.obs_size); }
     __device__ __forceinline__ bool primary() const { return this->wave == 0; }
     __device__ __forceinline__ int  ep_lane() const { return this->j; }
     // all NS waves carry every episode's state: serial per-episode work is dealt out 32/NS episodes per wave (less divergence,
@@ -767,6 +769,7 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
 #endif
 
     __host__ __device__ static size_t lds_floats(int obs_size) { return engine3_lds_floats<NT>(obs_size) + R3S_XCHG + R3S_USER + (HID_IN_RING ? 0 : NT * 32 * 16); }
+    __host__ __device__ static size_t lds_floats(const PolicyDev &p) { return lds_floats(p.obs_size); }
     __device__ __forceinline__ bool primary() const { return this->wave == 0; }
     __device__ __forceinline__ int  ep_lane() const { return this->j; }
     __device__ __forceinline__ bool owns_lane() const { return this->wave == this->j / (EPB / NS); }
@@ -993,7 +996,8 @@ template <int NT, int NC, int DBG, int NW> struct Geom { using Eng = Engine3<NT,
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -4> { using Eng = Engine3S<NT, NC, 4>; static constexpr int WAVES = 4; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -2> { using Eng = Engine3S<NT, NC, 2>; static constexpr int WAVES = 2; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -16> { using Eng = Engine3T<NT, NC>; static constexpr int WAVES = 4; };   // 16 episodes per workgroup
-template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -64> { using Eng = EngineV<NC>; static constexpr int WAVES = 4; };        // generic stacks on the vector ALU
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -64> { using Eng = EngineV<NC>; static constexpr int WAVES = 4; };        // generic stacks (any Sequential depth)
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -65> { using Eng = EngineV<NC, false>; static constexpr int WAVES = 4; }; // ... two workgroups per CU (256 registers per lane)
 
 // geometry for n episodes: 8 = the throughput shape; below ~3/4 of a chip of 256-episode workgroups the split shape
 template <int NT> inline int geometry_for(uint64_t n)

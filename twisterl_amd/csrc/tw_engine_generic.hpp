@@ -21,7 +21,11 @@ constexpr int GEN_STRIDE = 17;             // floats per unit row of an activati
 typedef float fx4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) fx4 gfx4;
 
-template <int NC>
+// ASM_MFMA: the MFMAs as inline asm with the accumulators pinned to VGPRs (with the intrinsic the allocator shuttles them between VGPRs
+// and AGPRs around every k-group).  Only where a wave may use all 512 registers: capped at 256 (two workgroups per CU) the allocator
+// puts copies of the asm's operands in front of an MFMA it cannot see, without the wait states an MFMA needs after a VALU write --
+// deterministic wrong sums (round 3, 9-cell rollout) -- and with 256 registers there are no AGPRs to shuttle through anyway.
+template <int NC, bool ASM_MFMA = true>
 struct EngineV {
     static constexpr int NW = 4, THREADS = 256, EPB = GEN_COLS, NS = 4;
     static constexpr bool SPLIT = true;
@@ -29,14 +33,22 @@ struct EngineV {
     PolicyDev pol;
     int tid, lane, wave, j, h, g;
     float *lds0, *lds_out, *lds_user;
+    uint64_t boffs;                        // float offsets of the three activation buffers, 21 bits each (one value: selecting among
+                                           // three adjacent members made the compiler index them in memory -- the whole engine went to scratch)
     int *lds_rows;                         // [16 columns][NC] obs ids of the forward (the embedding gather works on other columns than its lane's)
     const uint8_t *perm_obs, *perm_act;
 #ifdef TW_ABLATE
     unsigned long long stq[6] = {0, 0, 0, 0, 0, 0};      // diagnostic build: cycles in embedding | common | value head | action head
 #endif
 
-    // three activation buffers (the common output stays put while the two heads run) | head outputs [16][8] | kernel use
-    __host__ __device__ static size_t lds_floats(int) { return (size_t)3 * GEN_MAX_WIDTH * GEN_STRIDE + GEN_COLS * 8 + 256 + GEN_COLS * NC + 544; }   // (+ 2 KiB of read slack, see layer_tb)
+    // three activation buffers (the common output stays put while the two heads run), each as many rows as the widest layer it
+    // ever holds (PolicyDev::gen_rows, laid out by tw_policy_create with the buffer choices of stack() below): the usual
+    // 256 -> 512 -> 256 policy needs 57 KB instead of the 108 KB of three full-width buffers, and two workgroups share a CU
+    // | head outputs [16][8] | kernel use
+    __host__ __device__ static size_t lds_floats(const PolicyDev &p)
+    {
+        return (size_t)(p.gen_rows0 + p.gen_rows1 + p.gen_rows2) * GEN_STRIDE + GEN_COLS * 8 + 256 + GEN_COLS * NC + 544;   // (+ 2 KiB of read slack, see layer_tb)
+    }
     __device__ __forceinline__ bool primary() const { return wave == 0; }
     __device__ __forceinline__ int  ep_lane() const { return j; }
     __device__ __forceinline__ bool owns_lane() const { return wave == j / (EPB / NS); }
@@ -48,7 +60,8 @@ struct EngineV {
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         j = lane & 15; h = lane >> 4; g = tid >> 4;
         lds0 = lds;
-        lds_out = lds + (size_t)3 * GEN_MAX_WIDTH * GEN_STRIDE;
+        boffs = ((uint64_t)(pol.gen_rows0 * GEN_STRIDE) << 21) | ((uint64_t)((pol.gen_rows0 + pol.gen_rows1) * GEN_STRIDE) << 42);
+        lds_out = lds + (size_t)(pol.gen_rows0 + pol.gen_rows1 + pol.gen_rows2) * GEN_STRIDE;
         lds_user = lds_out + GEN_COLS * 8;
         lds_rows = reinterpret_cast<int *>(lds_user + 256);
         perm_obs = pol.obs_perms; perm_act = pol.act_perms;
@@ -56,7 +69,7 @@ struct EngineV {
     __device__ __forceinline__ void begin2() {}
     __device__ __forceinline__ void end() {}
 
-    __device__ __forceinline__ float *bufp(int i) const { return lds0 + (size_t)i * (GEN_MAX_WIDTH * GEN_STRIDE); }
+    __device__ __forceinline__ float *bufp(int i) const { return lds0 + (size_t)((boffs >> (21 * i)) & 0x1fffffu); }
 
     // obs ids of the board's cells (after the twist); -1 for cells the board does not have
     __device__ __forceinline__ void rows_of(uint64_t board, int n_cells, int perm, int (&rowoff)[NC]) const
@@ -126,7 +139,8 @@ struct EngineV {
                 for (int i = 0; i < PF; ++i) {
 #pragma unroll
                     for (int t = 0; t < TB; ++t) {
-                        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(w[i][t]), "v"(xv[i]));
+                        if constexpr (ASM_MFMA) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(w[i][t]), "v"(xv[i]));
+                        else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t], xv[i], acc[t], 0, 0, 0);
                         if (t == TB - 1) xv[i] = xq[i * (4 * GEN_STRIDE)];            // (after the last MFMA that reads it was issued)
                     }
                     ldw(w[i]);
@@ -137,12 +151,15 @@ struct EngineV {
             for (int i = 0; i < PF; ++i) {
                 if (g0 + i < KG) {
 #pragma unroll
-                    for (int t = 0; t < TB; ++t) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(w[i][t]), "v"(xv[i]));
+                    for (int t = 0; t < TB; ++t) {
+                        if constexpr (ASM_MFMA) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(w[i][t]), "v"(xv[i]));
+                        else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t], xv[i], acc[t], 0, 0, 0);
+                    }
                 }
             }
             // (the MFMAs are inline asm with the accumulators pinned to VGPRs -- with the intrinsic the allocator shuttles them
             //  between VGPRs and AGPRs around every group; the wait states between the last MFMA and the reads below are ours)
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            if constexpr (ASM_MFMA) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             // D row 4kq + r of tile t is output (b * TB + t) * 16 + 4kq + r
 #pragma unroll
             for (int t = 0; t < TB; ++t) {
@@ -209,7 +226,7 @@ struct EngineV {
         int ro[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) ro[i] = lds_rows[col * NC + i];
-        constexpr int QT = NC > 16 ? 1 : 4;            // (boards above 16 cells: QT x NC row quads are in flight per lane)
+        constexpr int QT = NC > 16 ? 1 : (NC > 9 ? 2 : 4);     // QT x NC row quads are in flight per lane: at most 128 registers (two workgroups per CU)
         const int nq = E / 4;
         for (int q0 = ql; q0 < nq; q0 += 16 * QT) {
             int qs[QT];

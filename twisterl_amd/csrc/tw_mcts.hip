@@ -107,7 +107,7 @@ __global__ void __launch_bounds__((Geom<NT, NC, 0, NW>::WAVES * 64), (NW == 8 ? 
     // The search path (root .. current node) with the value_sum / visit_count read on the way down, per owner lane in LDS
     // ([level][episode], three planes): back-propagation then needs no reads at all -- it stores value_sum + v and visit + 1
     // for every level at once instead of chasing parent pointers through HBM (one dependent round trip per level).
-    float    *p_vs  = lds + Eng::lds_floats(a.pol.obs_size) + eng.ep_lane();
+    float    *p_vs  = lds + Eng::lds_floats(a.pol) + eng.ep_lane();
     uint32_t *p_idx = reinterpret_cast<uint32_t *>(p_vs + PATH_DEPTH * Eng::EPB);
     uint32_t *p_vis = p_idx + PATH_DEPTH * Eng::EPB;
     int      plen = 0;
@@ -508,7 +508,7 @@ static int launch_mcts_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
     constexpr int EPB = G::Eng::EPB;
     const uint64_t nb = PERSIST ? rollout_f32_resident_episodes(a.reserve_cus) / (8 * EPW) : (a.num_episodes + EPB - 1) / EPB;   // persistent: one workgroup per CU
     if (nb == 0 || nb > 0x7fffffffull) { set_error("mcts: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = (G::Eng::lds_floats(a.pol.obs_size) + (size_t)3 * PATH_DEPTH * EPB) * sizeof(float);
+    const size_t lds_bytes = (G::Eng::lds_floats(a.pol) + (size_t)3 * PATH_DEPTH * EPB) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("mcts: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_f32_kernel<NT, NC, NW, PERSIST>), lds_bytes)) return rc;
 #ifdef TW_ABLATE

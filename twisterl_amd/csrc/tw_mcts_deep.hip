@@ -134,7 +134,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     const int lane = eng.lane, wave = eng.wave;
     const int col  = eng.ep_lane();                           // this lane's MFMA column in the engine's mapping
     const uint32_t NL = a.lds_nodes;                          // nodes of a tree whose hot quad lives in LDS
-    float *xbase = lds + Eng::lds_floats(a.pol.obs_size);
+    float *xbase = lds + Eng::lds_floats(a.pol);
     uint2 *req = reinterpret_cast<uint2 *>(xbase);                               // request boards [C]
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
     const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
@@ -860,7 +860,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus, a.num_searches) / NWK;
     // the hot quads of the first lds_nodes nodes of every tree live in LDS: as many as fit beside the engine
     MctsArgs b = a;
-    const size_t eng_floats = G::Eng::lds_floats(a.pol.obs_size);
+    const size_t eng_floats = G::Eng::lds_floats(a.pol);
     const size_t budget = (size_t)159 * 1024 / sizeof(float);
     if (eng_floats + deep_extra_floats(C, 0, NWK) > budget) { set_error("mcts (deep): the policy engine alone needs %zu bytes of LDS", eng_floats * 4); return TW_ERR_UNSUPPORTED; }
     size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK)) / ((size_t)NWK * 6);

@@ -57,8 +57,10 @@ int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_
 __device__ unsigned long long g_gen_stamps[8];
 #endif
 
+// (the generic engine's workgroups are small -- 256 threads, exact-size activation buffers: two of them share a CU, and while one
+//  gathers its embeddings from L2 the other one keeps the matrix cores busy)
 template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
-__global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), (NW == 8 ? 2 : 1)) rollout_f32_kernel(const RolloutArgs a)
+__global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), ((NW == 8 || NW == -65) ? 2 : 1)) rollout_f32_kernel(const RolloutArgs a)
 {
     using Eng = typename Geom<NT, NC, DBG, NW>::Eng;       // NW < 0: -NW waves share 32 episodes (Engine3S); all carry the same state
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), (NW == 8 
     if constexpr (!PERSIST) { if (valid && writer) a.out.ep_len[e_local] = (uint32_t)t + 1u; }
     eng.end();
 #ifdef TW_ABLATE
-    if constexpr (NW == -64) {
+    if constexpr (NW == -64 || NW == -65) {
         if (eng.lane == 0 && (eng.wave == 0 || eng.wave == 3)) for (int i = 0; i < 4; ++i) atomicAdd(&g_gen_stamps[(eng.wave ? 4 : 0) + i], eng.stq[i]);
     }
     if constexpr (NW == -16) {      // wave 0: prologue | chunk compute | vmcnt wait | barrier wait | heads
@@ -168,6 +170,14 @@ static uint64_t persist_blocks(int reserve_cus)
 }
 
 uint64_t rollout_f32_resident_episodes(int reserve_cus) { return persist_blocks(reserve_cus) * 8 * EPW; }
+
+// generic policy stacks (EngineV): workgroups of 16 episodes, as many per CU as their LDS allows (at most two: the registers)
+static uint64_t generic_groups_per_cu(const PolicyDev &pol, int n_cells)
+{
+    const size_t lds_bytes = (n_cells <= 4 ? EngineV<4>::lds_floats(pol) : (n_cells <= 9 ? EngineV<9>::lds_floats(pol) : EngineV<16>::lds_floats(pol))) * sizeof(float);
+    return lds_bytes * 2 <= 159 * 1024 ? 2 : 1;
+}
+uint64_t rollout_generic_resident_episodes(const PolicyDev &pol, int n_cells, int reserve_cus) { return persist_blocks(reserve_cus) * generic_groups_per_cu(pol, n_cells) * 16; }
 
 // Episodes are ragged (a solved puzzle ends its episode), and a lane whose episode is over can only be refilled when there
 // are more episodes than lanes.  Between CUs x 32 episodes and 3/4 of CUs x 256 the small-batch shape with the episode
@@ -189,13 +199,13 @@ static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
 {
     using G = Geom<NT, NC, DBG, NW>;
     constexpr int EPB = G::Eng::EPB, THREADS = 64 * G::WAVES;
-    const uint64_t nb = PERSIST ? persist_blocks(a.reserve_cus) : (a.num_episodes + EPB - 1) / EPB;
+    const uint64_t nb = PERSIST ? persist_blocks(a.reserve_cus) * (NW == -65 ? generic_groups_per_cu(a.pol, a.env.n_cells) : 1) : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = G::Eng::lds_floats(a.pol) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
-    const bool stamps = (NW == -64 || NW == -16) && getenv("TW_STAMPS");
+    const bool stamps = (NW == -64 || NW == -65 || NW == -16) && getenv("TW_STAMPS");
     if (stamps) { unsigned long long z[8] = {0}; TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_stamps), z, sizeof(z))); }
     { const char *d = getenv("TW_ENG_DBG"); const int v = d ? atoi(d) : 0; TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eng_dbg), &v, sizeof(v))); }
 #endif
@@ -205,7 +215,7 @@ static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
         unsigned long long g[8];
         TW_HIP(hipStreamSynchronize(s));
         TW_HIP(hipMemcpyFromSymbol(g, HIP_SYMBOL(g_gen_stamps), sizeof(g)));
-        if (NW == -64)
+        if (NW == -64 || NW == -65)
             fprintf(stderr, "[generic engine stamps, cycles summed over %llu workgroups] wave0: embed %llu common %llu value %llu action %llu | wave3: %llu %llu %llu %llu\n",
                     (unsigned long long)nb, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
         else
@@ -270,13 +280,13 @@ int launch_rollout_f32(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
         }
         const int nc = a.env.n_cells;
         if (a.queue) {            // more episodes than one 16-episode workgroup per CU: persistent lanes + episode queue
-            if (nc <= 4) return launch_geom<0, 4, 0, -64, true>(a, s, blocks, threads);
-            if (nc <= 9) return launch_geom<0, 9, 0, -64, true>(a, s, blocks, threads);
-            return launch_geom<0, 16, 0, -64, true>(a, s, blocks, threads);
+            if (nc <= 4) return launch_geom<0, 4, 0, -65, true>(a, s, blocks, threads);
+            if (nc <= 9) return launch_geom<0, 9, 0, -65, true>(a, s, blocks, threads);
+            return launch_geom<0, 16, 0, -65, true>(a, s, blocks, threads);
         }
-        if (nc <= 4) return launch_geom<0, 4, 0, -64>(a, s, blocks, threads);
-        if (nc <= 9) return launch_geom<0, 9, 0, -64>(a, s, blocks, threads);
-        return launch_geom<0, 16, 0, -64>(a, s, blocks, threads);
+        if (nc <= 4) return launch_geom<0, 4, 0, -65>(a, s, blocks, threads);
+        if (nc <= 9) return launch_geom<0, 9, 0, -65>(a, s, blocks, threads);
+        return launch_geom<0, 16, 0, -65>(a, s, blocks, threads);
     }
     // host-side shape checks: everything the kernel indexes with is validated here
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||

@@ -137,7 +137,7 @@ int launch_rollout_big(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uin
     using Eng = EngineV<BIG_NC>;
     const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = Eng::lds_floats(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_big_kernel<BIG_NC>), lds_bytes)) return rc;
     hipLaunchKernelGGL((rollout_big_kernel<BIG_NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a, obs16);

@@ -86,7 +86,7 @@ static int launch_solve_geom(const SolveArgs &a, hipStream_t s)
     constexpr int EPB = G::Eng::EPB;
     const uint64_t nb = (a.num_attempts + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
-    const size_t lds_bytes = G::Eng::lds_floats(a.pol.obs_size) * sizeof(float);
+    const size_t lds_bytes = G::Eng::lds_floats(a.pol) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("solve: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&solve_f32_kernel<NT, NC, NW>), lds_bytes)) return rc;
     hipLaunchKernelGGL((solve_f32_kernel<NT, NC, NW>), dim3((unsigned)nb), dim3(64 * G::WAVES), lds_bytes, s, a);
