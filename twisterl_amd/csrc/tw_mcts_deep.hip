@@ -50,14 +50,15 @@ namespace tw {
 //        every time they are read.  A descent is then a chain of `best` links.  Like `hot`, in LDS for the first `lds_nodes` nodes
 constexpr size_t DEEP_NODE_BYTES = 72;
 size_t mcts_deep_node_bytes() { return DEEP_NODE_BYTES; }
-// Entries of a walker's board-keyed output table: about eight times the nodes one move's searches expand (an episode expands
-// ~0.15 x searches NEW boards per move, CPU count), between 1,024 and 16,384 -- 32 KiB to 512 KiB per walker.  Direct-mapped and
-// overwritten on collision: whatever the table forgets costs a column of a forward, never a bit of the result.
+// Entries of a walker's board-keyed output table: sixteen times the nodes one move's searches expand (an episode expands ~0.15 x
+// searches NEW boards per move, CPU count; measured at 1 / 2 / 4 / 8 / 16 x: 4,096 x 1,000 138 / 133 / 134 / 129 / 127 ms, 64 x 1,000 69.4 /
+// 65.9 / 63.6 / 63.0 / 63.7), between 1,024 and 32,768 -- 32 KiB to 1 MiB per walker.  Direct-mapped and overwritten on collision:
+// whatever the table forgets costs a column of a forward, never a bit of the result.
 uint32_t mcts_deep_table_entries(uint32_t num_searches, uint32_t max_expand_depth)
 {
-    const uint64_t want = 8ull * num_searches * (max_expand_depth ? max_expand_depth : 1u);
+    const uint64_t want = 16ull * num_searches * (max_expand_depth ? max_expand_depth : 1u);
     uint32_t t = 1024;
-    while (t < want && t < 16384u) t <<= 1;
+    while (t < want && t < 32768u) t <<= 1;
     return t;
 }
 
