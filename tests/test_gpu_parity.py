@@ -353,6 +353,19 @@ def test_boards_of_17_to_25_cells_roll_out_on_the_device(tw, oracle):
             assert g.stats["rollout_threads"] == 256 and g.stats["rollout_blocks"] == 10
             o = oracle.ppo_collect(oenv, op, 150, 0.995, 0.995, seed=17, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8, merge_order=merge_order)
             _assert_same_collect(g, o, n2)
+        # evaluate() without MCTS runs on the device as well (solve_big_kernel): 3,000 episodes, best of 2 sampled attempts each, and
+        # the greedy form, against the oracle -- and the same numbers as the host-stepped path
+        for det, ns in ((False, 2), (True, 1)):
+            ge = tw.collector.evaluate(genv, gp, num_episodes=3000, deterministic=det, num_searches=ns, num_mcts_searches=0, seed=7, C=1.41,
+                                       max_expand_depth=1, num_cores=32)
+            oe = oracle.evaluate(oenv, op, 3000, det, ns, seed=7, arith=oracle.ARITH_CHAIN, det_math=True)
+            assert f32_bits(ge[0]) == f32_bits(oe[0]) and f32_bits(ge[1]) == f32_bits(oe[1]), (w, h, det, ge, oe)
+        with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):                  # the host-stepped path (tw_ppo_collect_env)
+            he = tw.collector.evaluate(genv, gp, num_episodes=300, deterministic=False, num_searches=2, num_mcts_searches=0, seed=7, C=1.41,
+                                       max_expand_depth=1, num_cores=32)
+        de = tw.collector.evaluate(genv, gp, num_episodes=300, deterministic=False, num_searches=2, num_mcts_searches=0, seed=7, C=1.41,
+                                   max_expand_depth=1, num_cores=32)
+        assert f32_bits(he[0]) == f32_bits(de[0]) and f32_bits(he[1]) == f32_bits(de[1])
         with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):                  # the host-stepped path (tw_ppo_collect_env)
             hst = coll.collect(genv, gp, seed=17)
         assert hst.stats["rollout_blocks"] != 10

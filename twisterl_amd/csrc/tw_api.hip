@@ -1468,7 +1468,7 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
         hipError_t me = hipMemsetAsync(buf + o_cnt, 0, 128, s);
         if (me != hipSuccess) { (void)hipFree(buf); return hip_fail(me, "hipMemsetAsync(eval counter)", __FILE__, __LINE__); }
         rc = launch_mcts_f32(ma, s, nullptr, nullptr);
-    } else rc = launch_solve_f32(sa, s);
+    } else rc = sa.env.n_cells > 16 ? launch_solve_big(sa, s) : launch_solve_f32(sa, s);
     std::vector<float> hs(A), hr(A); std::vector<uint32_t> hn(A);
     hipError_t e = hipSuccess;
     if (rc == TW_OK) {
@@ -1502,7 +1502,11 @@ extern "C" int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, c
 {
     if (!env || !policy || !prm || !success_rate || !mean_reward) { set_error("tw_evaluate: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
-    if ((uint64_t)env->width * env->height > 16) {                       // boards above 16 cells: the any-environment path (host env)
+    // boards of 17 .. 25 cells without MCTS: on the device (solve_big_kernel); everything else above 16 cells: the any-environment path (host env)
+    const uint64_t cells = (uint64_t)env->width * env->height;
+    const bool big_dev = cells > 16 && cells <= 25 && policy->dev.generic && prm->num_mcts_searches == 0 && prm->precision == TW_PREC_F32_EXACT &&
+                         (uint64_t)env->depth_slope * env->difficulty <= 1022 && env->max_depth != 0 && !launch_options().force_geom;
+    if (cells > 16 && !big_dev) {
         uint64_t depth0 = 0;
         rc = big_board_checks(env, prm->precision, &depth0); if (rc) return rc;
         tw_puzzle *proto = tw_puzzle_create(env->width, env->height, env->difficulty, env->depth_slope, env->max_depth);
@@ -1512,7 +1516,7 @@ extern "C" int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, c
         tw_puzzle_destroy(proto);
         return rc;
     }
-    PuzzleConsts envc; rc = make_env_consts(env, &envc); if (rc) return rc;
+    PuzzleConsts envc; rc = make_env_consts(env, &envc, 25); if (rc) return rc;
     if (num_episodes == 0) { *success_rate = __builtin_nanf(""); *mean_reward = __builtin_nanf(""); return TW_OK; }   // 0/0 (evaluate.rs:52)
     std::vector<float> bs, br; std::vector<uint8_t> acts;
     rc = run_solve(envc, policy, prm, num_episodes, episode_offset, false, nullptr, envc.depth0 + 1, false, bs, br, acts);

@@ -471,6 +471,7 @@ struct SolveArgs {
     int32_t      t_pad;
 };
 int launch_solve_f32(const SolveArgs &a, hipStream_t s);
+int launch_solve_big(const SolveArgs &a, hipStream_t s);       // evaluate() of boards of 17 .. 25 cells (tw_rollout_big.hip)
 
 struct MctsNode;   // tw_mcts.hip
 // MCTS-guided inference (solve.rs:41-47): the MCTS kernel runs single_solve instead of AZ self-play when on != 0

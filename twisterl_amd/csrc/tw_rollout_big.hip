@@ -6,8 +6,9 @@
 // a "generic" policy (tw_policy_create) -- runs on EngineV (tw_engine_generic.hpp: every Linear on the matrix cores, the
 // EmbeddingBag gathered from global memory).  Same path otherwise: PPOCollector::single_collect (collector/ppo.rs:54-80),
 // Policy::forward_with_perm (nn/policy.rs:56-100), sample_from_logits (policy.rs:169-172), Env::step / masks / reward / is_final
-// (puzzle.rs:135-181), same RNG streams, same arithmetic: bit-equal to the oracle.  Boards above 25 cells, self-play and
-// evaluate / solve of boards above 16 cells stay on the host-stepped path (tw_env_generic.hip).
+// (puzzle.rs:135-181), same RNG streams, same arithmetic: bit-equal to the oracle.  evaluate() without MCTS runs here too
+// (solve_big_kernel).  Boards above 25 cells, self-play, solve() from a given state and MCTS-guided evaluate of boards above 16
+// cells stay on the host-stepped path (tw_env_generic.hip).
 #include "tw_engine_generic.hpp"
 
 namespace tw {
@@ -109,6 +110,100 @@ __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a
     }
     if (valid && writer) a.out.ep_len[e_local] = (uint32_t)t + 1u;
     eng.end();
+}
+
+// evaluate() of such a board (rust/src/rl/evaluate.rs:22-89 over single_solve, rl/solve.rs:17-71; tw_solve.hip for boards up to 16
+// cells): one column = one ATTEMPT (episode e, search a): reset, then while !is_final { total += reward; probs = Policy::predict
+// (masked softmax, random twist); action = argmax | weighted sample; step }.  Best-of-N and the means are reduced on the host.
+template <int NC>
+__global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
+{
+    using Eng = EngineV<NC>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Eng eng;
+    eng.begin1(a.pol, lds);
+    const PuzzleConsts env = a.env;
+    const int nc = env.n_cells;
+    const u128 ident = big_ident(nc);
+    const uint64_t att = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)eng.j;
+    const bool valid = att < a.num_attempts, writer = eng.h == 0 && eng.primary();
+    const uint64_t ep  = a.episode_offset + att / a.num_searches;                    // episode: keys the start state
+    const uint64_t key = ep * (uint64_t)a.num_searches + att % a.num_searches;       // keys this attempt's draws
+    BigLane st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;
+    if (valid) {                                                                      // env.reset() per episode (evaluate.rs:39,65)
+        for (int d = 0; d < env.difficulty; ++d) {
+            const u32x4 w = rng_draw(a.seed, ep, (uint32_t)d, STREAM_SCRAMBLE);
+            big_step(st, env, (int)u32_below(w.x, 4u));
+        }
+        st.depth = env.depth0;
+    }
+    bool  alive = valid && !(st.depth == 0 || st.board == ident);
+    float total = 0.0f;
+    int   t = 0;
+    eng.begin2();
+    while (__syncthreads_or(alive ? 1 : 0)) {
+        int perm = -1;
+        if (eng.pol.n_perms > 0) {
+            const u32x4 w = rng_draw(a.seed, key, (uint32_t)t, STREAM_PERM);
+            perm = (int)u32_below(w.x, (uint32_t)eng.pol.n_perms);
+        }
+        int rowoff[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int row = -1;
+            if (i < nc) {
+                const int id = i * nc + (int)big_cell(st.board, i);
+                row = perm >= 0 ? (int)eng.pol.obs_perms16[(size_t)perm * eng.pol.obs_size + id] : id;
+            }
+            rowoff[i] = row;
+        }
+        float lg[4], value;
+        eng.forward(rowoff, lg, value);
+        eng.act_perm(perm, lg);
+        const uint32_t mb = (st.zx > 0 ? 1u : 0u) | (st.zy > 0 ? 2u : 0u) | (st.zx < env.width - 1 ? 4u : 0u) | (st.zy < env.height - 1 ? 8u : 0u);
+        float probs[4];
+        masked_softmax4(lg, mb, probs);                                               // policy.rs:43-47
+        if (alive) {
+            total = total + (st.board == ident ? 1.0f : (st.depth == 0 ? -0.5f : env.r_step));      // solve.rs:31,34
+            int action = 0;
+            if (a.deterministic) {
+                float bv = probs[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) if (probs[i] > bv) { bv = probs[i]; action = i; }
+            } else {
+                const u32x4 w = rng_draw(a.seed, key, (uint32_t)t, STREAM_SOLVE);
+                action = sample_weighted4(probs, 4, u32_to_unit(w.x));
+            }
+            big_step(st, env, action);                                                // solve.rs:56
+            ++t;
+            if (st.depth == 0 || st.board == ident) alive = false;
+        }
+    }
+    if (valid && writer) {
+        total = total + (st.board == ident ? 1.0f : (st.depth == 0 ? -0.5f : env.r_step));          // solve.rs:65-66
+        a.success[att] = st.board == ident ? 1.0f : 0.0f;                             // solve.rs:68
+        a.total[att]   = total;
+        a.n_steps[att] = (uint32_t)t;
+    }
+    eng.end();
+}
+
+int launch_solve_big(const SolveArgs &a, hipStream_t s)
+{
+    if (a.env.n_cells <= 16 || a.env.n_cells > BIG_NC || !a.pol.generic || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
+        (a.pol.n_perms > 0 && !a.pol.obs_perms16) || a.num_searches == 0 || !a.success || !a.total || !a.n_steps || a.actions || a.from_state) {
+        set_error("evaluate (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
+        return TW_ERR_UNSUPPORTED;
+    }
+    using Eng = EngineV<BIG_NC>;
+    const uint64_t nb = (a.num_attempts + Eng::EPB - 1) / Eng::EPB;
+    if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
+    const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
+    if (lds_bytes > 159 * 1024) { set_error("solve: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&solve_big_kernel<BIG_NC>), lds_bytes)) return rc;
+    hipLaunchKernelGGL((solve_big_kernel<BIG_NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
 }
 
 // obs ids of the padded trajectories -> the compact result (one wave per episode, grid-stride)
