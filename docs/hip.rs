@@ -4,7 +4,7 @@
 //
 // *** NOT COMPILED, NOT TESTED: this image has no Rust toolchain (rustc / cargo absent, no network).  The C ABI it binds is
 // *** exercised from compiled C (examples/collect_from_c.c) and from Python (twisterl_amd/_lib.py, the whole test suite);
-// *** struct layouts below are field-for-field copies of include/twisterl_hip.h at ABI version 4.
+// *** struct layouts below are field-for-field copies of include/twisterl_hip.h at ABI version 5 (no struct has changed since 4).
 //
 // What else the reference needs (three small additions, all `pub(crate)`):
 //   rust/build.rs                 println!("cargo:rustc-link-search=native={}", env::var("TWISTERL_HIP_LIB_DIR").unwrap());

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 4
+#define TW_ABI_VERSION 5   /* 5: tw_gather_plan, tw_comm_set_timeout_ms, tw_debug_counters, TW_OPT_AZ_REUSE (no struct changed since 4) */
 
 /* status codes */
 enum {

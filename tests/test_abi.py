@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the ctypes prototype table covers the header exactly
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.tw_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.tw_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_launch_options_are_validated():

@@ -16,7 +16,7 @@ TW_OK, TW_ERR_INVALID, TW_ERR_UNSUPPORTED, TW_ERR_NO_DEVICE, TW_ERR_HIP, TW_ERR_
 TW_PREC_F32_EXACT, TW_PREC_F16, TW_PREC_F16X2 = 0, 1, 2
 TW_EVAL_FORWARD, TW_EVAL_PREDICT, TW_EVAL_FULL_PREDICT = 0, 1, 2
 TW_OPT_FORCE_GEOM, TW_OPT_NO_PERSIST, TW_OPT_AZ_VARIANT, TW_OPT_AZ_TREE_BUDGET, TW_OPT_AZ_TREE_BUDGET_MIN, TW_OPT_AZ_REUSE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 4
+ABI_VERSION = 5
 (TW_F_OBS, TW_F_LOGITS, TW_F_PERMS, TW_F_VALUES, TW_F_REWARDS, TW_F_ACTIONS, TW_F_ADVS, TW_F_RETS,
  TW_F_REMAINING, TW_F_EP_LEN, TW_F_EP_START, TW_F_COUNT) = range(12)
 
