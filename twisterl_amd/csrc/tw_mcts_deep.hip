@@ -872,6 +872,10 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     if (nl > a.node_cap) nl = a.node_cap;
     b.lds_nodes = (uint32_t)nl;
     deep_tree_budgets(&b.tree_budget_min, &b.tree_budget);
+    // (round 3, with the table: minimum 16 / 32 / 48 / 80 / 120 / 200 k cycles -> 4,096 x 100 (eight walkers) 25.3 / 22.4 / 21.2 / 19.9 / 20.2 / 22.7 ms,
+    //  4,096 x 1,000 (four) 125 / 126 / 124 / 124 / 132 / 144, 1,024 x 1,000 80.3 / 80.5 / 81.6 / 84.5 / 88.8 / 98.2: eight walkers share a forward
+    //  of 59 k cycles and wait a little longer for it)
+    if (NWK == 8 && launch_options().az_tree_budget_min == 0 && b.tree_budget > 80000u) b.tree_budget_min = 80000u;
     const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK)) * sizeof(float);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
