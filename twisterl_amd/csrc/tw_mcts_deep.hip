@@ -830,7 +830,7 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     //  1,024 x 1,000 100.5 / 91.3: four as soon as they fill every CU, and always for long searches)
     sh.walkers = num_episodes <= 2 * avail ? 1 : ((2 * num_episodes < 7 * avail && num_searches < 512) ? 2 : 4);
     if (num_searches < 300 && num_episodes > 10 * avail) sh.walkers = 8;     // (with the 80 k budget below: 4,096 x 200 35.1 / 37.7 ms for eight / four, 8,192 x 200 54.8 / 61.7, 4,096 x 400 64.3 / 59.4)
-    //     // (round 3, eight / four walkers, ms: 3,072 x 100 18.9 / 19.2, 4,096 x 100 21.8 / 23.5, 4,096 x 200 37.8 / 37.4, 4,096 x 400 66.2 / 62.1)
+    // (before that budget, eight / four walkers, ms: 3,072 x 100 18.9 / 19.2, 4,096 x 100 21.8 / 23.5, 4,096 x 200 37.8 / 37.4, 4,096 x 400 66.2 / 62.1)
     // (round 3: with the table serving most outputs a forward's look-ahead columns matter less than its cost -- the 16-column forward is
     //  40 k cycles, the 32-column one 59 k: four walkers x 4 columns against four x 8, ms: 4,096 x 1,000 131.6 / 135.0, 2,048 x 1,000 94.1 / 107.3,
     //  1,024 x 1,000 82.0 / 90.0, 2,048 x 100 13.4 / 15.5, 1,024 x 100 11.7 / 13.2; two walkers, 768 x 100: 10.6 / 12.3.  Eight walkers
