@@ -801,7 +801,7 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
     E = 3 * cus
     auto = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
     from twisterl_amd import _lib
-    for variant in (16 + 4, 16 + 3, 16 + 5, 32 + 4, 32 + 3, 32 + 5, 32 + 6):
+    for variant in (16 + 4, 16 + 3, 16 + 5, 16 + 6, 32 + 4, 32 + 3, 32 + 5, 32 + 6):
         with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, variant):
             pinned = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
         for k in auto:

@@ -832,6 +832,22 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
         sv = 2 < n2 ? 2 : 0; av = 1;       // (virtual pair n2 + k is pair k of the next forward)
         set_pointers();
     }
+    // A wave of the workgroup beyond the four engine waves (self-play walkers, tw_mcts_deep.hip): it takes part in begin1 and in a
+    // forward only through the workgroup barriers -- one in begin1, one in the prologue, one per step, two in the heads.
+    __device__ __forceinline__ void begin_idle(const PolicyDev &p)
+    {
+        this->pol = p;
+        this->tid = threadIdx.x; this->lane = this->tid & 63; this->wave = __builtin_amdgcn_readfirstlane(this->tid >> 6);
+        this->j = this->lane & 15; this->h = this->lane >> 4;
+        this->n_chunks = this->pol.emb / KC;
+        np = (this->n_chunks + 1) / 2;
+        n2 = (np + 1) / 2 * 2;
+        __builtin_amdgcn_s_barrier();
+    }
+    __device__ __forceinline__ void idle_forward() const
+    {
+        for (int i = 0; i < n2 + 3; ++i) __builtin_amdgcn_s_barrier();
+    }
     template <int SLOT, int OP = 0>
     __device__ __forceinline__ void stream_pair() const
     {

@@ -833,16 +833,17 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     // (before that budget, eight / four walkers, ms: 3,072 x 100 18.9 / 19.2, 4,096 x 100 21.8 / 23.5, 4,096 x 200 37.8 / 37.4, 4,096 x 400 66.2 / 62.1)
     // (round 3: with the table serving most outputs a forward's look-ahead columns matter less than its cost -- the 16-column forward is
     //  40 k cycles, the 32-column one 59 k: four walkers x 4 columns against four x 8, ms: 4,096 x 1,000 131.6 / 135.0, 2,048 x 1,000 94.1 / 107.3,
-    //  1,024 x 1,000 82.0 / 90.0, 2,048 x 100 13.4 / 15.5, 1,024 x 100 11.7 / 13.2; two walkers, 768 x 100: 10.6 / 12.3.  Eight walkers
-    //  need the 32 columns: 4,096 x 100 21.8 against 23.5 for four x 4)
-    sh.wide = sh.walkers == 8;
+    //  1,024 x 1,000 82.0 / 90.0, 2,048 x 100 13.4 / 15.5, 1,024 x 100 11.7 / 13.2; two walkers, 768 x 100: 10.6 / 12.3.  (Eight walkers seemed to
+    //  need the 32 columns: 4,096 x 100 21.8 against 23.5 for four x 4) -- until the 16-column engine learnt to carry walk-only waves: eight walkers x
+    //  2 columns against eight x 4 on the 32-column engine: 4,096 x 100 19.1 / 19.8 ms, 6,144 x 100 24.8 / 27.9, 16,384 x 100 53.9 / 56.6, 8,192 x 32 14.4 / 14.6
+    sh.wide = false;
     // diagnostic (TW_OPT_AZ_VARIANT): 3 / 4 / 5 pin two / one / four walkers per workgroup, + 16 / + 32 the 16- / 32-column engine
     const int v = launch_options().az_variant;
     if ((v & 7) == 3) sh.walkers = 2;
     if ((v & 7) == 4) sh.walkers = 1;
     if ((v & 7) == 5) sh.walkers = 4;
     if ((v & 7) == 6) { sh.walkers = 8; sh.wide = true; }
-    if ((v & 16) && sh.walkers != 8) sh.wide = false;
+    if (v & 16) sh.wide = false;
     if (v & 32) sh.wide = true;
     if (!(v & 48) && launch_options().force_geom == 32) sh.wide = true;
     return sh;
@@ -914,7 +915,7 @@ static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
     switch (deep_walkers_per_group(a.num_episodes, a.reserve_cus, a.num_searches)) {
         case 1: return launch_deep_nwk<NT, NC, NW, 1>(a, s, blocks, threads);
         case 2: return launch_deep_nwk<NT, NC, NW, 2>(a, s, blocks, threads);
-        case 8: if constexpr (NW == -4) return launch_deep_nwk<NT, NC, NW, 8>(a, s, blocks, threads);     // (32-column engine only)
+        case 8: return launch_deep_nwk<NT, NC, NW, 8>(a, s, blocks, threads);
         default: return launch_deep_nwk<NT, NC, NW, 4>(a, s, blocks, threads);
     }
 }
