@@ -829,7 +829,8 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     // (round 3, ms for two / four walkers: 600 x 100 11.7 / 13.1, 768 x 100 12.7 / 13.1, 900 x 100 13.2 / 13.2, 1,024 x 100 14.1 / 13.1, 768 x 1,000 93.2 / 90.6,
     //  1,024 x 1,000 100.5 / 91.3: four as soon as they fill every CU, and always for long searches)
     sh.walkers = num_episodes <= 2 * avail ? 1 : ((2 * num_episodes < 7 * avail && num_searches < 512) ? 2 : 4);
-    if (num_searches < 300 && num_episodes > 10 * avail) sh.walkers = 8;     // (with the 80 k budget below: 4,096 x 200 35.1 / 37.7 ms for eight / four, 8,192 x 200 54.8 / 61.7, 4,096 x 400 64.3 / 59.4)
+    if (num_searches < 800 && num_episodes > 10 * avail) sh.walkers = 8;     // (eight x 2 columns / four x 4 on the 16-column engine: 4,096 x 400 56.4 / 60.3 ms, x 600 78.6 / 83.3, x 1,000 128.7 / 126.6, 8,192 x 400 78.6 / 98.6)
+    // earlier:     // (with the 80 k budget below: 4,096 x 200 35.1 / 37.7 ms for eight / four, 8,192 x 200 54.8 / 61.7, 4,096 x 400 64.3 / 59.4)
     // (before that budget, eight / four walkers, ms: 3,072 x 100 18.9 / 19.2, 4,096 x 100 21.8 / 23.5, 4,096 x 200 37.8 / 37.4, 4,096 x 400 66.2 / 62.1)
     // (round 3: with the table serving most outputs a forward's look-ahead columns matter less than its cost -- the 16-column forward is
     //  40 k cycles, the 32-column one 59 k: four walkers x 4 columns against four x 8, ms: 4,096 x 1,000 131.6 / 135.0, 2,048 x 1,000 94.1 / 107.3,
