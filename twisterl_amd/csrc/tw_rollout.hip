@@ -60,7 +60,7 @@ __device__ unsigned long long g_gen_stamps[8];
 // (the generic engine's workgroups are small -- 256 threads, exact-size activation buffers: two of them share a CU, and while one
 //  gathers its embeddings from L2 the other one keeps the matrix cores busy)
 template <int NT, int NC, int DBG = 0, int NW = 8, bool PERSIST = false>
-__global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), ((NW == 8 || NW == -65) ? 2 : 1)) rollout_f32_kernel(const RolloutArgs a)
+__global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), ((NW == 8 || NW == -65 || NW == -5) ? 2 : 1)) rollout_f32_kernel(const RolloutArgs a)
 {
     using Eng = typename Geom<NT, NC, DBG, NW>::Eng;       // NW < 0: -NW waves share 32 episodes (Engine3S); all carry the same state
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -88,8 +88,15 @@ __global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), ((NW == 8
 
     eng.begin2();
     // (the barrier inside __syncthreads_or publishes the first two ring slots and the LDS constants)
+#ifdef TW_ABLATE
+    const unsigned long long q_loop = __builtin_readcyclecounter();
+    unsigned long long n_fwd = 0;
+#endif
 
     while (__syncthreads_or(alive ? 1 : 0)) {
+#ifdef TW_ABLATE
+        ++n_fwd;
+#endif
         // ---- observe (puzzle.rs:183-185) + twist of the obs ids (policy.rs:67-83) -------------
         int perm = -1;
         if (eng.pol.n_perms > 0) {
@@ -153,9 +160,10 @@ __global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), ((NW == 8
     if constexpr (NW == -64 || NW == -65) {
         if (eng.lane == 0 && (eng.wave == 0 || eng.wave == 3)) for (int i = 0; i < 4; ++i) atomicAdd(&g_gen_stamps[(eng.wave ? 4 : 0) + i], eng.stq[i]);
     }
-    if constexpr (NW == -16) {      // wave 0: prologue | chunk compute | vmcnt wait | barrier wait | heads
+    if constexpr (NW == -16 || NW == -4 || NW == -5) {      // wave 0: prologue | chunk loop | - | - | heads; forwards; cycles in the step loop
         if (eng.lane == 0 && eng.wave == 0) for (int i = 0; i < 5; ++i) atomicAdd(&g_gen_stamps[i], eng.stq[i]);
-        if (eng.lane == 0 && eng.wave == 0) atomicAdd(&g_gen_stamps[5], (unsigned long long)t + 1ull);
+        if (eng.lane == 0 && eng.wave == 0) atomicAdd(&g_gen_stamps[5], n_fwd);
+        if (eng.lane == 0 && eng.wave == 0) atomicAdd(&g_gen_stamps[6], __builtin_readcyclecounter() - q_loop);
     }
 #endif
 }
@@ -190,7 +198,12 @@ uint64_t f32_resident_episodes(uint64_t num_episodes, int hidden, bool selfplay,
 {
     const uint64_t full = rollout_f32_resident_episodes(reserve_cus), small = full / 8;
     const bool in_range = selfplay ? num_episodes * 4 <= full * 3 : waves_per_group(num_episodes) != 8;
-    if (hidden >= 128 && num_episodes > small && in_range && !launch_options().force_geom) return small;
+    if (hidden >= 128 && num_episodes > small && in_range && !launch_options().force_geom) {
+#ifdef TW_ABLATE   // diagnostic build, TW_MID_G=1: two 32-episode workgroups per CU (Engine3G; measured no faster -- profiles/r03_mid_rollout_two_groups_per_cu.txt)
+        if (!selfplay && num_episodes >= 2 * small && getenv("TW_MID_G")) return 2 * small;
+#endif
+        return small;
+    }
     return full;
 }
 
@@ -199,13 +212,13 @@ static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
 {
     using G = Geom<NT, NC, DBG, NW>;
     constexpr int EPB = G::Eng::EPB, THREADS = 64 * G::WAVES;
-    const uint64_t nb = PERSIST ? persist_blocks(a.reserve_cus) * (NW == -65 ? generic_groups_per_cu(a.pol, a.env.n_cells) : 1) : (a.num_episodes + EPB - 1) / EPB;
+    const uint64_t nb = PERSIST ? persist_blocks(a.reserve_cus) * (NW == -65 ? generic_groups_per_cu(a.pol, a.env.n_cells) : (NW == -5 ? 2 : 1)) : (a.num_episodes + EPB - 1) / EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = G::Eng::lds_floats(a.pol) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_f32_kernel<NT, NC, DBG, NW, PERSIST>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
-    const bool stamps = (NW == -64 || NW == -65 || NW == -16) && getenv("TW_STAMPS");
+    const bool stamps = (NW == -64 || NW == -65 || NW == -16 || NW == -4 || NW == -5) && getenv("TW_STAMPS");
     if (stamps) { unsigned long long z[8] = {0}; TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gen_stamps), z, sizeof(z))); }
     { const char *d = getenv("TW_ENG_DBG"); const int v = d ? atoi(d) : 0; TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_eng_dbg), &v, sizeof(v))); }
 #endif
@@ -219,8 +232,8 @@ static int launch_geom(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, ui
             fprintf(stderr, "[generic engine stamps, cycles summed over %llu workgroups] wave0: embed %llu common %llu value %llu action %llu | wave3: %llu %llu %llu %llu\n",
                     (unsigned long long)nb, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
         else
-            fprintf(stderr, "[16-column engine on %d waves, wave 0, cycles per forward] prologue %.0f chunk loop %.0f heads %.0f\n",
-                    G::WAVES, (double)g[0] / g[5], (double)g[1] / g[5], (double)g[4] / g[5]);
+            fprintf(stderr, "[geometry %d, wave 0, cycles per forward] prologue %.0f chunk loop %.0f heads %.0f | whole step %.0f (%llu forwards)\n",
+                    NW, (double)g[0] / g[5], (double)g[1] / g[5], (double)g[4] / g[5], (double)g[6] / g[5], g[5]);
     }
 #endif
     TW_HIP(hipGetLastError());
@@ -247,7 +260,13 @@ static int launch_one(const RolloutArgs &a, hipStream_t s, uint32_t *blocks, uin
     // small batches: fewer waves per workgroup, so that the episodes spread over more CUs
     const uint64_t resident = f32_resident_episodes(a.num_episodes, a.pol.hidden, false, a.reserve_cus);
     if (a.queue && a.init_boards && a.num_episodes > resident) {
-        if constexpr (NT >= 4) { if (resident < rollout_f32_resident_episodes(a.reserve_cus)) return launch_geom<NT, NC, 0, -4, true>(a, s, blocks, threads); }
+        if constexpr (NT >= 4) {
+            const uint64_t full = rollout_f32_resident_episodes(a.reserve_cus);
+#ifdef TW_ABLATE
+            if (resident == full / 4) return launch_geom<NT, NC, 0, -5, true>(a, s, blocks, threads);
+#endif
+            if (resident < full) return launch_geom<NT, NC, 0, -4, true>(a, s, blocks, threads);
+        }
         return launch_geom<NT, NC, 0, 8, true>(a, s, blocks, threads);
     }
     const int nw = geometry_for<NT>(a.num_episodes);
