@@ -74,14 +74,19 @@ enum { DP_ROOT = 0, DP_LEAF = 1, DP_DEAD = 2 };
 // MctsArgs::tree_budget_min / tree_budget: cycles of tree walk per trip after which a walker stops at the next search boundary
 // -- once another walker of the workgroup waits for a forward (its demand, or the root of a new move) / unconditionally; all
 // its columns then carry frontier nodes.  A waiting walker is not kept waiting for long streaks of stored outputs, and as long
-// as nobody waits no forward is run for look-ahead alone.  Measured (scripts/az_budget_sweep.sh, profiles/r02_az_budget_sweep.txt; ms; fixed budget of
-// 48,000 / 72,000 cycles against min 48,000 + max 300,000): 4,096 x 100 33.0 / 33.3 / 32.3, 2,048 x 100 21.6 / - / 20.7,
-// 256 x 100 10.7 / 9.7 / 9.3, 4,096 x 1,000 244 / 222 / 202, 512 x 1,000 133 / 128 / 117.5; a minimum of 16,000: 35.4, 8,000: 38.5
-// at 4,096 x 100 (the forward costs more than a tree phase: long tree phases amortise it).
+// as nobody waits no forward is run for look-ahead alone: the unconditional budget is off by default (4.29e9 cycles).  It used
+// to be 300,000 cycles (round 2, before the board-keyed table: scripts/az_budget_sweep.sh, profiles/r02_az_budget_sweep.txt); with the
+// table a streak of searches served from it runs for hundreds of thousands of cycles, and stopping it bought a forward whose
+// columns the next demand's forward would have carried anyway (a lone walker: 53 % of its trips were such stops).  Round 3, ms,
+// 300,000 / 1,000,000 / 3,000,000 / never: 64 x 1,000 62.5 / 61.5 / 59.3 / 60.6, 512 x 1,000 73.9 / 70.8 / 70.4 / 70.1; 300,000 / never:
+// 4,096 x 1,000 128.4 / 120.0, 1,024 x 1,000 81.7 / 79.8, 4,096 x 100 19.5 / 19.2, 1,024 x 100 11.6 / 11.5, 512 x 100 9.23 / 8.96, 256 x 100 7.66 / 7.56.
+// The minimum (round 2: fixed budget of 48,000 / 72,000 cycles against min 48,000 + max 300,000: 4,096 x 100 33.0 / 33.3 / 32.3,
+// 256 x 100 10.7 / 9.7 / 9.3, 4,096 x 1,000 244 / 222 / 202; a minimum of 16,000: 35.4, 8,000: 38.5 at 4,096 x 100) stays: the forward
+// costs more than a tree phase, long tree phases amortise it.
 static void deep_tree_budgets(uint32_t *min_cycles, uint32_t *max_cycles)
 {
     const LaunchOptions o = launch_options();                       // diagnostic: TW_OPT_AZ_TREE_BUDGET(_MIN)
-    *max_cycles = o.az_tree_budget > 0 ? (uint32_t)o.az_tree_budget : 300000u;
+    *max_cycles = o.az_tree_budget > 0 ? (uint32_t)o.az_tree_budget : 0xffffffffu;
     *min_cycles = o.az_tree_budget_min > 0 ? (uint32_t)o.az_tree_budget_min : 48000u;
     if (*min_cycles > *max_cycles) *min_cycles = *max_cycles;
 }
@@ -603,7 +608,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 bool need_nn = false;
                 TW_DS(y2);
                 if (!resume) {
-                    if (it != S) {
+                    if (it != S && (NWK > 1 || a.tree_budget != 0xffffffffu)) {         // (a lone walker keeps nobody waiting)
                         const unsigned long long walked = __builtin_readcyclecounter() - tree_t0;
                         bool stop = walked > (unsigned long long)a.tree_budget;
                         if (!stop && walked > (unsigned long long)a.tree_budget_min) {        // somebody waits for a forward: do not keep it waiting
