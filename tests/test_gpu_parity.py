@@ -808,6 +808,30 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
             assert np.array_equal(auto[k], pinned[k]), (variant, k)
 
 
+def test_self_play_takes_the_longest_looking_episodes_first_and_gives_the_same_bytes(tw, oracle):
+    """The walker self-play kernel hands the episodes to its walkers by decreasing distance of the start board from the solved one
+    (launch_episode_order, tw_rollout.hip) -- a schedule, not a result: every episode is keyed by its own index.  Several rounds
+    through the queue, a difficulty that leaves episodes of 1 .. depth-limit moves, one / four / eight walkers per workgroup:
+    bit-identical to the oracle and to the order by index (TW_OPT_AZ_VARIANT + 64)."""
+    import twisterl_amd
+    cus = twisterl_amd.device_info()["compute_units"]
+    gp, op = _pair(oracle, 9, 11, 64, 128, twists=True)
+    genv, oenv = tw.env.Puzzle(3, 3, 4, 2, 256), oracle.Puzzle(3, 3, 4, 2, 256)
+    for E, S, pin in ((5 * cus + 7, 12, 0), (2 * cus - 3, 12, 0), (3 * cus + 1, 12, 6)):
+        coll = tw.collector.AZCollector(num_episodes=E, num_mcts_searches=S, C=1.41, max_expand_depth=1, num_cores=32, seed=31, merge_order=False)
+        with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, pin):
+            g = coll.collect(genv, gp, seed=31).to_numpy()
+        with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, pin + 64):
+            h = coll.collect(genv, gp, seed=31).to_numpy()
+        for k in g:
+            assert np.array_equal(g[k], h[k]), (E, k)
+        assert g["ep_len"].min() < g["ep_len"].max()                  # ragged: the order matters for the schedule
+        o = oracle.az_collect(oenv, op, E, S, 1.41, 1, seed=31, arith=oracle.ARITH_CHAIN, num_threads=16, merge_order=False, det_math=True)
+        assert np.array_equal(g["ep_len"], o.ep_len) and np.array_equal(g["obs"].astype(np.int64), o.obs)
+        assert np.array_equal(f32_bits(g["logits"]), f32_bits(o.logits))
+        assert np.array_equal(f32_bits(g["remaining_values"]), f32_bits(o.additional_data["remaining_values"]))
+
+
 # ------------------------------------------------------------------------------ full-size properties
 def test_full_size_properties_puzzle8_65k(tw, oracle):
     """BASELINE config 2 size (65,536 envs): determinism, replay parity on a sample, GAE parity on

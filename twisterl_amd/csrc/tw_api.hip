@@ -239,7 +239,7 @@ extern "C" int tw_set_launch_option(int option, int value)
             g_force_geom.store(value); return TW_OK;
         case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
         case TW_OPT_AZ_VARIANT:
-            if (value < 0 || (value & 7) > 6 || (value & ~55) != 0 || (value & 48) == 48) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32)", value); return TW_ERR_INVALID; }
+            if (value < 0 || (value & 7) > 6 || (value & ~119) != 0 || (value & 48) == 48) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32) (+ 64)", value); return TW_ERR_INVALID; }
             g_az_variant.store(value); return TW_OK;
         case TW_OPT_AZ_TREE_BUDGET:
             if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }
@@ -1300,7 +1300,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(136), o_scan = seg(scan_scratch_bytes(E)),
                  o_arena = seg(deep ? arenas * mcts_deep_arena_bytes(cap64) : arenas * cap64 * mcts_node_bytes()),
-                 o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0);
+                 o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0), o_order = seg(deep ? E * 4 : 0);
     const uint32_t tbl_entries = deep ? mcts_deep_table_entries(ma.num_searches, ma.max_expand_depth) : 0;
     const size_t tbl_bytes = (size_t)arenas * tbl_entries * 32;
     const size_t o_tbl = seg(tbl_bytes);
@@ -1339,6 +1339,14 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
         TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
         rc = launch_init_boards(ma.env, ma.seed, ma.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
         if (rc) return rc;
+        // walker kernel: longest-looking episodes first (diagnostic, TW_OPT_AZ_VARIANT + 64: by index).  (The lane-per-episode kernel's
+        // queue gains nothing from it: 16,384 x 100 71.5 against 75.3 ms, but 262,144 x 32 186.9 against 182.2, 32,768 x 32 47.1 against 46.0)
+        if (deep && !(launch_options().az_variant & 64)) {
+            rc = launch_episode_order(ma.env, ma.init_boards, E, reinterpret_cast<uint32_t *>(ws + o_order), s);
+            if (rc) return rc;
+            ma.order = reinterpret_cast<const uint32_t *>(ws + o_order);
+            ma.order_across = 1;
+        }
     }
     TW_HIP(hipEventRecord(ev.ev[0], s));
     rc = deep ? launch_mcts_deep(ma, s, &st.rollout_blocks, &st.rollout_threads)

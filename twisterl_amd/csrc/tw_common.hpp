@@ -444,6 +444,9 @@ int launch_rollout_big(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uin
 int launch_compact_obs16(const uint16_t *obs16, const uint32_t *ep_len, const uint64_t *ep_start, uint64_t E, int t_pad, int n_cells,
                          uint16_t *out, hipStream_t s);
 int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s);
+// episodes by decreasing distance of their start board from the solved one (sum of the tiles' Manhattan distances): the order the
+// self-play walkers take them in -- the episodes that are likely to run to the depth limit start first (tw_rollout.hip)
+int launch_episode_order(const PuzzleConsts &env, const uint64_t *boards, uint64_t n, uint32_t *order, hipStream_t s);
 uint64_t rollout_f32_resident_episodes(int reserve_cus = 0);   // episodes the f32 rollout keeps resident at once (persistent mode above that)
 // Lanes the exact-f32 kernels (rollout, self-play) keep resident for a batch: episodes beyond that wait in the queue of the
 // persistent-lane mode.  CUs x 256 for the 256-episode shape; between CUs x 32 and 3/4 of that the small-batch shape
@@ -507,6 +510,8 @@ struct MctsArgs {
     void           *tbl;               // deep shape: board-keyed output tables, [walkers][tbl_entries][32 bytes], zeroed before the launch
     uint32_t        tbl_entries;       // ... entries per walker (a power of two)
     uint32_t        reuse_mode;        // lane-per-episode kernel: how a node that takes its parent's move back finds its grandparent's output (TW_OPT_AZ_REUSE)
+    const uint32_t *order;             // deep shape: the order in which the walkers take the episodes (launch_episode_order), or null = by index
+    uint32_t        order_across;      // ... the first ones dealt out across the workgroups (walker w of workgroup b: number w * workgroups + b) instead of in a row
 };
 size_t mcts_node_bytes();
 // the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue

@@ -231,7 +231,11 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
         t = 0; phase = DP_ROOT;
     };
-    if (walker && slot < E) take(slot);
+    // The walkers take the episodes in MctsArgs::order, the ones that look longest first; MctsArgs::order_across: dealt out ACROSS
+    // the workgroups at launch (walker w of workgroup b starts with number w * workgroups + b), from the queue afterwards.
+    auto nth = [&](uint64_t q) -> uint64_t { return a.order ? (uint64_t)uniu(a.order[q]) : q; };
+    const uint64_t first = (a.order && a.order_across) ? (uint64_t)(walker ? wave : 0) * gridDim.x + blockIdx.x : slot;
+    if (walker && first < E) take(nth(first));
     if (walker && lane < DEEP_POOL) pidx[lane] = DNONE;
     if (!walker) more = false;
     if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[TWV + wave] = phase != DP_DEAD ? 1 : 0; wait_f[wave] = 0; if (wave + 4 < 8) wait_f[wave + 4] = 0; }
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                                 if (lane == 0) got = atomicAdd(a.queue, 1u);
                                 got = (unsigned)uni((int)got);
                             }
-                            if ((uint64_t)got < E) take((uint64_t)got);
+                            if ((uint64_t)got < E) take(nth((uint64_t)got));
                             else { more = false; phase = DP_DEAD; }
                             TW_DS(y9); TW_DA(c_fin, y2, y9);
                             break;

@@ -53,6 +53,77 @@ int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_
     return TW_OK;
 }
 
+// Longest-first order for the self-play episode queue.  A collect is as long as its longest episode's chain of searches plus
+// the time that episode waited for a walker; episodes that are not solved run to the depth limit (17 moves against a mean of 5 at
+// difficulty 8), and the boards far from the solved one are the ones that are not solved.  Key = sum over the tiles of the Manhattan
+// distance to their place (a lower bound of the moves needed), counting sort by decreasing key; one workgroup, microseconds.
+// Which walker runs which episode never changes a bit of the result (every episode is keyed by its own global index).
+__device__ __forceinline__ bool rank_is_leader(unsigned long long peers, int lane) { return (peers & ((1ull << lane) - 1ull)) == 0ull; }
+__global__ void __launch_bounds__(1024) episode_order_kernel(const PuzzleConsts env, const uint64_t *boards, uint32_t n, uint32_t *order)
+{
+    // a STABLE counting sort (equal keys stay in index order: the schedule, and with it the collect's time, is the same every
+    // run): wave w owns the indices [w * span, (w + 1) * span), counts them, and scatters them in order from its own cursors
+    constexpr int WAVES = 16;
+    __shared__ uint32_t cnt[WAVES][64], cur[WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < WAVES * 64; i += 1024) (&cnt[0][0])[i] = 0;
+    uint64_t lutx = 0, luty = 0;                                // place of tile v in the solved board, one nibble each
+    for (int i = 0; i < env.n_cells; ++i) {
+        const uint64_t v = nib(env.ident, i);
+        lutx |= (uint64_t)(i % env.width) << (4 * v); luty |= (uint64_t)(i / env.width) << (4 * v);
+    }
+    auto key = [&](uint64_t b) -> uint32_t {
+        int d = 0;
+        for (int i = 0; i < env.n_cells; ++i) {
+            const uint64_t v = nib(b, i);
+            if (v == 0) continue;                               // the blank
+            const int dx = i % env.width - (int)((lutx >> (4 * v)) & 15), dy = i / env.width - (int)((luty >> (4 * v)) & 15);
+            d += (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
+        }
+        return (uint32_t)(d < 63 ? d : 63);
+    };
+    const uint32_t span = ((n + WAVES - 1) / WAVES + 63u) & ~63u;
+    const uint32_t lo = (uint32_t)wave * span, hi = lo + span < n ? lo + span : n;
+    __syncthreads();
+    for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[wave][key(boards[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {                                     // key k: after every larger key, wave by wave
+        uint32_t pos = 0;
+        for (int k = 63; k > (int)threadIdx.x; --k) for (int w = 0; w < WAVES; ++w) pos += cnt[w][k];
+        for (int w = 0; w < WAVES; ++w) { cur[w][threadIdx.x] = pos; pos += cnt[w][threadIdx.x]; }
+    }
+    __syncthreads();
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {                 // (wave-uniform trip count)
+        const uint32_t i = i0 + lane;
+        const bool on = i < hi;
+        const uint32_t k = on ? key(boards[i]) : 64u;
+        unsigned long long peers = __builtin_amdgcn_ballot_w64(on);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(on && ((k >> b) & 1u));
+            peers &= ((k >> b) & 1u) ? m : ~m;
+        }
+        if (on) {
+            const uint32_t rank = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
+            order[cur[wave][k] + rank] = i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (on && rank_is_leader(peers, lane)) cur[wave][k] += (uint32_t)__builtin_popcountll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+int launch_episode_order(const PuzzleConsts &env, const uint64_t *boards, uint64_t n, uint32_t *order, hipStream_t s)
+{
+    if (n == 0) return TW_OK;
+    if (n > 0xffffffffull || env.n_cells < 1 || env.n_cells > 16) { set_error("episode order: unsupported shape"); return TW_ERR_INVALID; }
+    hipLaunchKernelGGL(episode_order_kernel, dim3(1), dim3(1024), 0, s, env, boards, (uint32_t)n, order);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
 #ifdef TW_ABLATE   // diagnostic build: cycle stamps of the generic engine (TW_STAMPS=1 prints them per launch)
 __device__ unsigned long long g_gen_stamps[8];
 #endif
