@@ -103,10 +103,13 @@ def side_configs(twisterl, torch):
     """BASELINE.json configs 1, 2 and 5 at full size, N = 1 only: Puzzle-8 PPO rollouts (1,024 envs exact f32 = config 1's batch on
     the GPU; 65,536 envs with the f16-input forward = config 2), AlphaZero self-play on Puzzle-15 at the reference's per-GPU batch
     (4,096 episodes x 100 and x 1,000 searches, src/twisterl/defaults.py:84-91) and at the reference's default (512 x 1,000).
-    Median of three collects each after one warm-up; every entry carries its own roofline fraction."""
+    PPO entries: the median of three collects after one warm-up.  Self-play entries: the three collects TOGETHER (evaluations of
+    all three / time of all three, as the headline sums its steps): a self-play collect is as long as its longest episode's chain
+    of searches whatever the batch holds, while the evaluations it counts follow the batch's total number of moves -- one seed's
+    rate moves by +- 8 %.  Every entry carries its own roofline fraction."""
     out = {}
 
-    def timed(c, env, pol):
+    def timed(c, env, pol, together=False):
         c.collect(env, pol, seed=1)
         rs = []
         for i in range(3):
@@ -116,7 +119,7 @@ def side_configs(twisterl, torch):
             rs.append((time.perf_counter() - t1, len(d), dict(d.stats)))
             del d
         rs.sort(key=lambda r: r[0])
-        return rs[1]
+        return rs[1] if not together else rs
 
     try:
         arrs8 = synthetic_weights(9, seed=0)
@@ -138,13 +141,17 @@ def side_configs(twisterl, torch):
         env = twisterl.env.Puzzle(4, 4, 8, 2, 256)
         for key, E, S in (("config5_az_4096x100", 4096, 100), ("config5_az_4096x1000", 4096, 1000), ("config5_az_512x1000_reference_default", 512, 1000)):
             c = twisterl.collector.AZCollector(E, S, 1.41, 1, 32)
-            dt1, n, st = timed(c, env, pol)
-            k = st["ms_rollout"] * 1e-3
-            consumed, fwd_only = st["forward_evals"], st["forward_evals"] - st["reused_evals"]
+            rs = timed(c, env, pol, together=True)
+            dt1 = sum(r[0] for r in rs); n = sum(r[1] for r in rs)
+            k = sum(r[2]["ms_rollout"] for r in rs) * 1e-3
+            consumed = sum(r[2]["forward_evals"] for r in rs); reused = sum(r[2]["reused_evals"] for r in rs)
+            fwd_only = consumed - reused
             tf = consumed * FLOP_PER_RECORD[16] / k / 1e12
+            st = rs[1][2]
             out[key] = {"value": consumed / dt1, "unit": "leaf evaluations/s (Policy::full_predict calls the searches consume = what the reference evaluates)",
-                        "ms_per_step": dt1 * 1e3, "kernel_ms": k * 1e3, "records": n, "episodes": E, "searches": S,
-                        "forward_evals": consumed, "reused_evals": st["reused_evals"], "speculative_evals": st["speculative_evals"],
+                        "ms_per_step": dt1 * 1e3 / len(rs), "kernel_ms": k * 1e3 / len(rs), "collects": len(rs), "records": n, "episodes": E, "searches": S,
+                        "forward_evals": consumed, "reused_evals": reused, "speculative_evals": sum(r[2]["speculative_evals"] for r in rs),
+                        "per_collect": [{"ms": round(r[0] * 1e3, 3), "forward_evals": r[2]["forward_evals"]} for r in rs],
                         "launch": [st["rollout_blocks"], st["rollout_threads"]],
                         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["fp32"],
                                      "frac_outputs_of_a_forward_only": fwd_only * FLOP_PER_RECORD[16] / k / 1e12 / PEAK_TFLOPS["fp32"]}}

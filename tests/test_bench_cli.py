@@ -88,6 +88,9 @@ def test_side_config_schema():
         assert {"value", "unit", "ms_per_step", "kernel_ms", "records", "roofline"} <= set(v), k
         assert {"bound", "achieved", "peak", "unit", "frac"} <= set(v["roofline"]) and 0 < v["roofline"]["frac"]
         if k.startswith("config5"):
-            assert {"forward_evals", "reused_evals", "episodes", "searches", "launch"} <= set(v)
+            assert {"forward_evals", "reused_evals", "episodes", "searches", "launch", "collects", "per_collect"} <= set(v)
+            # the three collects together: evaluations of all three over the time of all three
+            assert v["collects"] == 3 and v["forward_evals"] == 3 * 40 * v["episodes"] and v["records"] == 3 * 10 * v["episodes"]
+            assert abs(v["kernel_ms"] - 1.0) < 1e-9 and len(v["per_collect"]) == 3
             assert v["roofline"]["frac_outputs_of_a_forward_only"] < v["roofline"]["frac"]
     json.dumps(out)

@@ -465,7 +465,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 const uint32_t cnt = (uint32_t)__builtin_popcount(act_mask);
                 const uint32_t pos = (uint32_t)__builtin_popcount(act_mask & ((1u << ca) - 1u));
                 PuzzleLane c = s;
-                puzzle_step(c, env, ca);
+                puzzle_step_legal(c, env, ca);                                // (a child exists only for a legal move: prior > 0; the other lanes' result is not used)
                 if (has && lane < 4) {
                     const uint32_t ni = n_nodes + pos;
                     const uint32_t undo = (idx != 0u && (uint32_t)ca == (((idx_link >> 27) & 3u) ^ 2u)) ? LK_UNDO : 0u;   // 0 left, 1 up, 2 right, 3 down
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 for (int x = 0; x < 4; ++x) if ((act_mask >> x) & 1u) { if (seen == k) act = x; ++seen; }
                 const uint32_t undo = (node != 0u && (uint32_t)act == (((cur_link >> 27) & 3u) ^ 2u)) ? LK_UNDO : 0u;
                 node = cb + (uint32_t)k;
-                puzzle_step(cur, env, act);
+                puzzle_step_legal(cur, env, act);                             // (the sampled child exists: its move is legal)
                 cur_link = ((uint32_t)act << 27) | undo;
                 push(node);
             };
