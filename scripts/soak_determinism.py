@@ -43,9 +43,11 @@ for E, rep in ((1024, 4 * n), (4096, 4 * n), (8000, 2 * n), (20000, 2 * n)):
             elif dg != ref: bad += 1
         print("fp32 small E", E, "difficulty", env.difficulty, "repeats", rep, "mismatching repeats", bad, flush=True)
 # (walker kernel: 256 episodes = one walker per workgroup, 800 / 1,024 two, 2,000 four on the 32-column engine, 4,096 and 6,000 x 100
-#  eight in eight-wave workgroups; 20,000 and 70,000: lane-per-episode kernel)
+#  eight in eight-wave workgroups, 512 x 1,000 lone walkers on long streaks of searches, 1,100 x 400 four walkers + the episode queue in
+#  longest-first order; 20,000 and 70,000: lane-per-episode kernel)
 for E, S, rep, p in ((256, 60, n, pol0), (800, 40, n, pol), (1024, 50, n, pol0), (2000, 40, n, pol), (4096, 30, n, pol0), (4096, 100, n, pol),
-                     (6000, 100, max(2, n // 2), pol0), (20000, 16, n, pol0), (70000, 8, max(2, n // 3), pol0)):
+                     (6000, 100, max(2, n // 2), pol0), (512, 1000, max(2, n // 4), pol0), (1100, 400, max(2, n // 4), pol0),
+                     (20000, 16, n, pol0), (70000, 8, max(2, n // 3), pol0)):
     env = twisterl.env.Puzzle(4, 4, 4 if S < 100 else 8, 2, 256)
     coll = twisterl.collector.AZCollector(E, S, 1.41, 1, 1)
     ref = None; bad = 0
