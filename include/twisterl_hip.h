@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 5   /* 5: tw_gather_plan, tw_comm_set_timeout_ms, tw_debug_counters, TW_OPT_AZ_REUSE (no struct changed since 4) */
+#define TW_ABI_VERSION 5   /* 5: tw_gather_plan, tw_comm_set_timeout_ms, tw_debug_counters, tw_debug_episode_order, TW_OPT_AZ_REUSE (no struct changed since 4) */
 
 /* status codes */
 enum {
@@ -98,6 +98,10 @@ int tw_debug_counters(uint64_t *out, int n);
 typedef struct {
     uint32_t width, height, difficulty, depth_slope, max_depth;
 } tw_puzzle_desc;
+/* Test hook: start boards (nibble i = tile at cell i; Env::reset of episode episode_offset + i, puzzle.rs:119-133) and the order in
+   which the self-play walkers take the episodes (decreasing sum of the tiles' Manhattan distances, ties by index), as tw_az_collect
+   computes them on the device; boards_out[n], order_out[n] on the host.  Boards of up to 16 cells. */
+int tw_debug_episode_order(const tw_puzzle_desc *env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *boards_out, uint32_t *order_out);
 
 typedef struct tw_puzzle tw_puzzle;
 

@@ -808,6 +808,31 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
             assert np.array_equal(auto[k], pinned[k]), (variant, k)
 
 
+def test_episode_order_is_a_stable_sort_by_manhattan_distance(tw, oracle):
+    """launch_episode_order (tw_rollout.hip) through the test hook tw_debug_episode_order: the start boards are the ones the
+    collectors play (first record of every self-play episode), the order is a permutation sorted by decreasing sum of the tiles'
+    Manhattan distances to their places, ties in index order -- for ragged sizes around the kernel's 16 x 64-lane spans."""
+    gp, _ = _pair(oracle, 16, 2, 32, 128)
+    for (w, h, diff), n in (((4, 4, 8), 4096), ((4, 4, 8), 1), ((4, 4, 8), 63), ((4, 4, 8), 1025), ((3, 3, 5), 777), ((4, 3, 30), 20_000), ((2, 2, 3), 130)):
+        env = tw.env.Puzzle(w, h, diff, 2, 256)
+        boards, order = _lib.debug_episode_order(env._desc(), 41, 5, n)
+        assert sorted(order.tolist()) == list(range(n))
+        cells = w * h
+        tiles = np.stack([(boards >> np.uint64(4 * i)) & np.uint64(15) for i in range(cells)], axis=1).astype(np.int64)     # [n][cell]
+        assert np.all(np.sort(tiles, axis=1) == np.arange(cells))
+        px = np.arange(cells) % w; py = np.arange(cells) // w     # the solved board holds tile v at cell v (the blank, 0, at cell 0)
+        ci = np.arange(cells)
+        d = (np.abs(ci % w - px[tiles]) + np.abs(ci // w - py[tiles])) * (tiles != 0)
+        key = np.minimum(d.sum(axis=1), 63)
+        want = np.argsort(-key, kind="stable")
+        assert np.array_equal(order.astype(np.int64), want), (w, h, n)
+        if cells == 16 and n == 4096:                               # the boards are the collectors' start boards
+            g = tw.collector.AZCollector(num_episodes=300, num_mcts_searches=2, C=1.41, max_expand_depth=1, num_cores=1, seed=41, episode_offset=5,
+                                         merge_order=False).collect(env, gp, seed=41).to_numpy()
+            first = g["obs"][g["ep_start"].astype(np.int64)].astype(np.int64)
+            assert np.array_equal(first, tiles[:300] + 16 * ci)
+
+
 def test_self_play_takes_the_longest_looking_episodes_first_and_gives_the_same_bytes(tw, oracle):
     """The walker self-play kernel hands the episodes to its walkers by decreasing distance of the start board from the solved one
     (launch_episode_order, tw_rollout.hip) -- a schedule, not a result: every episode is keyed by its own index.  Several rounds

@@ -102,6 +102,7 @@ SYMBOLS = {
     "tw_release_cached_memory": (C.c_int, []),
     "tw_set_launch_option": (C.c_int, [C.c_int, C.c_int]),
     "tw_debug_counters": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
+    "tw_debug_episode_order": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "tw_puzzle_create": (_VP, [C.c_uint32] * 5),
     "tw_puzzle_clone": (_VP, [_VP]),
     "tw_puzzle_destroy": (None, [_VP]),
@@ -240,6 +241,16 @@ def debug_counters(n: int = 16) -> list:
     buf = (C.c_uint64 * n)()
     check(lib().tw_debug_counters(buf, n))
     return [int(x) for x in buf]
+
+
+def debug_episode_order(desc, seed: int, episode_offset: int, n: int):
+    """Start boards (uint64, nibble i = tile at cell i) of n Puzzle episodes and the order in which the self-play walkers take them
+    (tw_debug_episode_order; test hook).  `desc`: a PuzzleDesc."""
+    import numpy as np
+    boards = np.zeros(n, dtype=np.uint64); order = np.zeros(n, dtype=np.uint32)
+    check(lib().tw_debug_episode_order(C.byref(desc), seed, episode_offset, n, boards.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       order.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return boards, order
 
 
 def release_cached_memory() -> None:

@@ -1084,6 +1084,29 @@ int make_env_consts(const tw_puzzle_desc *env, PuzzleConsts *out, uint64_t max_c
 
 }  // namespace
 
+// test hook: the start boards of episodes [episode_offset, episode_offset + n) and the order the self-play walkers take them in
+// (init_boards_kernel + episode_order_kernel, exactly as tw_az_collect launches them), copied to the host
+extern "C" int tw_debug_episode_order(const tw_puzzle_desc *env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *boards_out, uint32_t *order_out)
+{
+    if (!env || !boards_out || !order_out) { set_error("tw_debug_episode_order: null argument"); return TW_ERR_INVALID; }
+    if (n == 0 || n > (1ull << 24)) { set_error("tw_debug_episode_order: n = %llu out of range", (unsigned long long)n); return TW_ERR_INVALID; }
+    int rc = require_device(); if (rc) return rc;
+    PuzzleConsts envc; rc = make_env_consts(env, &envc, 16); if (rc) return rc;
+    hipStream_t s = current_stream();
+    void *buf = nullptr;
+    TW_HIP(hipMalloc(&buf, n * 12));
+    uint64_t *b = reinterpret_cast<uint64_t *>(buf); uint32_t *o = reinterpret_cast<uint32_t *>(b + n);
+    rc = launch_init_boards(envc, seed, episode_offset, n, b, s);
+    if (!rc) rc = launch_episode_order(envc, b, n, o, s);
+    hipError_t e = rc ? hipSuccess : hipMemcpyAsync(boards_out, b, n * 8, hipMemcpyDeviceToHost, s);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(order_out, o, n * 4, hipMemcpyDeviceToHost, s);
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(buf);
+    if (rc) return rc;
+    TW_HIP(e);
+    return TW_OK;
+}
+
 // Boards above 16 cells (puzzle.rs:34-42 takes any width x height; the kernels pack a board as 16 nibbles): the Puzzle steps
 // on the host through the any-environment collectors (tw_env_generic.hip) -- same RNG spec, same arithmetic, the policy
 // evaluations of a moment in one batched launch.  f32; evaluate / solve of such boards are not implemented.
