@@ -309,9 +309,9 @@ def test_ppo_collect_of_boards_above_16_cells(tw, oracle, w, h, diff, emb, commo
     assert genv.get_state() == before
 
 
-def test_boards_of_17_to_25_cells_roll_out_on_the_device(tw, oracle):
-    """5 x 5 (and 6 x 4) PPO collects run the device kernel of tw_rollout_big.hip -- 5-bit cells in a 128-bit register, two-byte obs
-    ids, the generic engine -- not the host-stepped path: 65,536 envs of a 5 x 5 board in 4,096 workgroups of 256 threads, sampled
+def test_boards_of_17_to_64_cells_roll_out_on_the_device(tw, oracle):
+    """5 x 5 (and 6 x 4, 6 x 6, 7 x 5, 8 x 8) PPO collects run the device kernel of tw_rollout_big.hip -- 5-bit cells in a 128-bit register up
+    to 25 cells, one byte per cell in 9 / 16 registers up to 36 / 64, two-byte obs ids, the generic engine -- not the host-stepped path: 65,536 envs of a 5 x 5 board in 4,096 workgroups of 256 threads, sampled
     episodes bit-equal to the oracle on every field (the RNG is keyed by the global episode index); a small batch with the
     transpose twist compared whole, in both orders; and the same bytes as the host-stepped path (pinned through TW_OPT_FORCE_GEOM)."""
     from tests.util import make_deep_policy_arrays
@@ -340,7 +340,7 @@ def test_boards_of_17_to_25_cells_roll_out_on_the_device(tw, oracle):
         for k, ok in (("logits", o.logits), ("values", o.values), ("rewards", o.rewards), ("advs", o.additional_data["advs"]), ("rets", o.additional_data["rets"])):
             assert np.array_equal(f32_bits(a[k][s:s + ln]), f32_bits(ok)), (e, k)
     del a, g
-    for (w, h, twists) in ((5, 5, True), (6, 4, False)):
+    for (w, h, twists) in ((5, 5, True), (6, 4, False), (6, 6, True), (7, 5, False), (8, 8, True)):
         n2 = w * h
         arrs = make_deep_policy_arrays(n2, seed=6, emb=32, common=(64, 32), scale=2.0)
         op_, ap_ = puzzle_transpose_twist(w) if twists else ((), ())

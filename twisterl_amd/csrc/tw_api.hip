@@ -1163,16 +1163,16 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     if (prm->precision > TW_PREC_F16X2) { set_error("tw_ppo_collect: unknown precision %u", prm->precision); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
 
-    // boards of 17 .. 25 cells roll out on the device too (tw_rollout_big.hip: 5-bit cells, two-byte obs ids, the generic engine);
-    // larger ones -- and whatever that kernel does not take -- step on the host (tw_env_generic.hip)
+    // boards of 17 .. 64 cells roll out on the device too (tw_rollout_big.hip: 5-bit or one-byte cells, two-byte obs ids, the generic
+    // engine); whatever that kernel does not take steps on the host (tw_env_generic.hip)
     const uint64_t cells = (uint64_t)env->width * env->height;
     const bool big = cells > 16;
-    if (big && !(cells <= 25 && policy->dev.generic && prm->precision == TW_PREC_F32_EXACT && (uint64_t)env->depth_slope * env->difficulty <= 1022 &&
+    if (big && !(cells <= 64 && policy->dev.generic && prm->precision == TW_PREC_F32_EXACT && (uint64_t)env->depth_slope * env->difficulty <= 1022 &&
                  env->max_depth != 0 && !launch_options().force_geom))
         return collect_big_board(env, policy, prm, nullptr, out);
 
     RolloutArgs ra{};
-    rc = make_env_consts(env, &ra.env, 25); if (rc) return rc;
+    rc = make_env_consts(env, &ra.env, 64); if (rc) return rc;
     ra.pol = policy->dev;
     if (ra.pol.obs_size != ra.env.n_cells * ra.env.n_cells) {
         set_error("index out of bounds: policy obs_size %d != Puzzle obs ids %d", ra.pol.obs_size, ra.env.n_cells * ra.env.n_cells);
@@ -1533,9 +1533,9 @@ extern "C" int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, c
 {
     if (!env || !policy || !prm || !success_rate || !mean_reward) { set_error("tw_evaluate: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
-    // boards of 17 .. 25 cells without MCTS: on the device (solve_big_kernel); everything else above 16 cells: the any-environment path (host env)
+    // boards of 17 .. 64 cells without MCTS: on the device (solve_big_kernel); everything else above 16 cells: the any-environment path (host env)
     const uint64_t cells = (uint64_t)env->width * env->height;
-    const bool big_dev = cells > 16 && cells <= 25 && policy->dev.generic && prm->num_mcts_searches == 0 && prm->precision == TW_PREC_F32_EXACT &&
+    const bool big_dev = cells > 16 && cells <= 64 && policy->dev.generic && prm->num_mcts_searches == 0 && prm->precision == TW_PREC_F32_EXACT &&
                          (uint64_t)env->depth_slope * env->difficulty <= 1022 && env->max_depth != 0 && !launch_options().force_geom;
     if (cells > 16 && !big_dev) {
         uint64_t depth0 = 0;
@@ -1547,7 +1547,7 @@ extern "C" int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, c
         tw_puzzle_destroy(proto);
         return rc;
     }
-    PuzzleConsts envc; rc = make_env_consts(env, &envc, 25); if (rc) return rc;
+    PuzzleConsts envc; rc = make_env_consts(env, &envc, 64); if (rc) return rc;
     if (num_episodes == 0) { *success_rate = __builtin_nanf(""); *mean_reward = __builtin_nanf(""); return TW_OK; }   // 0/0 (evaluate.rs:52)
     std::vector<float> bs, br; std::vector<uint8_t> acts;
     rc = run_solve(envc, policy, prm, num_episodes, episode_offset, false, nullptr, envc.depth0 + 1, false, bs, br, acts);

@@ -223,11 +223,12 @@ struct EngineV {
         }
         __syncthreads();
         const int col = tid >> 4, ql = tid & 15;
+        const int nq = E / 4;
+        if constexpr (NC <= 25) {
         int ro[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) ro[i] = lds_rows[col * NC + i];
         constexpr int QT = NC > 16 ? 1 : (NC > 9 ? 2 : 4);     // QT x NC row quads are in flight per lane: at most 128 registers (two workgroups per CU)
-        const int nq = E / 4;
         for (int q0 = ql; q0 < nq; q0 += 16 * QT) {
             int qs[QT];
 #pragma unroll
@@ -256,6 +257,44 @@ struct EngineV {
                 y[(4 * qs[u] + 0) * GEN_STRIDE + col] = a[u].x; y[(4 * qs[u] + 1) * GEN_STRIDE + col] = a[u].y;
                 y[(4 * qs[u] + 2) * GEN_STRIDE + col] = a[u].z; y[(4 * qs[u] + 3) * GEN_STRIDE + col] = a[u].w;
             }
+        }
+        } else {
+        // boards of 26 .. 64 cells: the cells in blocks of 16 (the row loads of a block are in flight together, the adds stay in cell
+        // order), two output quads per trip; the ids are read from LDS where they are used
+        constexpr int QT = 2, CB = 16;
+        for (int q0 = ql; q0 < nq; q0 += 16 * QT) {
+            int qs[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) qs[u] = q0 + 16 * u < nq ? q0 + 16 * u : q0;
+            fx4 a[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) a[u] = *(const gfx4 *)(bias + 4 * qs[u]);
+#pragma unroll
+            for (int c0 = 0; c0 < NC; c0 += CB) {
+                fx4 r[QT][CB]; int ro[CB];
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    ro[i] = c0 + i < NC ? lds_rows[col * NC + c0 + i] : -1;
+                    const float *row = tab + (size_t)(ro[i] >= 0 ? ro[i] : 0) * E;
+#pragma unroll
+                    for (int u = 0; u < QT; ++u) r[u][i] = *(const gfx4 *)(row + 4 * qs[u]);
+                }
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    if (ro[i] >= 0) {
+#pragma unroll
+                        for (int u = 0; u < QT; ++u) { a[u].x = a[u].x + r[u][i].x; a[u].y = a[u].y + r[u][i].y; a[u].z = a[u].z + r[u][i].z; a[u].w = a[u].w + r[u][i].w; }
+                    }
+                }
+            }
+            float *y = bufp(0);
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                if (pol.emb_relu) { a[u].x = a[u].x > 0.0f ? a[u].x : 0.0f; a[u].y = a[u].y > 0.0f ? a[u].y : 0.0f; a[u].z = a[u].z > 0.0f ? a[u].z : 0.0f; a[u].w = a[u].w > 0.0f ? a[u].w : 0.0f; }
+                y[(4 * qs[u] + 0) * GEN_STRIDE + col] = a[u].x; y[(4 * qs[u] + 1) * GEN_STRIDE + col] = a[u].y;
+                y[(4 * qs[u] + 2) * GEN_STRIDE + col] = a[u].z; y[(4 * qs[u] + 3) * GEN_STRIDE + col] = a[u].w;
+            }
+        }
         }
         __syncthreads();
 #ifdef TW_ABLATE

@@ -1,43 +1,103 @@
-// tw_rollout_big.hip -- the fused PPO rollout for Puzzle boards of 17 .. 25 cells (5 x 5, 6 x 4, ..) on the device.
+// tw_rollout_big.hip -- the fused PPO rollout for Puzzle boards of 17 .. 64 cells (5 x 5, 6 x 4, 6 x 6, 8 x 8, ..) on the device.
 //
 // Puzzle::new takes any width x height (reference rust/src/envs/puzzle.rs:34-42); the rollout kernels of tw_rollout.hip pack a
-// board as 16 nibbles in one 64-bit register.  Here a board is 25 x 5 bits in a 128-bit integer, obs ids (cell * n_cells + tile,
-// puzzle.rs:183-185) run up to 624 and are stored as uint16, and the policy -- any Sequential stack over an obs_size above 256 is
+// board as 16 nibbles in one 64-bit register.  Here a board of up to 25 cells is 25 x 5 bits in a 128-bit integer, a board of up
+// to 36 / 64 cells one byte per cell in 9 / 16 registers (Board8); obs ids (cell * n_cells + tile, puzzle.rs:183-185) run up to
+// 4,095 and are stored as uint16, and the policy -- any Sequential stack over an obs_size above 256 is
 // a "generic" policy (tw_policy_create) -- runs on EngineV (tw_engine_generic.hpp: every Linear on the matrix cores, the
 // EmbeddingBag gathered from global memory).  Same path otherwise: PPOCollector::single_collect (collector/ppo.rs:54-80),
 // Policy::forward_with_perm (nn/policy.rs:56-100), sample_from_logits (policy.rs:169-172), Env::step / masks / reward / is_final
 // (puzzle.rs:135-181), same RNG streams, same arithmetic: bit-equal to the oracle.  evaluate() without MCTS runs here too
-// (solve_big_kernel).  Boards above 25 cells, self-play, solve() from a given state and MCTS-guided evaluate of boards above 16
+// (solve_big_kernel).  Boards above 64 cells, self-play, solve() from a given state and MCTS-guided evaluate of boards above 16
 // cells stay on the host-stepped path (tw_env_generic.hip).
 #include "tw_engine_generic.hpp"
 
 namespace tw {
 
 typedef unsigned __int128 u128;
-constexpr int BIG_NC = 25;
+constexpr int BIG_NC = 25;               // cells of a 5-bit board; 36 and 64: byte boards
 
-struct BigLane { u128 board; int32_t zx, zy, depth; };       // 5 bits per cell: cell i holds tile (board >> 5i) & 31
+// 5 bits per cell in 128 bits: cell i holds tile (b >> 5i) & 31
+struct Board5 {
+    u128 b;
+    __device__ static Board5 ident(int n_cells)
+    {
+        Board5 r; r.b = 0;
+        for (int i = 0; i < n_cells; ++i) r.b |= (u128)(uint32_t)i << (5 * i);
+        return r;
+    }
+    __device__ uint32_t cell(int i) const { return (uint32_t)(b >> (5 * i)) & 31u; }
+    __device__ void slide(int zi, int ti)                                   // the tile at cell ti moves to the blank's cell zi
+    {
+        const u128 tile = (b >> (5 * ti)) & (u128)31;                       // cell zi holds 0
+        b = (b & ~((u128)31 << (5 * ti))) | (tile << (5 * zi));
+    }
+    __device__ bool operator==(const Board5 &o) const { return b == o.b; }
+};
 
-__device__ inline uint32_t big_cell(u128 b, int i) { return (uint32_t)(b >> (5 * i)) & 31u; }
+// one byte per cell, NC / 4 registers.  Cells are addressed with compile-time indices wherever the cell loop is unrolled; the two
+// run-time accesses of a step select among the words (a register array indexed at run time would live in scratch)
+template <int NC>
+struct Board8 {
+    static constexpr int NW = (NC + 3) / 4;
+    uint32_t w[NW];
+    __device__ static Board8 ident(int n_cells)
+    {
+        Board8 r;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int i = 4 * k + c; if (i < n_cells) v |= (uint32_t)i << (8 * c); }
+            r.w[k] = v;
+        }
+        return r;
+    }
+    __device__ uint32_t cell(int i) const                                   // (i: a constant after unrolling)
+    {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) v = (k == (i >> 2)) ? w[k] : v;
+        return (v >> (8 * (i & 3))) & 255u;
+    }
+    __device__ void slide(int zi, int ti)
+    {
+        const uint32_t tile = cell(ti);
+        const uint32_t clr = ~(255u << (8 * (ti & 3))), put = tile << (8 * (zi & 3));
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            uint32_t v = w[k];
+            v = (k == (ti >> 2)) ? (v & clr) : v;
+            v = (k == (zi >> 2)) ? (v | put) : v;                           // cell zi holds 0
+            w[k] = v;
+        }
+    }
+    __device__ bool operator==(const Board8 &o) const
+    {
+        uint32_t d = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) d |= w[k] ^ o.w[k];
+        return d == 0;
+    }
+};
 
-__device__ inline void big_step(BigLane &s, const PuzzleConsts &c, int action)          // Env::step (puzzle.rs:135-160), as puzzle_step
+template <int NC> struct BoardOf { using T = Board8<NC>; };
+template <> struct BoardOf<BIG_NC> { using T = Board5; };
+
+template <typename Board>
+struct BigLaneT { Board board; int32_t zx, zy, depth; };
+
+template <typename Board>
+__device__ inline void big_step(BigLaneT<Board> &s, const PuzzleConsts &c, int action)          // Env::step (puzzle.rs:135-160), as puzzle_step
 {
     const int dx = (action == 2 ? 1 : 0) - (action == 0 ? 1 : 0), dy = (action == 3 ? 1 : 0) - (action == 1 ? 1 : 0);
     int nx = s.zx + dx, ny = s.zy + dy;
     const bool ok = (unsigned)nx < (unsigned)c.width && (unsigned)ny < (unsigned)c.height;
     nx = ok ? nx : s.zx; ny = ok ? ny : s.zy;
     const int zi = s.zy * c.width + s.zx, ti = ny * c.width + nx;
-    const u128 tile = (s.board >> (5 * ti)) & (u128)31;                     // cell zi holds 0
-    s.board = (s.board & ~((u128)31 << (5 * ti))) | (tile << (5 * zi));
+    s.board.slide(zi, ti);                                                  // (an illegal move: zi == ti, the board stays)
     s.zx = nx; s.zy = ny;
     s.depth = s.depth > 0 ? s.depth - 1 : 0;
-}
-
-__device__ inline u128 big_ident(int n_cells)
-{
-    u128 id = 0;
-    for (int i = 0; i < n_cells; ++i) id |= (u128)(uint32_t)i << (5 * i);
-    return id;
 }
 
 template <int NC>
@@ -50,13 +110,14 @@ __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a
     const PuzzleConsts env = a.env;
     const int j = eng.j;
     const int nc = env.n_cells;
-    const u128 ident = big_ident(nc);
+    using Board = typename BoardOf<NC>::T;
+    const Board ident = Board::ident(nc);
     // every lane group of every wave carries the state of column j (the engine's mapping); lanes 0-15 of wave 0 store
     const uint64_t e_local = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)j;
     const bool valid  = e_local < a.num_episodes;
     const bool writer = eng.h == 0 && eng.primary();
     const uint64_t e_global = a.episode_offset + e_local;
-    BigLane st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;
+    BigLaneT<Board> st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;
     if (valid) {                                                             // Env::reset (puzzle.rs:119-133)
         for (int d = 0; d < env.difficulty; ++d) {
             const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)d, STREAM_SCRAMBLE);
@@ -80,7 +141,7 @@ __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a
         for (int i = 0; i < NC; ++i) {
             int row = -1;
             if (i < nc) {
-                const int id = i * nc + (int)big_cell(st.board, i);
+                const int id = i * nc + (int)st.board.cell(i);
                 row = perm >= 0 ? (int)eng.pol.obs_perms16[(size_t)perm * eng.pol.obs_size + id] : id;
             }
             rowoff[i] = row;
@@ -102,7 +163,8 @@ __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a
                 const uint32_t zero4[4] = {0u, 0u, 0u, 0u};
                 store_rec(a.out.rec + rec, zero4, lg, value, rew, action, perm);
                 uint16_t *o = obs16 + rec * (uint64_t)nc;
-                for (int i = 0; i < nc; ++i) o[i] = (uint16_t)(i * nc + (int)big_cell(st.board, i));
+#pragma unroll
+                for (int i = 0; i < NC; ++i) if (i < nc) o[i] = (uint16_t)(i * nc + (int)st.board.cell(i));
             }
             if (st.depth == 0 || solved) alive = false;                      // puzzle.rs:167-169
             else { big_step(st, env, action); ++t; }
@@ -124,12 +186,13 @@ __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
     eng.begin1(a.pol, lds);
     const PuzzleConsts env = a.env;
     const int nc = env.n_cells;
-    const u128 ident = big_ident(nc);
+    using Board = typename BoardOf<NC>::T;
+    const Board ident = Board::ident(nc);
     const uint64_t att = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)eng.j;
     const bool valid = att < a.num_attempts, writer = eng.h == 0 && eng.primary();
     const uint64_t ep  = a.episode_offset + att / a.num_searches;                    // episode: keys the start state
     const uint64_t key = ep * (uint64_t)a.num_searches + att % a.num_searches;       // keys this attempt's draws
-    BigLane st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;
+    BigLaneT<Board> st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;
     if (valid) {                                                                      // env.reset() per episode (evaluate.rs:39,65)
         for (int d = 0; d < env.difficulty; ++d) {
             const u32x4 w = rng_draw(a.seed, ep, (uint32_t)d, STREAM_SCRAMBLE);
@@ -152,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
         for (int i = 0; i < NC; ++i) {
             int row = -1;
             if (i < nc) {
-                const int id = i * nc + (int)big_cell(st.board, i);
+                const int id = i * nc + (int)st.board.cell(i);
                 row = perm >= 0 ? (int)eng.pol.obs_perms16[(size_t)perm * eng.pol.obs_size + id] : id;
             }
             rowoff[i] = row;
@@ -188,22 +251,30 @@ __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
     eng.end();
 }
 
-int launch_solve_big(const SolveArgs &a, hipStream_t s)
+template <int NC>
+static int launch_solve_big_nc(const SolveArgs &a, hipStream_t s)
 {
-    if (a.env.n_cells <= 16 || a.env.n_cells > BIG_NC || !a.pol.generic || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
-        (a.pol.n_perms > 0 && !a.pol.obs_perms16) || a.num_searches == 0 || !a.success || !a.total || !a.n_steps || a.actions || a.from_state) {
-        set_error("evaluate (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
-        return TW_ERR_UNSUPPORTED;
-    }
-    using Eng = EngineV<BIG_NC>;
+    using Eng = EngineV<NC>;
     const uint64_t nb = (a.num_attempts + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
     const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
     if (lds_bytes > 159 * 1024) { set_error("solve: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&solve_big_kernel<BIG_NC>), lds_bytes)) return rc;
-    hipLaunchKernelGGL((solve_big_kernel<BIG_NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&solve_big_kernel<NC>), lds_bytes)) return rc;
+    hipLaunchKernelGGL((solve_big_kernel<NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a);
     TW_HIP(hipGetLastError());
     return TW_OK;
+}
+
+int launch_solve_big(const SolveArgs &a, hipStream_t s)
+{
+    if (a.env.n_cells <= 16 || a.env.n_cells > 64 || !a.pol.generic || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
+        (a.pol.n_perms > 0 && !a.pol.obs_perms16) || a.num_searches == 0 || !a.success || !a.total || !a.n_steps || a.actions || a.from_state) {
+        set_error("evaluate (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
+        return TW_ERR_UNSUPPORTED;
+    }
+    if (a.env.n_cells <= BIG_NC) return launch_solve_big_nc<BIG_NC>(a, s);
+    if (a.env.n_cells <= 36) return launch_solve_big_nc<36>(a, s);
+    return launch_solve_big_nc<64>(a, s);
 }
 
 // obs ids of the padded trajectories -> the compact result (one wave per episode, grid-stride)
@@ -219,27 +290,35 @@ __global__ void __launch_bounds__(256) compact_obs16_kernel(const uint16_t *obs1
     }
 }
 
+template <int NC>
+static int launch_rollout_big_nc(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    using Eng = EngineV<NC>;
+    const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
+    if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
+    const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
+    if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_big_kernel<NC>), lds_bytes)) return rc;
+    hipLaunchKernelGGL((rollout_big_kernel<NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a, obs16);
+    TW_HIP(hipGetLastError());
+    if (blocks) *blocks = (uint32_t)nb;
+    if (threads) *threads = Eng::THREADS;
+    return TW_OK;
+}
+
 int launch_rollout_big(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     // host-side shape checks: everything the kernel indexes with is validated here
-    if (a.env.n_cells <= 16 || a.env.n_cells > BIG_NC || a.env.width * a.env.height != a.env.n_cells || !a.pol.generic ||
+    if (a.env.n_cells <= 16 || a.env.n_cells > 64 || a.env.width * a.env.height != a.env.n_cells || !a.pol.generic ||
         a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 || (a.pol.n_perms > 0 && !a.pol.obs_perms16) ||
         a.out.t_pad < a.env.depth0 + 1 || !obs16 || a.queue || a.init_boards) {
         set_error("rollout (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d generic=%d)", a.env.n_cells, a.pol.obs_size,
                   a.pol.n_actions, a.pol.generic);
         return TW_ERR_UNSUPPORTED;
     }
-    using Eng = EngineV<BIG_NC>;
-    const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
-    if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
-    const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
-    if (lds_bytes > 159 * 1024) { set_error("rollout: %zu bytes of LDS needed, 159 KiB available", lds_bytes); return TW_ERR_UNSUPPORTED; }
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&rollout_big_kernel<BIG_NC>), lds_bytes)) return rc;
-    hipLaunchKernelGGL((rollout_big_kernel<BIG_NC>), dim3((unsigned)nb), dim3(Eng::THREADS), lds_bytes, s, a, obs16);
-    TW_HIP(hipGetLastError());
-    if (blocks) *blocks = (uint32_t)nb;
-    if (threads) *threads = Eng::THREADS;
-    return TW_OK;
+    if (a.env.n_cells <= BIG_NC) return launch_rollout_big_nc<BIG_NC>(a, obs16, s, blocks, threads);
+    if (a.env.n_cells <= 36) return launch_rollout_big_nc<36>(a, obs16, s, blocks, threads);
+    return launch_rollout_big_nc<64>(a, obs16, s, blocks, threads);
 }
 
 int launch_compact_obs16(const uint16_t *obs16, const uint32_t *ep_len, const uint64_t *ep_start, uint64_t E, int t_pad, int n_cells,
