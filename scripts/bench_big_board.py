@@ -18,3 +18,17 @@ for w, D in ((5, 16), (6, 16), (8, 16)):
             t0 = time.perf_counter(); d = coll.collect(env, pol, seed=2); dt = time.perf_counter() - t0
         print(json.dumps({"board": "%dx%d, policy %d->512->256->4|1, difficulty %d" % (w, w, n2 * n2, D), "path": name, "envs": E, "records": len(d), "wall_ms": dt * 1e3,
                           "rollout_ms": d.stats["ms_rollout"], "records_per_s": len(d) / dt, "blocks": d.stats["rollout_blocks"], "threads": d.stats["rollout_threads"]}))
+
+# AlphaZero self-play of such boards: the device kernel (tw_mcts_big.hip) against the host-stepped collector
+for w, E, S in ((5, 4096, 100), (8, 4096, 100)):
+    n2 = w * w
+    pol = amd_policy(make_deep_policy_arrays(n2, seed=0, emb=512, common=(256,)))
+    env = twisterl.env.Puzzle(w, w, 8, 2, 256)
+    for name, EE, geom in (("device (tw_mcts_big.hip)", E, 0), ("host-stepped (tw_az_collect_env)", E // 16, 1)):
+        with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, geom):
+            coll = twisterl.collector.AZCollector(EE, S, 1.41, 1, 32)
+            coll.collect(env, pol, seed=1)
+            t0 = time.perf_counter(); d = coll.collect(env, pol, seed=2); dt = time.perf_counter() - t0
+        print(json.dumps({"board": "%dx%d self-play, policy %d->512->256->4|1, difficulty 8, %d searches" % (w, w, n2 * n2, S), "path": name, "episodes": EE, "records": len(d),
+                          "wall_ms": dt * 1e3, "leaf_evaluations_per_s": d.stats["forward_evals"] / dt if d.stats["forward_evals"] else None,
+                          "records_per_s": len(d) / dt, "blocks": d.stats["rollout_blocks"], "threads": d.stats["rollout_threads"]}))

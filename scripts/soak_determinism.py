@@ -92,3 +92,18 @@ for kw, E, rep in ((dict(emb=508, common=(256,)), 65536, n), (dict(emb=512, comm
         if ref is None: ref = dg
         elif dg != ref: bad += 1
     print("generic policy", kw, "E", E, "repeats", rep, "mismatching repeats", bad, flush=True)
+# boards above 16 cells on the device (tw_rollout_big.hip, tw_mcts_big.hip) and self-play with a generic policy on a 4 x 4 board
+for (w, h), kw, E, S, rep in (((5, 5), dict(emb=64, common=(128,)), 20000, 0, n), ((6, 4), dict(emb=32, common=(48, 32)), 5000, 0, n), ((8, 8), dict(emb=64, common=(64,)), 8192, 0, n),
+                              ((6, 4), dict(emb=32, common=(48, 32)), 600, 24, n), ((6, 6), dict(emb=32, common=(64, 32)), 400, 16, n), ((8, 8), dict(emb=32, common=(32,)), 300, 12, n),
+                              ((4, 4), dict(emb=64, common=(96, 32)), 2000, 24, n)):
+    polb = amd_policy(make_deep_policy_arrays(w * h, seed=1, scale=2.0, **kw))
+    env = twisterl.env.Puzzle(w, h, 6, 2, 256)
+    coll = twisterl.collector.AZCollector(E, S, 1.41, 1, 1) if S else twisterl.collector.PPOCollector(E, 0.995, 0.995, 1)
+    ref = None; bad = 0
+    for i in range(rep):
+        d = coll.collect(env, polb, seed=5)
+        dg = digest(d)
+        if ref is None: ref = dg
+        elif dg != ref: bad += 1
+    print("board", w, "x", h, "self-play %d searches" % S if S else "PPO", kw, "E", E, "launch", d.stats["rollout_blocks"], "x", d.stats["rollout_threads"],
+          "repeats", rep, "mismatching repeats", bad, flush=True)

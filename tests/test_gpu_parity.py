@@ -313,7 +313,8 @@ def test_boards_of_17_to_64_cells_roll_out_on_the_device(tw, oracle):
     """5 x 5 (and 6 x 4, 6 x 6, 7 x 5, 8 x 8) PPO collects run the device kernel of tw_rollout_big.hip -- 5-bit cells in a 128-bit register up
     to 25 cells, one byte per cell in 9 / 16 registers up to 36 / 64, two-byte obs ids, the generic engine -- not the host-stepped path: 65,536 envs of a 5 x 5 board in 4,096 workgroups of 256 threads, sampled
     episodes bit-equal to the oracle on every field (the RNG is keyed by the global episode index); a small batch with the
-    transpose twist compared whole, in both orders; and the same bytes as the host-stepped path (pinned through TW_OPT_FORCE_GEOM)."""
+    transpose twist compared whole, in both orders; and the same bytes as the host-stepped path (pinned through TW_OPT_FORCE_GEOM).
+    Plain evaluate() and AlphaZero self-play of these boards run on the device too."""
     from tests.util import make_deep_policy_arrays
     arrs = make_deep_policy_arrays(25, seed=5, emb=64, common=(128,), scale=2.0)
     gp, op = amd_policy(arrs), oracle_policy(oracle, arrs)
@@ -366,6 +367,20 @@ def test_boards_of_17_to_64_cells_roll_out_on_the_device(tw, oracle):
         de = tw.collector.evaluate(genv, gp, num_episodes=300, deterministic=False, num_searches=2, num_mcts_searches=0, seed=7, C=1.41,
                                    max_expand_depth=1, num_cores=32)
         assert f32_bits(he[0]) == f32_bits(de[0]) and f32_bits(he[1]) == f32_bits(de[1])
+        # self-play runs on the device as well (tw_mcts_big.hip: nodes without a board, the state follows the actions): 40 episodes in three
+        # workgroups, both expansion depths, against the oracle's native collector and the host-stepped path
+        for S, med in ((8, 1), (5, 2)):
+            acoll = tw.collector.AZCollector(num_episodes=40, num_mcts_searches=S, C=1.41, max_expand_depth=med, num_cores=32, seed=23)
+            z = acoll.collect(genv, gp, seed=23)
+            assert (z.stats["rollout_blocks"], z.stats["rollout_threads"]) == (3, 256) and z.stats["forward_evals"] > 40 * S
+            zo = oracle.az_collect(oenv, op, 40, S, 1.41, med, seed=23, arith=oracle.ARITH_CHAIN, num_threads=8, det_math=True)
+            _assert_same_az(z, zo, n2)
+            with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):
+                zh = acoll.collect(genv, gp, seed=23)
+            assert zh.stats["rollout_blocks"] != 3
+            za, zb = z.to_numpy(), zh.to_numpy()
+            for k in za:
+                assert np.array_equal(za[k], zb[k]), k
         with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):                  # the host-stepped path (tw_ppo_collect_env)
             hst = coll.collect(genv, gp, seed=17)
         assert hst.stats["rollout_blocks"] != 10

@@ -1287,10 +1287,16 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     }
     if (prm->precision != TW_PREC_F32_EXACT) { set_error("tw_az_collect: precision %u not implemented", prm->precision); return TW_ERR_UNSUPPORTED; }
     int rc = require_device(); if (rc) return rc;
-    if ((uint64_t)env->width * env->height > 16) return collect_big_board(env, policy, nullptr, prm, out);
+    // boards of 17 .. 64 cells: self-play on the device too (tw_mcts_big.hip: boards of 5-bit or one-byte cells, nodes without a
+    // board, two-byte obs ids, the generic engine); whatever that kernel does not take steps on the host (tw_env_generic.hip)
+    const uint64_t cells = (uint64_t)env->width * env->height;
+    const bool big = cells > 16;
+    if (big && !(cells <= 64 && policy->dev.generic && (uint64_t)env->depth_slope * env->difficulty <= 1022 && env->max_depth != 0 &&
+                 !launch_options().force_geom))
+        return collect_big_board(env, policy, nullptr, prm, out);
 
     MctsArgs ma{};
-    rc = make_env_consts(env, &ma.env); if (rc) return rc;
+    rc = make_env_consts(env, &ma.env, 64); if (rc) return rc;
     ma.pol = policy->dev;
     if (ma.pol.obs_size != ma.env.n_cells * ma.env.n_cells) {
         set_error("index out of bounds: policy obs_size %d != Puzzle obs ids %d", ma.pol.obs_size, ma.env.n_cells * ma.env.n_cells);
@@ -1316,14 +1322,15 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     // persistent lanes (more episodes than resident lanes): one tree arena per LANE, start boards + episode queue
     ma.reserve_cus = (int)(prm->reserve_cus > 0x7fffu ? 0x7fffu : prm->reserve_cus);
     // few, deep searches: the walker-per-wave shape (tw_mcts_deep.hip) -- always persistent, 64-byte nodes, one arena per walker
-    const bool deep = mcts_deep_applies(ma);
-    const uint64_t resident = deep ? mcts_deep_walkers(E, ma.reserve_cus, ma.num_searches) : f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
-    const bool persist = deep || (E > resident && !launch_options().no_persist && !ma.pol.generic);
+    const bool deep = !big && mcts_deep_applies(ma);
+    const uint64_t resident = big ? E : deep ? mcts_deep_walkers(E, ma.reserve_cus, ma.num_searches) : f32_resident_episodes(E, (int)ma.pol.hidden, true, ma.reserve_cus);
+    const bool persist = !big && (deep || (E > resident && !launch_options().no_persist && !ma.pol.generic));
     const uint64_t arenas = persist ? resident : E;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(136), o_scan = seg(scan_scratch_bytes(E)),
-                 o_arena = seg(deep ? arenas * mcts_deep_arena_bytes(cap64) : arenas * cap64 * mcts_node_bytes()),
-                 o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0), o_order = seg(deep ? E * 4 : 0);
+                 o_arena = seg(big ? arenas * cap64 * mcts_big_node_bytes() : deep ? arenas * mcts_deep_arena_bytes(cap64) : arenas * cap64 * mcts_node_bytes()),
+                 o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0), o_order = seg(deep ? E * 4 : 0),
+                 o_obs16 = seg(big ? R * cells * 2 : 0);
     const uint32_t tbl_entries = deep ? mcts_deep_table_entries(ma.num_searches, ma.max_expand_depth) : 0;
     const size_t tbl_bytes = (size_t)arenas * tbl_entries * 32;
     const size_t o_tbl = seg(tbl_bytes);
@@ -1372,7 +1379,8 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
         }
     }
     TW_HIP(hipEventRecord(ev.ev[0], s));
-    rc = deep ? launch_mcts_deep(ma, s, &st.rollout_blocks, &st.rollout_threads)
+    rc = big  ? launch_mcts_big(ma, reinterpret_cast<uint16_t *>(ws + o_obs16), s, &st.rollout_blocks, &st.rollout_threads)
+       : deep ? launch_mcts_deep(ma, s, &st.rollout_blocks, &st.rollout_threads)
               : launch_mcts_f32(ma, s, &st.rollout_blocks, &st.rollout_threads);
     if (rc) return rc;
     TW_HIP(hipEventRecord(ev.ev[1], s));
@@ -1397,7 +1405,8 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     c->n_records = total; c->n_episodes = E; c->n_cells = (uint32_t)ma.env.n_cells; c->n_actions = 4; c->is_ppo = 0;
     size_t ccur = 0;
     auto cseg = [&](int f, size_t bytes) { c->field_bytes[f] = bytes; size_t o = ccur; ccur = align_up(ccur + bytes, 256); return o; };
-    const size_t c_obs = cseg(TW_F_OBS, total * c->n_cells), c_lg = cseg(TW_F_LOGITS, total * 16), c_prm = cseg(TW_F_PERMS, total),
+    if (big) c->obs_width = 2;
+    const size_t c_obs = cseg(TW_F_OBS, total * c->n_cells * c->obs_width), c_lg = cseg(TW_F_LOGITS, total * 16), c_prm = cseg(TW_F_PERMS, total),
                  c_rem = cseg(TW_F_REMAINING, total * 4), c_len = cseg(TW_F_EP_LEN, E * 4), c_start = cseg(TW_F_EP_START, E * 8);
     rc = hipGetDevice(&c->device) == hipSuccess ? arena_acquire(ccur, &c->arena, &c->arena_cap) : TW_ERR_HIP;
     if (rc) { delete c; return rc; }
@@ -1407,8 +1416,11 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
 
 #define TW_HIP_C(call) do { hipError_t _e = (call); if (_e != hipSuccess) { tw_collected_free(c); return hip_fail(_e, #call, __FILE__, __LINE__); } } while (0)
     TW_HIP_C(hipEventRecord(ev.ev[3], s));
-    rc = launch_finalize_az(ma.out, ep_start_ws, E, ma.env.n_cells, ca + c_obs, reinterpret_cast<float *>(ca + c_lg),
+    rc = launch_finalize_az(ma.out, ep_start_ws, E, big ? 0 : ma.env.n_cells, ca + c_obs, reinterpret_cast<float *>(ca + c_lg),      // (0 cells: the obs ids come from their own array)
                             reinterpret_cast<int8_t *>(ca + c_prm), reinterpret_cast<float *>(ca + c_rem), s);
+    if (rc == TW_OK && big)
+        rc = launch_compact_obs16(reinterpret_cast<const uint16_t *>(ws + o_obs16), ma.out.ep_len, ep_start_ws, E, t_pad, (int)cells,
+                                  reinterpret_cast<uint16_t *>(ca + c_obs), s);
     if (rc) { tw_collected_free(c); return rc; }
     TW_HIP_C(hipMemcpyAsync(ca + c_len, ma.out.ep_len, E * 4, hipMemcpyDeviceToDevice, s));
     TW_HIP_C(hipMemcpyAsync(ca + c_start, ep_start_ws, E * 8, hipMemcpyDeviceToDevice, s));

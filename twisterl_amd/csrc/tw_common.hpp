@@ -523,6 +523,9 @@ __host__ __device__ inline size_t mcts_deep_arena_bytes(uint64_t node_cap) { ret
 uint32_t mcts_deep_table_entries(uint32_t num_searches, uint32_t max_expand_depth);     // per walker, 32 bytes each
 int      launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads);
+// self-play of boards of 17 .. 64 cells (tw_mcts_big.hip): 32-byte nodes without a board, obs ids as for launch_rollout_big
+size_t mcts_big_node_bytes();
+int launch_mcts_big(const MctsArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_finalize_az(const PaddedTraj &in, const uint64_t *ep_start, uint64_t n_episodes, int n_cells,
                        uint8_t *obs_out, float *probs_out, int8_t *perms_out, float *remaining_out, hipStream_t s);
 int launch_onehot(const uint8_t *obs, uint64_t row0, uint64_t rows, int n_cells, int obs_size, float *out, hipStream_t s);

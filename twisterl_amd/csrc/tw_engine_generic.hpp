@@ -22,9 +22,12 @@ typedef float fx4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) fx4 gfx4;
 
 // ASM_MFMA: the MFMAs as inline asm with the accumulators pinned to VGPRs (with the intrinsic the allocator shuttles them between VGPRs
-// and AGPRs around every k-group).  Only where a wave may use all 512 registers: capped at 256 (two workgroups per CU) the allocator
-// puts copies of the asm's operands in front of an MFMA it cannot see, without the wait states an MFMA needs after a VALU write --
-// deterministic wrong sums (round 3, 9-cell rollout) -- and with 256 registers there are no AGPRs to shuttle through anyway.
+// and AGPRs around every k-group).  ONLY for kernels that keep all their registers in VGPRs.  Wherever the allocator parks values in
+// AGPRs -- a kernel capped at 256 registers (two workgroups per CU), or one whose own state does not fit (self-play, boards above 25
+// cells) -- it may put the reload of an asm operand right in front of an MFMA it cannot see, without the wait states an MFMA needs
+// after a VALU write: deterministic wrong sums (round 3: the 9-cell rollout at two workgroups per CU; self-play of a 6 x 4 board with a
+// 32 -> 48 -> 32 stack, one visit count off in 14 of 126 records).  Those kernels take the intrinsic form (`EngineV<NC, false>`,
+// geometry -65); scripts/kernel_resources.sh shows the AGPR count of every instantiation.
 template <int NC, bool ASM_MFMA = true>
 struct EngineV {
     static constexpr int NW = 4, THREADS = 256, EPB = GEN_COLS, NS = 4;

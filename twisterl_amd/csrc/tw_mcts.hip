@@ -577,9 +577,9 @@ int launch_mcts_f32(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t
             return TW_ERR_UNSUPPORTED;
         }
         const int nc = a.env.n_cells;
-        if (nc <= 4) return launch_mcts_geom<0, 4, -64>(a, s, blocks, threads);
-        if (nc <= 9) return launch_mcts_geom<0, 9, -64>(a, s, blocks, threads);
-        return launch_mcts_geom<0, 16, -64>(a, s, blocks, threads);
+        if (nc <= 4) return launch_mcts_geom<0, 4, -65>(a, s, blocks, threads);
+        if (nc <= 9) return launch_mcts_geom<0, 9, -65>(a, s, blocks, threads);
+        return launch_mcts_geom<0, 16, -65>(a, s, blocks, threads);
     }
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||
         a.pol.obs_size > 256 || a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 ||

@@ -11,99 +11,14 @@
 // (solve_big_kernel).  Boards above 64 cells, self-play, solve() from a given state and MCTS-guided evaluate of boards above 16
 // cells stay on the host-stepped path (tw_env_generic.hip).
 #include "tw_engine_generic.hpp"
+#include "tw_big_board.hpp"
 
 namespace tw {
-
-typedef unsigned __int128 u128;
-constexpr int BIG_NC = 25;               // cells of a 5-bit board; 36 and 64: byte boards
-
-// 5 bits per cell in 128 bits: cell i holds tile (b >> 5i) & 31
-struct Board5 {
-    u128 b;
-    __device__ static Board5 ident(int n_cells)
-    {
-        Board5 r; r.b = 0;
-        for (int i = 0; i < n_cells; ++i) r.b |= (u128)(uint32_t)i << (5 * i);
-        return r;
-    }
-    __device__ uint32_t cell(int i) const { return (uint32_t)(b >> (5 * i)) & 31u; }
-    __device__ void slide(int zi, int ti)                                   // the tile at cell ti moves to the blank's cell zi
-    {
-        const u128 tile = (b >> (5 * ti)) & (u128)31;                       // cell zi holds 0
-        b = (b & ~((u128)31 << (5 * ti))) | (tile << (5 * zi));
-    }
-    __device__ bool operator==(const Board5 &o) const { return b == o.b; }
-};
-
-// one byte per cell, NC / 4 registers.  Cells are addressed with compile-time indices wherever the cell loop is unrolled; the two
-// run-time accesses of a step select among the words (a register array indexed at run time would live in scratch)
-template <int NC>
-struct Board8 {
-    static constexpr int NW = (NC + 3) / 4;
-    uint32_t w[NW];
-    __device__ static Board8 ident(int n_cells)
-    {
-        Board8 r;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int i = 4 * k + c; if (i < n_cells) v |= (uint32_t)i << (8 * c); }
-            r.w[k] = v;
-        }
-        return r;
-    }
-    __device__ uint32_t cell(int i) const                                   // (i: a constant after unrolling)
-    {
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) v = (k == (i >> 2)) ? w[k] : v;
-        return (v >> (8 * (i & 3))) & 255u;
-    }
-    __device__ void slide(int zi, int ti)
-    {
-        const uint32_t tile = cell(ti);
-        const uint32_t clr = ~(255u << (8 * (ti & 3))), put = tile << (8 * (zi & 3));
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            uint32_t v = w[k];
-            v = (k == (ti >> 2)) ? (v & clr) : v;
-            v = (k == (zi >> 2)) ? (v | put) : v;                           // cell zi holds 0
-            w[k] = v;
-        }
-    }
-    __device__ bool operator==(const Board8 &o) const
-    {
-        uint32_t d = 0;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) d |= w[k] ^ o.w[k];
-        return d == 0;
-    }
-};
-
-template <int NC> struct BoardOf { using T = Board8<NC>; };
-template <> struct BoardOf<BIG_NC> { using T = Board5; };
-
-template <typename Board>
-struct BigLaneT { Board board; int32_t zx, zy, depth; };
-
-template <typename Board>
-__device__ inline void big_step(BigLaneT<Board> &s, const PuzzleConsts &c, int action)          // Env::step (puzzle.rs:135-160), as puzzle_step
-{
-    const int dx = (action == 2 ? 1 : 0) - (action == 0 ? 1 : 0), dy = (action == 3 ? 1 : 0) - (action == 1 ? 1 : 0);
-    int nx = s.zx + dx, ny = s.zy + dy;
-    const bool ok = (unsigned)nx < (unsigned)c.width && (unsigned)ny < (unsigned)c.height;
-    nx = ok ? nx : s.zx; ny = ok ? ny : s.zy;
-    const int zi = s.zy * c.width + s.zx, ti = ny * c.width + nx;
-    s.board.slide(zi, ti);                                                  // (an illegal move: zi == ti, the board stays)
-    s.zx = nx; s.zy = ny;
-    s.depth = s.depth > 0 ? s.depth - 1 : 0;
-}
 
 template <int NC>
 __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a, uint16_t *obs16)
 {
-    using Eng = EngineV<NC>;
+    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -180,7 +95,7 @@ __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a
 template <int NC>
 __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
 {
-    using Eng = EngineV<NC>;
+    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -254,7 +169,7 @@ __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
 template <int NC>
 static int launch_solve_big_nc(const SolveArgs &a, hipStream_t s)
 {
-    using Eng = EngineV<NC>;
+    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
     const uint64_t nb = (a.num_attempts + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
     const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
@@ -293,7 +208,7 @@ __global__ void __launch_bounds__(256) compact_obs16_kernel(const uint16_t *obs1
 template <int NC>
 static int launch_rollout_big_nc(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    using Eng = EngineV<NC>;
+    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
     const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);

@@ -126,9 +126,9 @@ int launch_solve_f32(const SolveArgs &a, hipStream_t s)
             return TW_ERR_UNSUPPORTED;
         }
         const int nc = a.env.n_cells;
-        if (nc <= 4) return launch_solve_geom<0, 4, -64>(a, s);
-        if (nc <= 9) return launch_solve_geom<0, 9, -64>(a, s);
-        return launch_solve_geom<0, 16, -64>(a, s);
+        if (nc <= 4) return launch_solve_geom<0, 4, -65>(a, s);
+        if (nc <= 9) return launch_solve_geom<0, 9, -65>(a, s);
+        return launch_solve_geom<0, 16, -65>(a, s);
     }
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells ||
         a.pol.obs_size > 256 || a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 || a.num_searches == 0 ||
