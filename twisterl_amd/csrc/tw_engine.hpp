@@ -1292,8 +1292,8 @@ template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -4> { using Eng = En
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -2> { using Eng = Engine3S<NT, NC, 2>; static constexpr int WAVES = 2; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -16> { using Eng = Engine3T<NT, NC>; static constexpr int WAVES = 4; };   // 16 episodes per workgroup
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -5> { using Eng = Engine3G<NT, NC>; static constexpr int WAVES = 4; };    // four waves share 32, two workgroups per CU
-template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -64> { using Eng = EngineV<NC>; static constexpr int WAVES = 4; };        // generic stacks (any Sequential depth)
-template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -65> { using Eng = EngineV<NC, false>; static constexpr int WAVES = 4; }; // ... two workgroups per CU (256 registers per lane)
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -64> { using Eng = EngineV<NC, true>; static constexpr int WAVES = 4; };   // generic stacks, inline-asm MFMAs: not used any more (tw_engine_generic.hpp)
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -65> { using Eng = EngineV<NC, false>; static constexpr int WAVES = 4; }; // generic stacks (any Sequential depth)
 
 // geometry for n episodes: 8 = the throughput shape; below ~3/4 of a chip of 256-episode workgroups the split shape
 template <int NT> inline int geometry_for(uint64_t n)

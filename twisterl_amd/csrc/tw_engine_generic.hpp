@@ -22,13 +22,14 @@ typedef float fx4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) fx4 gfx4;
 
 // ASM_MFMA: the MFMAs as inline asm with the accumulators pinned to VGPRs (with the intrinsic the allocator shuttles them between VGPRs
-// and AGPRs around every k-group).  ONLY for kernels that keep all their registers in VGPRs.  Wherever the allocator parks values in
-// AGPRs -- a kernel capped at 256 registers (two workgroups per CU), or one whose own state does not fit (self-play, boards above 25
-// cells) -- it may put the reload of an asm operand right in front of an MFMA it cannot see, without the wait states an MFMA needs
-// after a VALU write: deterministic wrong sums (round 3: the 9-cell rollout at two workgroups per CU; self-play of a 6 x 4 board with a
-// 32 -> 48 -> 32 stack, one visit count off in 14 of 126 records).  Those kernels take the intrinsic form (`EngineV<NC, false>`,
-// geometry -65); scripts/kernel_resources.sh shows the AGPR count of every instantiation.
-template <int NC, bool ASM_MFMA = true>
+// and AGPRs around every k-group).  NO kernel uses that form any more (round 3).  hipcc pads the wait states an MFMA needs after a
+// vector-ALU write of one of its operands for its own MFMAs, not for an asm string: the accumulator's zero-initialisation (v_mov) or the
+// reload of a value the allocator parked in an AGPR can land right in front of the asm MFMA.  Seen twice as deterministic wrong sums:
+// the 9-cell rollout at two workgroups per CU, and self-play of a 6 x 4 board with a 32 -> 48 -> 32 stack (one visit count off in 14 of
+// 126 records; every other shape tested was right).  scripts/scan_mfma_hazards.py looks for the pattern in the compiled kernels (an
+// operand written by one of the two vector instructions in front of an MFMA, no s_nop between): none with the intrinsic form; the
+// asm MFMAs of the other engines (tw_engine.hpp) take their operands from LDS / global loads and ReLUs that carry their own s_nop.
+template <int NC, bool ASM_MFMA = false>
 struct EngineV {
     static constexpr int NW = 4, THREADS = 256, EPB = GEN_COLS, NS = 4;
     static constexpr bool SPLIT = true;

@@ -18,7 +18,7 @@ namespace tw {
 template <int NC>
 __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a, uint16_t *obs16)
 {
-    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
+    using Eng = EngineV<NC, false>;      // (the MFMAs as the intrinsic: tw_engine_generic.hpp, ASM_MFMA)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, 1) rollout_big_kernel(const RolloutArgs a
 template <int NC>
 __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
 {
-    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
+    using Eng = EngineV<NC, false>;      // (the MFMAs as the intrinsic: tw_engine_generic.hpp, ASM_MFMA)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     eng.begin1(a.pol, lds);
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
 template <int NC>
 static int launch_solve_big_nc(const SolveArgs &a, hipStream_t s)
 {
-    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
+    using Eng = EngineV<NC, false>;      // (the MFMAs as the intrinsic: tw_engine_generic.hpp, ASM_MFMA)
     const uint64_t nb = (a.num_attempts + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("solve: bad attempt count %llu", (unsigned long long)a.num_attempts); return TW_ERR_INVALID; }
     const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) compact_obs16_kernel(const uint16_t *obs1
 template <int NC>
 static int launch_rollout_big_nc(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
-    using Eng = EngineV<NC, (NC <= BIG_NC)>;      // (above 25 cells the kernel parks registers in AGPRs: the MFMAs as the intrinsic, see tw_mcts_big.hip)
+    using Eng = EngineV<NC, false>;      // (the MFMAs as the intrinsic: tw_engine_generic.hpp, ASM_MFMA)
     const uint64_t nb = (a.num_episodes + Eng::EPB - 1) / Eng::EPB;
     if (nb == 0 || nb > 0x7fffffffull) { set_error("rollout: bad episode count %llu", (unsigned long long)a.num_episodes); return TW_ERR_INVALID; }
     const size_t lds_bytes = Eng::lds_floats(a.pol) * sizeof(float);
