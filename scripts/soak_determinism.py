@@ -12,7 +12,9 @@ def digest(d):
     out = []
     for k in sorted(t):
         x = t[k]
-        v = x.view(torch.uint8).to(torch.int64) if x.dtype in (torch.uint8, torch.int8) else x.contiguous().view(torch.int32).to(torch.int64)
+        if x.dtype in (torch.uint8, torch.int8): v = x.view(torch.uint8).to(torch.int64)
+        elif x.element_size() == 2: v = x.contiguous().view(torch.int16).to(torch.int64)          # two-byte obs ids (boards above 16 cells)
+        else: v = x.contiguous().view(torch.int32).to(torch.int64)
         w = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64) % 1000003
         out.append(int((v.reshape(-1) * w).sum().item()))
     return tuple(out)
