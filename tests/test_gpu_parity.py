@@ -361,6 +361,16 @@ def test_boards_of_17_to_64_cells_roll_out_on_the_device(tw, oracle):
                                        max_expand_depth=1, num_cores=32)
             oe = oracle.evaluate(oenv, op, 3000, det, ns, seed=7, arith=oracle.ARITH_CHAIN, det_math=True)
             assert f32_bits(ge[0]) == f32_bits(oe[0]) and f32_bits(ge[1]) == f32_bits(oe[1]), (w, h, det, ge, oe)
+        # ... and the MCTS-guided form (mcts_big_kernel in solve mode): greedy and sampled, both expansion depths
+        for det, ns, S, med in ((True, 1, 6, 1), (False, 2, 5, 2)):
+            ge = tw.collector.evaluate(genv, gp, num_episodes=60, deterministic=det, num_searches=ns, num_mcts_searches=S, seed=7, C=1.41,
+                                       max_expand_depth=med, num_cores=32)
+            oe = oracle.evaluate(oenv, op, 60, det, ns, num_mcts_searches=S, seed=7, Cc=1.41, max_expand_depth=med, arith=oracle.ARITH_CHAIN, det_math=True)
+            assert f32_bits(ge[0]) == f32_bits(oe[0]) and f32_bits(ge[1]) == f32_bits(oe[1]), (w, h, det, S, med, ge, oe)
+            with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):              # the host-stepped path gives the same numbers
+                he = tw.collector.evaluate(genv, gp, num_episodes=60, deterministic=det, num_searches=ns, num_mcts_searches=S, seed=7, C=1.41,
+                                           max_expand_depth=med, num_cores=32)
+            assert f32_bits(ge[0]) == f32_bits(he[0]) and f32_bits(ge[1]) == f32_bits(he[1])
         with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):                  # the host-stepped path (tw_ppo_collect_env)
             he = tw.collector.evaluate(genv, gp, num_episodes=300, deterministic=False, num_searches=2, num_mcts_searches=0, seed=7, C=1.41,
                                        max_expand_depth=1, num_cores=32)

@@ -1486,11 +1486,13 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
     // MCTS-guided inference (solve.rs:41-47): per-attempt node arenas for the search trees
     const bool mcts = prm->num_mcts_searches != 0;
     const uint64_t node_cap = 5ull + 4ull * prm->num_mcts_searches * (prm->max_expand_depth ? prm->max_expand_depth : 1u);
-    if (mcts && (node_cap > 0xffffffffull || A * node_cap * mcts_node_bytes() > (200ull << 30))) {
+    const bool big_mcts = mcts && sa.env.n_cells > 16;                   // boards of 17 .. 64 cells: tw_mcts_big.hip (32-byte nodes without a board)
+    const size_t node_bytes = big_mcts ? mcts_big_node_bytes() : mcts_node_bytes();
+    if (mcts && (node_cap > 0xffffffffull || A * node_cap * node_bytes > (200ull << 30))) {
         set_error("solve: MCTS arenas of %llu attempts x %llu nodes do not fit", (unsigned long long)A, (unsigned long long)node_cap);
         return TW_ERR_UNSUPPORTED;
     }
-    const size_t o_cnt = seg(mcts ? 128 : 0), o_arena = seg(mcts ? (size_t)(A * node_cap) * mcts_node_bytes() : 0);
+    const size_t o_cnt = seg(mcts ? 128 : 0), o_arena = seg(mcts ? (size_t)(A * node_cap) * node_bytes : 0);
     uint8_t *buf = nullptr;
     TW_HIP(hipMalloc((void **)&buf, cur ? cur : 256));
     sa.success = reinterpret_cast<float *>(buf + o_s); sa.total = reinterpret_cast<float *>(buf + o_r);
@@ -1510,7 +1512,7 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
         ma.reuse_mode = (uint32_t)launch_options().az_reuse;
         hipError_t me = hipMemsetAsync(buf + o_cnt, 0, 128, s);
         if (me != hipSuccess) { (void)hipFree(buf); return hip_fail(me, "hipMemsetAsync(eval counter)", __FILE__, __LINE__); }
-        rc = launch_mcts_f32(ma, s, nullptr, nullptr);
+        rc = big_mcts ? launch_mcts_big(ma, nullptr, s, nullptr, nullptr) : launch_mcts_f32(ma, s, nullptr, nullptr);
     } else rc = sa.env.n_cells > 16 ? launch_solve_big(sa, s) : launch_solve_f32(sa, s);
     std::vector<float> hs(A), hr(A); std::vector<uint32_t> hn(A);
     hipError_t e = hipSuccess;
@@ -1545,9 +1547,9 @@ extern "C" int tw_evaluate(const tw_puzzle_desc *env, const tw_policy *policy, c
 {
     if (!env || !policy || !prm || !success_rate || !mean_reward) { set_error("tw_evaluate: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
-    // boards of 17 .. 64 cells without MCTS: on the device (solve_big_kernel); everything else above 16 cells: the any-environment path (host env)
+    // boards of 17 .. 64 cells: on the device (solve_big_kernel; MCTS-guided: mcts_big_kernel); whatever they do not take: the any-environment path (host env)
     const uint64_t cells = (uint64_t)env->width * env->height;
-    const bool big_dev = cells > 16 && cells <= 64 && policy->dev.generic && prm->num_mcts_searches == 0 && prm->precision == TW_PREC_F32_EXACT &&
+    const bool big_dev = cells > 16 && cells <= 64 && policy->dev.generic && prm->precision == TW_PREC_F32_EXACT &&
                          (uint64_t)env->depth_slope * env->difficulty <= 1022 && env->max_depth != 0 && !launch_options().force_geom;
     if (cells > 16 && !big_dev) {
         uint64_t depth0 = 0;

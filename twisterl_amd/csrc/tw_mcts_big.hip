@@ -10,7 +10,9 @@
 //   * obs ids of the records go to their own array [E][t_pad][n_cells] (compact_obs16_kernel, as the PPO rollout of such boards);
 //   * plain form of the search: back-propagation through the parent links, no stored outputs, no persistent lanes -- this path is
 //     about being on the device at all (the host-stepped collectors of tw_env_generic.hip step the environment on the CPU).
-// Bit-equal to the oracle's native collector.  MCTS-guided evaluate / solve of such boards stay host-stepped.
+// Bit-equal to the oracle's native collector.  MctsArgs::solve.on: MCTS-guided inference instead (single_solve over predict_probs_mcts,
+// rust/src/rl/solve.rs:17-71 -- evaluate() with num_mcts_searches > 0), one column = one ATTEMPT, as in tw_mcts.hip; solve() from a
+// given state of such a board stays host-stepped.
 #include "tw_engine_generic.hpp"
 #include "tw_big_board.hpp"
 
@@ -51,7 +53,10 @@ __global__ void __launch_bounds__(256, 1) mcts_big_kernel(const MctsArgs a, uint
     const uint64_t e_local = (uint64_t)blockIdx.x * Eng::EPB + (uint64_t)j;
     const bool valid = e_local < a.num_episodes;
     const bool owner = valid && eng.h == 0 && eng.owns_lane();       // the lane that walks / mutates this column's tree
-    const uint64_t e_global = a.episode_offset + e_local;
+    const MctsSolve sv = a.solve;
+    // solve mode: column = ATTEMPT (episode, search); its draws are keyed like single_solve's (tw_solve.hip)
+    const uint64_t sv_ep = sv.on ? a.episode_offset + e_local / sv.num_searches : 0;
+    const uint64_t e_global = sv.on ? sv_ep * (uint64_t)sv.num_searches + e_local % sv.num_searches : a.episode_offset + e_local;
     BigNode *nodes = reinterpret_cast<BigNode *>(a.arena) + (valid ? e_local : 0) * (uint64_t)a.node_cap;
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     const uint64_t rec_base = e_local * (uint64_t)a.out.t_pad;
@@ -59,14 +64,16 @@ __global__ void __launch_bounds__(256, 1) mcts_big_kernel(const MctsArgs a, uint
 
     Lane st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;   // the episode's env (az.rs:56-57)
     if (owner) {                                                      // Env::reset (puzzle.rs:119-133)
-        for (int d = 0; d < env.difficulty; ++d) {
-            const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)d, STREAM_SCRAMBLE);
+        for (int d = 0; d < env.difficulty; ++d) {                    // (solve mode: env.reset() per episode, evaluate.rs:39,65)
+            const u32x4 w = rng_draw(a.seed, sv.on ? sv_ep : e_global, (uint32_t)d, STREAM_SCRAMBLE);
             big_step(st, env, (int)u32_below(w.x, 4u));
         }
         st.depth = env.depth0;
     }
     Lane leaf = st, cur = st;                                         // state whose evaluation is pending | state of `node`
     int      phase = owner ? BP_ROOT : BP_DONE;
+    if (sv.on && owner && big_final(st, ident)) phase = BP_DONE;      // `while !env.is_final()` (solve.rs:30)
+    float    total = 0.0f;                                            // solve mode: summed rewards (solve.rs:25-34)
     uint32_t it = 0, expanded = 0, node = 0, n_nodes = 0;
     int      t = 0;
     float    value = 0.0f;
@@ -212,6 +219,25 @@ __global__ void __launch_bounds__(256, 1) mcts_big_kernel(const MctsArgs a, uint
 #pragma unroll
                             for (int i = 0; i < 4; ++i) mp[i] = 1.0f / 4.0f;
                         }
+                        if (sv.on) {
+                            // solve.rs:31-58: total += reward; action = argmax | sample of the MCTS probs; step
+                            total = total + big_reward(st, ident, env);
+                            int action = 0;
+                            if (sv.deterministic) {
+                                float bv = mp[0];
+#pragma unroll
+                                for (int i = 1; i < 4; ++i) if (mp[i] > bv) { bv = mp[i]; action = i; }
+                            } else {
+                                const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_SOLVE);
+                                action = sample_weighted4(mp, 4, u32_to_unit(w.x));
+                            }
+                            if (sv.actions) sv.actions[e_local * (uint64_t)sv.act_pad + (uint64_t)t] = (uint8_t)action;
+                            big_step(st, env, action);
+                            ++t;
+                            if (big_final(st, ident)) { phase = BP_DONE; break; }
+                            phase = BP_ROOT; leaf = st;
+                            break;
+                        }
                         // az.rs:72-81: action = sample(mcts_probs); val = env.reward(); store the record
                         const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
                         const int action = sample_weighted4(mp, 4, u32_to_unit(w.x));
@@ -275,7 +301,15 @@ __global__ void __launch_bounds__(256, 1) mcts_big_kernel(const MctsArgs a, uint
         }
         publish();                                                    // (the mirror was read before the forward's first barrier)
     }
-    if (owner) atomicAdd(a.eval_count, evals);
+    if (owner) {
+        if (sv.on) {
+            total = total + big_reward(st, ident, env);                   // solve.rs:65-66
+            sv.success[e_local] = st.board == ident ? 1.0f : 0.0f;        // solve.rs:68
+            sv.total[e_local]   = total;
+            sv.n_steps[e_local] = (uint32_t)t;
+        }
+        atomicAdd(a.eval_count, evals);
+    }
     eng.end();
 }
 
@@ -301,7 +335,8 @@ int launch_mcts_big(const MctsArgs &a, uint16_t *obs16, hipStream_t s, uint32_t 
     const uint64_t need = 5ull + 4ull * a.num_searches * (a.max_expand_depth ? a.max_expand_depth : 1u);
     if (a.env.n_cells <= 16 || a.env.n_cells > 64 || a.env.width * a.env.height != a.env.n_cells || !a.pol.generic ||
         a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 || (a.pol.n_perms > 0 && !a.pol.obs_perms16) ||
-        a.out.t_pad < a.env.depth0 + 1 || !obs16 || !a.arena || !a.eval_count || a.node_cap < need || a.solve.on || a.queue || a.init_boards) {
+        (!a.solve.on && (a.out.t_pad < a.env.depth0 + 1 || !obs16)) || !a.arena || !a.eval_count || a.node_cap < need || a.queue || a.init_boards ||
+        (a.solve.on && (!a.solve.success || !a.solve.total || !a.solve.n_steps || a.solve.num_searches == 0 || a.solve.from_state))) {
         set_error("mcts (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d generic=%d node_cap=%u need=%llu)", a.env.n_cells,
                   a.pol.obs_size, a.pol.n_actions, a.pol.generic, a.node_cap, (unsigned long long)need);
         return TW_ERR_UNSUPPORTED;
