@@ -887,7 +887,11 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     // (round 3, with the table: minimum 16 / 32 / 48 / 80 / 120 / 200 k cycles -> 4,096 x 100 (eight walkers) 25.3 / 22.4 / 21.2 / 19.9 / 20.2 / 22.7 ms,
     //  4,096 x 1,000 (four) 125 / 126 / 124 / 124 / 132 / 144, 1,024 x 1,000 80.3 / 80.5 / 81.6 / 84.5 / 88.8 / 98.2: eight walkers share a forward
     //  of 59 k cycles and wait a little longer for it)
-    if (NWK == 8 && launch_options().az_tree_budget_min == 0 && b.tree_budget > 80000u) b.tree_budget_min = 80000u;
+    // (re-measured at the end of round 3 -- streaks not cut short, longest-looking episodes first --, minimum 32 / 48 / 64 / 80 / 100 / 140 k cycles, eight
+    //  walkers: 4,096 x 100 17.3 / 16.6 / 16.8 / 17.4 / 18.4 / 20.0 ms, 6,144 x 100 26.7 / 24.0 / 24.2 / 24.4 / 24.9 / 26.3, 16,384 x 100 56.1 / 53.0 / 51.6 / 52.6 /
+    //  53.2 / 57.4; two and four walkers, 24 / 36 / 48 / 64 / 90 k: 4,096 x 1,000 96.6 / 97.9 / 100.4 / 100.7 / 102.1, 2,048 x 100 12.7 / 12.5 / 12.2 / 12.7 / 13.2,
+    //  1,024 x 1,000 76.1 / 76.9 / 77.3 / 77.8 / 81.1, 1,024 x 100 10.3 / 10.3 / 10.5 / 10.6 / 11.1: 48 k stays, eight walkers take 56 k)
+    if (NWK == 8 && launch_options().az_tree_budget_min == 0 && b.tree_budget > 56000u) b.tree_budget_min = 56000u;
     const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK)) * sizeof(float);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
