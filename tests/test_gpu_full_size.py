@@ -137,6 +137,38 @@ def test_config5_selfplay_full_size_vs_oracle(tw, oracle, searches, n_sample):
         assert np.array_equal(f32_bits(sl("remaining_values")), f32_bits(o.additional_data["remaining_values"])), e
 
 
+def test_reference_default_selfplay_512x1000_vs_oracle(tw, oracle):
+    """The reference's own default (src/twisterl/defaults.py:84-88: 512 episodes x 1,000 searches) as bench.py's side entry runs it -- no
+    twists, one walker per workgroup on long streaks of searches served from its table, two episodes per CU taken longest-looking
+    first: determinism, the record identities, sampled episodes (among them the longest ones) bit-equal to the oracle."""
+    import twisterl_amd
+    gp, op = _bench_policy(oracle, twists=False)
+    E, S_, D = 512, 1000, 8
+    env, oenv = tw.env.Puzzle(4, 4, D, 2, 256), oracle.Puzzle(4, 4, D, 2, 256)
+    coll = tw.collector.AZCollector(E, S_, 1.41, 1, 32)
+    g = coll.collect(env, gp, seed=2)
+    t = g.to_torch()
+    L = t["ep_len"].cpu().numpy().astype(np.int64)
+    S = t["ep_start"].cpu().numpy().astype(np.int64)
+    assert L.sum() == len(g) and L.min() >= 1 and L.max() == 2 * D + 1
+    cus = twisterl_amd.device_info()["compute_units"]
+    assert (g.stats["rollout_blocks"], g.stats["rollout_threads"]) == (min(cus, E), 256)
+    assert len(g) <= g.stats["forward_evals"] <= len(g) * (S_ + 1) and g.stats["reused_evals"] > g.stats["forward_evals"] // 2
+    h = coll.collect(env, gp, seed=2).to_torch()
+    for k in t:
+        assert torch.equal(t[k], h[k]), k
+    del h
+    longest = [int(e) for e in np.argsort(-L, kind="stable")[:2]]
+    for e in sorted(set(longest + _sample_episodes(E, 4, seed=9))):
+        s, ln = int(S[e]), int(L[e])
+        o = oracle.az_collect(oenv, op, 1, S_, 1.41, 1, seed=2, episode_offset=e, arith=oracle.ARITH_CHAIN, merge_order=False, det_math=True)
+        assert ln == int(o.ep_len[0]), e
+        sl = lambda k: t[k][s:s + ln].cpu().numpy()
+        assert np.array_equal(sl("obs").astype(np.int64), o.obs), e
+        assert np.array_equal(f32_bits(sl("logits")), f32_bits(o.logits)), e
+        assert np.array_equal(f32_bits(sl("remaining_values")), f32_bits(o.additional_data["remaining_values"])), e
+
+
 @pytest.mark.parametrize("E,searches,n_sample,threads", [(65_536, 32, 26, 512), (16_384, 100, 24, 256)])
 def test_selfplay_lane_per_episode_kernel_full_size_vs_oracle(tw, oracle, request, E, searches, n_sample, threads):
     """`mcts_f32_kernel` (one lane pair per episode, tw_mcts.hip) at the sizes its numbers are quoted on: 65,536 x 32 (every
