@@ -371,6 +371,19 @@ def test_boards_of_17_to_64_cells_roll_out_on_the_device(tw, oracle):
                 he = tw.collector.evaluate(genv, gp, num_episodes=60, deterministic=det, num_searches=ns, num_mcts_searches=S, seed=7, C=1.41,
                                            max_expand_depth=med, num_cores=32)
             assert f32_bits(ge[0]) == f32_bits(he[0]) and f32_bits(ge[1]) == f32_bits(he[1])
+        # solve() from a given state, plain and MCTS-guided: the oracle's (success, reward) and action list, the caller's env untouched
+        start = oracle.Puzzle(w, h, 5, 2, 256); start.reset(seed=9, episode=3)
+        state = start.get_state()
+        genv.set_state(state); oenv.set_state(state)
+        before = genv.get_state()
+        for det, ns, S in ((True, 1, 0), (False, 4, 0), (False, 2, 4)):
+            (gs, gr), gact = tw.collector.solve(genv, gp, det, ns, S, 1.41, 1, seed=5)
+            (os_, or_), oact = oracle.solve(oenv, op, det, ns, num_mcts_searches=S, Cc=1.41, max_expand_depth=1, seed=5, arith=oracle.ARITH_CHAIN, det_math=True)
+            assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact, (w, h, det, ns, S)
+            with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):
+                (hs, hr), hact = tw.collector.solve(genv, gp, det, ns, S, 1.41, 1, seed=5)
+            assert (gs, f32_bits(gr)) == (hs, f32_bits(hr)) and gact == hact
+        assert genv.get_state() == before
         with _lib.launch_option(_lib.TW_OPT_FORCE_GEOM, 1):                  # the host-stepped path (tw_ppo_collect_env)
             he = tw.collector.evaluate(genv, gp, num_episodes=300, deterministic=False, num_searches=2, num_mcts_searches=0, seed=7, C=1.41,
                                        max_expand_depth=1, num_cores=32)

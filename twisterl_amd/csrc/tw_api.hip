@@ -1462,16 +1462,18 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
     sa.num_attempts = A; sa.episode_offset = episode_offset; sa.seed = prm->seed;
     sa.num_searches = prm->num_searches; sa.deterministic = prm->deterministic ? 1u : 0u;
     sa.from_state = from_state ? 1u : 0u;
+    std::vector<uint8_t> start_cells;
     if (from_state) {
         // the reference's set_state takes any vector (puzzle.rs:107-117); the device board is n_cells nibbles holding a
         // permutation of 0..n_cells-1 whose blank is where zero_location says -- anything else is refused here
         if (start->state.size() != (size_t)envc.n_cells) { set_error("solve: state has %zu entries, the board %d cells", start->state.size(), envc.n_cells); return TW_ERR_INVALID; }
-        uint64_t b = 0; uint32_t seen = 0;
+        uint64_t b = 0, seen = 0;
         for (size_t i = 0; i < start->state.size(); ++i) {
             const int64_t v = start->state[i];
-            if (v < 0 || v >= envc.n_cells || ((seen >> v) & 1u)) { set_error("solve: state is not a permutation of 0..%d (entry %zu = %lld)", envc.n_cells - 1, i, (long long)v); return TW_ERR_INVALID; }
-            seen |= 1u << v;
-            b |= (uint64_t)v << (4 * i);
+            if (v < 0 || v >= envc.n_cells || ((seen >> v) & 1ull)) { set_error("solve: state is not a permutation of 0..%d (entry %zu = %lld)", envc.n_cells - 1, i, (long long)v); return TW_ERR_INVALID; }
+            seen |= 1ull << v;
+            if (i < 16) b |= (uint64_t)v << (4 * i);                          // (boards above 16 cells: one byte per cell, start_cells below)
+            start_cells.push_back((uint8_t)v);
         }
         const int64_t zi = start->zy * start->width + start->zx;
         if (zi < 0 || zi >= envc.n_cells || start->state[(size_t)zi] != 0) { set_error("solve: zero_location (%lld, %lld) does not hold the blank", (long long)start->zx, (long long)start->zy); return TW_ERR_INVALID; }
@@ -1482,7 +1484,8 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
     hipStream_t s = current_stream();
     size_t cur = 0;
     auto seg = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
-    const size_t o_s = seg(A * 4), o_r = seg(A * 4), o_n = seg(A * 4), o_a = seg(want_actions ? A * (size_t)sa.t_pad : 0);
+    const size_t o_s = seg(A * 4), o_r = seg(A * 4), o_n = seg(A * 4), o_a = seg(want_actions ? A * (size_t)sa.t_pad : 0),
+                 o_cells = seg(from_state && envc.n_cells > 16 ? 64 : 0);
     // MCTS-guided inference (solve.rs:41-47): per-attempt node arenas for the search trees
     const bool mcts = prm->num_mcts_searches != 0;
     const uint64_t node_cap = 5ull + 4ull * prm->num_mcts_searches * (prm->max_expand_depth ? prm->max_expand_depth : 1u);
@@ -1497,6 +1500,12 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
     TW_HIP(hipMalloc((void **)&buf, cur ? cur : 256));
     sa.success = reinterpret_cast<float *>(buf + o_s); sa.total = reinterpret_cast<float *>(buf + o_r);
     sa.n_steps = reinterpret_cast<uint32_t *>(buf + o_n); sa.actions = want_actions ? buf + o_a : nullptr;
+    if (from_state && envc.n_cells > 16) {
+        hipError_t ce = hipMemcpyAsync(buf + o_cells, start_cells.data(), start_cells.size(), hipMemcpyHostToDevice, s);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(s);                 // (start_cells is a local)
+        if (ce != hipSuccess) { (void)hipFree(buf); return hip_fail(ce, "hipMemcpyAsync(start state)", __FILE__, __LINE__); }
+        sa.start_cells = buf + o_cells;
+    }
     int rc;
     if (mcts) {
         MctsArgs ma{};
@@ -1505,7 +1514,7 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
         ma.arena = reinterpret_cast<MctsNode *>(buf + o_arena); ma.node_cap = (uint32_t)node_cap;
         ma.eval_count = reinterpret_cast<unsigned long long *>(buf + o_cnt);
         ma.solve.on = 1; ma.solve.deterministic = sa.deterministic; ma.solve.num_searches = sa.num_searches;
-        ma.solve.from_state = sa.from_state; ma.solve.start_board = sa.start_board; ma.solve.start_zx = sa.start_zx;
+        ma.solve.from_state = sa.from_state; ma.solve.start_board = sa.start_board; ma.solve.start_zx = sa.start_zx; ma.solve.start_cells = sa.start_cells;
         ma.solve.start_zy = sa.start_zy; ma.solve.start_depth = sa.start_depth;
         ma.solve.success = sa.success; ma.solve.total = sa.total; ma.solve.n_steps = sa.n_steps; ma.solve.actions = sa.actions;
         ma.solve.act_pad = sa.t_pad;
@@ -1578,7 +1587,17 @@ extern "C" int tw_solve(const tw_puzzle *env, const tw_policy *policy, const tw_
 {
     if (!env || !policy || !prm || !success || !reward) { set_error("tw_solve: null argument"); return TW_ERR_INVALID; }
     int rc = require_device(); if (rc) return rc;
-    if (env->state.size() > 16) {                                          // boards above 16 cells: the any-environment path (host env)
+    // boards of 17 .. 64 cells: on the device too (solve_big_kernel / mcts_big_kernel); whatever they do not take: the any-environment path (host env)
+    bool big_dev = env->state.size() > 16 && env->state.size() <= 64 && policy->dev.generic && prm->precision == TW_PREC_F32_EXACT &&
+                   env->depth >= 0 && env->depth <= 1022 && env->max_depth != 0 && !launch_options().force_geom &&
+                   env->width * env->height == (int64_t)env->state.size();
+    if (big_dev) {                                                         // (the device board is a permutation with the blank where zero_location says; set_state
+        uint64_t seen = 0;                                                 //  takes any vector, puzzle.rs:107-117: anything else steps on the host as before)
+        for (int64_t v : env->state) { if (v < 0 || v >= (int64_t)env->state.size() || ((seen >> v) & 1ull)) { big_dev = false; break; } seen |= 1ull << v; }
+        const int64_t zi = env->zy * env->width + env->zx;
+        if (big_dev && (zi < 0 || zi >= (int64_t)env->state.size() || env->state[(size_t)zi] != 0)) big_dev = false;
+    }
+    if (env->state.size() > 16 && !big_dev) {
         tw_puzzle_desc bd; tw_puzzle_get_desc(env, &bd);
         uint64_t depth0 = 0;
         rc = big_board_checks(&bd, prm->precision, &depth0); if (rc) return rc;
@@ -1590,7 +1609,7 @@ extern "C" int tw_solve(const tw_puzzle *env, const tw_policy *policy, const tw_
         return rc;
     }
     tw_puzzle_desc d; tw_puzzle_get_desc(env, &d);
-    PuzzleConsts envc; rc = make_env_consts(&d, &envc); if (rc) return rc;
+    PuzzleConsts envc; rc = make_env_consts(&d, &envc, 64); if (rc) return rc;
     if (env->depth > 4096) { set_error("tw_solve: depth %lld too large", (long long)env->depth); return TW_ERR_UNSUPPORTED; }
     std::vector<float> bs, br; std::vector<uint8_t> acts;
     rc = run_solve(envc, policy, prm, 1, 0, true, env, (int)env->depth + 1, true, bs, br, acts);

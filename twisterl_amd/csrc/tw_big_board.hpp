@@ -23,6 +23,7 @@ struct Board5 {
         const u128 tile = (b >> (5 * ti)) & (u128)31;                       // cell zi holds 0
         b = (b & ~((u128)31 << (5 * ti))) | (tile << (5 * zi));
     }
+    __device__ void put(int i, uint32_t tile) { b = (b & ~((u128)31 << (5 * i))) | ((u128)(tile & 31u) << (5 * i)); }
     __device__ bool operator==(const Board5 &o) const { return b == o.b; }
 };
 
@@ -63,6 +64,12 @@ struct Board8 {
             w[k] = v;
         }
     }
+    __device__ void put(int i, uint32_t tile)
+    {
+        const uint32_t clr = ~(255u << (8 * (i & 3))), val = (tile & 255u) << (8 * (i & 3));
+#pragma unroll
+        for (int k = 0; k < NW; ++k) w[k] = (k == (i >> 2)) ? ((w[k] & clr) | val) : w[k];
+    }
     __device__ bool operator==(const Board8 &o) const
     {
         uint32_t d = 0;
@@ -71,6 +78,15 @@ struct Board8 {
         return d == 0;
     }
 };
+
+// a board from one byte per cell (solve() from a given state)
+template <typename Board>
+__device__ inline Board big_board_from_cells(const uint8_t *cells, int n_cells, const Board &solved)
+{
+    Board b = solved;                                   // (cell i of the solved board holds tile i: slide tile by tile into place would be
+    for (int i = 0; i < n_cells; ++i) b.put(i, cells[i]);   //  the long way round -- every cell is simply overwritten)
+    return b;
+}
 
 template <int NC> struct BoardOf { using T = Board8<NC>; };
 template <> struct BoardOf<BIG_NC> { using T = Board5; };

@@ -467,6 +467,7 @@ struct SolveArgs {
     uint32_t     num_searches, deterministic;
     uint32_t     from_state;       // 1: every attempt starts from (start_board, start_depth) -- solve()
     uint64_t     start_board; int32_t start_zx, start_zy, start_depth;
+    const uint8_t *start_cells;    // boards above 16 cells: the start state, one byte per cell (device memory)
     float       *success;          // [num_attempts] 1.0 / 0.0
     float       *total;            // [num_attempts] summed rewards (solve.rs:25-34,65-66)
     uint32_t    *n_steps;          // [num_attempts]
@@ -481,6 +482,7 @@ struct MctsNode;   // tw_mcts.hip
 struct MctsSolve {
     uint32_t on, deterministic, num_searches /* attempts per episode */, from_state;
     uint64_t start_board; int32_t start_zx, start_zy, start_depth;
+    const uint8_t *start_cells;    // boards above 16 cells: the start state, one byte per cell (device memory)
     float   *success, *total;      // [attempts]
     uint32_t *n_steps;             // [attempts]
     uint8_t *actions;              // [attempts][act_pad] or null

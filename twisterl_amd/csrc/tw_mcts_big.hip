@@ -11,8 +11,7 @@
 //   * plain form of the search: back-propagation through the parent links, no stored outputs, no persistent lanes -- this path is
 //     about being on the device at all (the host-stepped collectors of tw_env_generic.hip step the environment on the CPU).
 // Bit-equal to the oracle's native collector.  MctsArgs::solve.on: MCTS-guided inference instead (single_solve over predict_probs_mcts,
-// rust/src/rl/solve.rs:17-71 -- evaluate() with num_mcts_searches > 0), one column = one ATTEMPT, as in tw_mcts.hip; solve() from a
-// given state of such a board stays host-stepped.
+// rust/src/rl/solve.rs:17-71 -- evaluate() and solve() with num_mcts_searches > 0), one column = one ATTEMPT, as in tw_mcts.hip.
 #include "tw_engine_generic.hpp"
 #include "tw_big_board.hpp"
 
@@ -63,7 +62,9 @@ __global__ void __launch_bounds__(256, 1) mcts_big_kernel(const MctsArgs a, uint
     uint32_t *mir = reinterpret_cast<uint32_t *>(lds + Eng::lds_floats(a.pol)) + j * MW;     // the pending leaf of column j
 
     Lane st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;   // the episode's env (az.rs:56-57)
-    if (owner) {                                                      // Env::reset (puzzle.rs:119-133)
+    if (owner && sv.on && sv.from_state) {                            // solve(): every attempt clones the caller's env (solve.rs:85)
+        st.board = big_board_from_cells(sv.start_cells, nc, ident); st.zx = sv.start_zx; st.zy = sv.start_zy; st.depth = sv.start_depth;
+    } else if (owner) {                                               // Env::reset (puzzle.rs:119-133)
         for (int d = 0; d < env.difficulty; ++d) {                    // (solve mode: env.reset() per episode, evaluate.rs:39,65)
             const u32x4 w = rng_draw(a.seed, sv.on ? sv_ep : e_global, (uint32_t)d, STREAM_SCRAMBLE);
             big_step(st, env, (int)u32_below(w.x, 4u));
@@ -336,7 +337,7 @@ int launch_mcts_big(const MctsArgs &a, uint16_t *obs16, hipStream_t s, uint32_t 
     if (a.env.n_cells <= 16 || a.env.n_cells > 64 || a.env.width * a.env.height != a.env.n_cells || !a.pol.generic ||
         a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 || (a.pol.n_perms > 0 && !a.pol.obs_perms16) ||
         (!a.solve.on && (a.out.t_pad < a.env.depth0 + 1 || !obs16)) || !a.arena || !a.eval_count || a.node_cap < need || a.queue || a.init_boards ||
-        (a.solve.on && (!a.solve.success || !a.solve.total || !a.solve.n_steps || a.solve.num_searches == 0 || a.solve.from_state))) {
+        (a.solve.on && (!a.solve.success || !a.solve.total || !a.solve.n_steps || a.solve.num_searches == 0 || (a.solve.from_state && !a.solve.start_cells)))) {
         set_error("mcts (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d generic=%d node_cap=%u need=%llu)", a.env.n_cells,
                   a.pol.obs_size, a.pol.n_actions, a.pol.generic, a.node_cap, (unsigned long long)need);
         return TW_ERR_UNSUPPORTED;

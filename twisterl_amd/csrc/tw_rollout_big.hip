@@ -108,7 +108,9 @@ __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
     const uint64_t ep  = a.episode_offset + att / a.num_searches;                    // episode: keys the start state
     const uint64_t key = ep * (uint64_t)a.num_searches + att % a.num_searches;       // keys this attempt's draws
     BigLaneT<Board> st; st.board = ident; st.zx = 0; st.zy = 0; st.depth = 0;
-    if (valid) {                                                                      // env.reset() per episode (evaluate.rs:39,65)
+    if (valid && a.from_state) {                                                      // solve(): every attempt clones the caller's env (solve.rs:85)
+        st.board = big_board_from_cells(a.start_cells, nc, ident); st.zx = a.start_zx; st.zy = a.start_zy; st.depth = a.start_depth;
+    } else if (valid) {                                                               // env.reset() per episode (evaluate.rs:39,65)
         for (int d = 0; d < env.difficulty; ++d) {
             const u32x4 w = rng_draw(a.seed, ep, (uint32_t)d, STREAM_SCRAMBLE);
             big_step(st, env, (int)u32_below(w.x, 4u));
@@ -152,6 +154,7 @@ __global__ void __launch_bounds__(256, 1) solve_big_kernel(const SolveArgs a)
                 const u32x4 w = rng_draw(a.seed, key, (uint32_t)t, STREAM_SOLVE);
                 action = sample_weighted4(probs, 4, u32_to_unit(w.x));
             }
+            if (a.actions && writer) a.actions[att * (uint64_t)a.t_pad + (uint64_t)t] = (uint8_t)action;
             big_step(st, env, action);                                                // solve.rs:56
             ++t;
             if (st.depth == 0 || st.board == ident) alive = false;
@@ -183,7 +186,8 @@ static int launch_solve_big_nc(const SolveArgs &a, hipStream_t s)
 int launch_solve_big(const SolveArgs &a, hipStream_t s)
 {
     if (a.env.n_cells <= 16 || a.env.n_cells > 64 || !a.pol.generic || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.n_actions != 4 ||
-        (a.pol.n_perms > 0 && !a.pol.obs_perms16) || a.num_searches == 0 || !a.success || !a.total || !a.n_steps || a.actions || a.from_state) {
+        (a.pol.n_perms > 0 && !a.pol.obs_perms16) || a.num_searches == 0 || !a.success || !a.total || !a.n_steps || (a.actions && a.t_pad < 1) ||
+        (a.from_state && !a.start_cells)) {
         set_error("evaluate (boards above 16 cells): unsupported shape (n_cells=%d obs_size=%d actions=%d)", a.env.n_cells, a.pol.obs_size, a.pol.n_actions);
         return TW_ERR_UNSUPPORTED;
     }
