@@ -817,8 +817,8 @@ def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, h
 
 
 def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_busy(tw, oracle):
-    """tw_mcts_deep.hip: one walker x 16 columns per workgroup up to 2 episodes per CU; on the 32-column engine two x 16 up to 3.5,
-    four x 8 beyond, and beyond ten (short searches) eight x 4 in workgroups of eight waves -- at most
+    """tw_mcts_deep.hip, short searches: one walker x 16 columns per workgroup up to 2 episodes per CU, two x 8 up to 4.5, four x 4
+    beyond, and beyond ten eight x 2 in workgroups of eight waves (from 400 searches on: one up to 3, two below 8) -- at most
     one workgroup per CU, the rest of the episodes comes off the queue.  The parity cases of test_az_collect_bit_exact_vs_oracle
     run all of them; this pins the launches the workgroup shape tells apart, and every pinned shape (TW_OPT_AZ_VARIANT: 4 / 3 /
     5 / 6 = one / two / four / eight walkers, + 16 / + 32 = 16- / 32-column engine) gives the same bytes as the automatic choice."""

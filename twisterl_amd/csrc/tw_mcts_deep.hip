@@ -837,7 +837,14 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     DeepShape sh;
     // (round 3, ms for two / four walkers: 600 x 100 11.7 / 13.1, 768 x 100 12.7 / 13.1, 900 x 100 13.2 / 13.2, 1,024 x 100 14.1 / 13.1, 768 x 1,000 93.2 / 90.6,
     //  1,024 x 1,000 100.5 / 91.3: four as soon as they fill every CU, and always for long searches)
-    sh.walkers = num_episodes <= 2 * avail ? 1 : ((2 * num_episodes < 7 * avail && num_searches < 512) ? 2 : 4);
+    // (end of round 3 -- streaks not cut short, longest-looking episodes first: rounds through the queue cost little now, sharing a forward costs
+    //  what it did --, ms for one / two / four walkers: x 1,000: 640 61.4 / 65.5 / -, 768 64.2 / 66.3 / 71.2, 1,024 - / 72.5 / 77.8, 1,280 - / 75.8 / 81.8,
+    //  1,536 - / 75.6 / 81.7, 2,048 - / 83.2 / 83.0, 4,096 - / 127 / 98.4; x 400: 1,024 - / 32.4 / 34.9, 1,536 - / 33.1 / 36.5; x 100: 640 9.2 / 8.9 / -,
+    //  768 11.7 / 9.3 / 10.7, 1,024 - / 9.8 / 10.5, 1,280 - / 11.7 / 11.1, 1,536 - / 15.1 / 11.3)
+    const bool long_search = num_searches >= 400;
+    if (num_episodes <= (long_search ? 3 : 2) * avail) sh.walkers = 1;
+    else if (long_search ? num_episodes < 8 * avail : 2 * num_episodes <= 9 * avail) sh.walkers = 2;
+    else sh.walkers = 4;
     if (num_searches < 800 && num_episodes > 10 * avail) sh.walkers = 8;     // (eight x 2 columns / four x 4 on the 16-column engine: 4,096 x 400 56.4 / 60.3 ms, x 600 78.6 / 83.3, x 1,000 128.7 / 126.6, 8,192 x 400 78.6 / 98.6)
     // earlier:     // (with the 80 k budget below: 4,096 x 200 35.1 / 37.7 ms for eight / four, 8,192 x 200 54.8 / 61.7, 4,096 x 400 64.3 / 59.4)
     // (before that budget, eight / four walkers, ms: 3,072 x 100 18.9 / 19.2, 4,096 x 100 21.8 / 23.5, 4,096 x 200 37.8 / 37.4, 4,096 x 400 66.2 / 62.1)
