@@ -787,8 +787,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
-// The deep shape serves AlphaZero self-play of up to CUs x 16 episodes (4,096 on an MI355X: the reference's per-GPU batch; up to
-// CUs x 48 with longer searches) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
+// The deep shape serves AlphaZero self-play of up to CUs x 8 episodes (short searches) .. CUs x 256 (from 100 searches on: 65,536 on
+// an MI355X; the reference's per-GPU batch is 4,096) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
 // runs the lane-per-episode kernel of tw_mcts.hip.  Measured (scripts/bench_az.py, Puzzle-15, 512/256 policy, difficulty 8;
 // walker kernel vs lane-per-episode kernel, end of round 2):
 //   1,024 x 100: 14.1 vs 48.9 ms    1,024 x 1,000: 115 vs 498 ms    4,096 x 100: 26.4 vs 42.3 ms    4,096 x 1,000: 174 vs 509 ms
@@ -808,8 +808,11 @@ bool mcts_deep_applies(const MctsArgs &a)
     // round 3 (board-keyed output table, best-child links; walker with eight per workgroup / lane-per-episode, ms): 16,384 x 100 63.7 / 75.5,
     // 32,768 x 100 117 / 141, 8,192 x 400 96.5 / 235, 8,192 x 32 15.3 / 17.7, 16,384 x 32 27.3 / 25.2, 6,144 x 16 7.7 / 9.0, 8,192 x 16 9.6 / 9.1,
     // 4,096 x 8 4.1 / 3.6
+    // end of round 3 (streaks not cut short, longest-looking episodes first, 56 k wait budget): 49,152 x 100 154.9 / 193.8, 65,536 x 100 203 / 233, 131,072 x 100
+    // 395 / 291, 24,576 x 48 49.8 / 57.0, 32,768 x 48 65.4 / 66.8, 65,536 x 48 124 / 108, 32,768 x 64 79.4 / 88.7, 131,072 x 64 294 / 186, 12,288 x 32 20.3 / 19.8,
+    // 16,384 x 32 26.1 / 25.3, 8,192 x 16 9.0 / 9.2, 12,288 x 16 12.5 / 10.3, 4,096 x 8 4.0 / 3.6
     const uint32_t S = a.num_searches;
-    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 128u : (S >= 48 ? 48u : (S >= 32 ? 32u : (S >= 16 ? 24u : 8u))));
+    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 256u : (S >= 48 ? 128u : (S >= 32 ? 32u : (S >= 16 ? 24u : 8u))));
 }
 
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
