@@ -811,8 +811,11 @@ bool mcts_deep_applies(const MctsArgs &a)
     // end of round 3 (streaks not cut short, longest-looking episodes first, 56 k wait budget): 49,152 x 100 154.9 / 193.8, 65,536 x 100 203 / 233, 131,072 x 100
     // 395 / 291, 24,576 x 48 49.8 / 57.0, 32,768 x 48 65.4 / 66.8, 65,536 x 48 124 / 108, 32,768 x 64 79.4 / 88.7, 131,072 x 64 294 / 186, 12,288 x 32 20.3 / 19.8,
     // 16,384 x 32 26.1 / 25.3, 8,192 x 16 9.0 / 9.2, 12,288 x 16 12.5 / 10.3, 4,096 x 8 4.0 / 3.6
+    // ... and with the shape the automatic choice takes there (eight walkers on the 16-column engine; the pinned variant 6 is the 32-column one), walker /
+    // lane-per-episode, ms: 65,536 x 100 181.7 / 233, 98,304 x 100 266.7 / 255.9, 49,152 x 48 86.1 / 97.7, 65,536 x 48 112.6 / 108.2, 65,536 x 64 137.0 / 145.9,
+    // 16,384 x 32 24.5 / 25.3, 24,576 x 32 34.7 / 37.7, 8,192 x 16 8.5 / 9.2, 12,288 x 16 11.9 / 10.3, 6,144 x 24 9.0 / 13.3, 4,096 x 8 3.61 / 3.56
     const uint32_t S = a.num_searches;
-    return a.num_episodes <= (uint64_t)device_cus() * (S >= 100 ? 256u : (S >= 48 ? 128u : (S >= 32 ? 32u : (S >= 16 ? 24u : 8u))));
+    return a.num_episodes <= (uint64_t)device_cus() * (S >= 64 ? 256u : (S >= 48 ? 192u : (S >= 32 ? 96u : (S >= 16 ? 32u : 8u))));
 }
 
 // Shape of a launch: walkers per workgroup and engine width.  As few walkers as keep every CU busy -- with fewer walkers each one
