@@ -816,6 +816,36 @@ def test_mcts_guided_evaluate_and_solve_match_oracle(tw, oracle, w, diff, emb, h
         assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact
 
 
+def test_mcts_guided_evaluate_on_the_walker_kernel(tw, oracle):
+    """MCTS-guided evaluate / solve of the MFMA policy shapes run the walker kernel in its solve mode (tw_mcts_deep.hip, SOLVE: one walker
+    per attempt, persistent, the episode queue; the reference's `mcts_100` evaluation: 35.7 -> 6.0 ms): one, two and four walkers per
+    workgroup with rounds through the queue, attempts that start in a final state (difficulty 1: a scramble move into the wall leaves the
+    board solved), greedy and sampled with several attempts per episode, both expansion depths -- the oracle's numbers, and the same as
+    the lane-per-episode kernel (TW_OPT_AZ_VARIANT 2); solve() from a state with its action list."""
+    import twisterl_amd
+    cus = twisterl_amd.device_info()["compute_units"]
+    gp, op = _pair(oracle, 9, 6, 64, 128, twists=True, scale=3.0)
+    for diff, n_ep, det, ns, S, med in ((1, 40, True, 1, 5, 1), (3, cus + 9, False, 2, 4, 1), (2, 2 * cus + 5, False, 3, 4, 2), (3, 3 * cus + 1, True, 5, 3, 1)):
+        genv, oenv = tw.env.Puzzle(3, 3, diff, 2, 256), oracle.Puzzle(3, 3, diff, 2, 256)
+        kw = dict(num_episodes=n_ep, deterministic=det, num_searches=ns, num_mcts_searches=S, seed=3, C=1.41, max_expand_depth=med, num_cores=32)
+        g = tw.collector.evaluate(genv, gp, **kw)
+        with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, 2):
+            l = tw.collector.evaluate(genv, gp, **kw)
+        assert f32_bits(g[0]) == f32_bits(l[0]) and f32_bits(g[1]) == f32_bits(l[1]), (diff, n_ep, g, l)
+        if n_ep <= 2 * cus + 5:
+            o = oracle.evaluate(oenv, op, n_ep, det, ns, num_mcts_searches=S, seed=3, Cc=1.41, max_expand_depth=med, arith=oracle.ARITH_CHAIN, det_math=True)
+            assert f32_bits(g[0]) == f32_bits(o[0]) and f32_bits(g[1]) == f32_bits(o[1]), (diff, n_ep, g, o)
+    genv, oenv = tw.env.Puzzle(3, 3, 4, 2, 256), oracle.Puzzle(3, 3, 4, 2, 256)
+    start = oracle.Puzzle(3, 3, 4, 2, 256); start.reset(seed=2, episode=5)
+    state = start.get_state()
+    genv.set_state(state); oenv.set_state(state)
+    for det, ns, S in ((True, 1, 8), (False, 6, 5)):
+        (gs, gr), gact = tw.collector.solve(genv, gp, det, ns, S, 1.41, 1, seed=5)
+        (os_, or_), oact = oracle.solve(oenv, op, det, ns, num_mcts_searches=S, Cc=1.41, max_expand_depth=1, seed=5, arith=oracle.ARITH_CHAIN, det_math=True)
+        assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gact == oact
+    assert genv.get_state() == state
+
+
 def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_busy(tw, oracle):
     """tw_mcts_deep.hip, short searches: one walker x 16 columns per workgroup up to 2 episodes per CU, two x 8 up to 4.5, four x 4
     beyond, and beyond ten eight x 2 in workgroups of eight waves (from 400 searches on: one up to 3, two below 8) -- at most

@@ -1495,7 +1495,25 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
         set_error("solve: MCTS arenas of %llu attempts x %llu nodes do not fit", (unsigned long long)A, (unsigned long long)node_cap);
         return TW_ERR_UNSUPPORTED;
     }
-    const size_t o_cnt = seg(mcts ? 128 : 0), o_arena = seg(mcts ? (size_t)(A * node_cap) * node_bytes : 0);
+    // few deep searches on the MFMA policy shapes: the walker kernel (tw_mcts_deep.hip) in its solve mode -- one walker per attempt, persistent
+    MctsArgs ma{};
+    bool deep = false; uint64_t walkers = 0; uint32_t tbl_entries = 0;
+    if (mcts) {
+        ma.env = envc; ma.pol = sa.pol; ma.num_episodes = A; ma.episode_offset = episode_offset; ma.seed = prm->seed;
+        ma.num_searches = prm->num_mcts_searches; ma.max_expand_depth = prm->max_expand_depth; ma.C = prm->C;
+        ma.node_cap = (uint32_t)node_cap;
+        ma.solve.on = 1; ma.solve.deterministic = sa.deterministic; ma.solve.num_searches = sa.num_searches;
+        ma.solve.from_state = sa.from_state; ma.solve.start_board = sa.start_board; ma.solve.start_zx = sa.start_zx;
+        ma.solve.start_zy = sa.start_zy; ma.solve.start_depth = sa.start_depth;
+        ma.solve.act_pad = sa.t_pad;
+        ma.reuse_mode = (uint32_t)launch_options().az_reuse;
+        deep = !big_mcts && mcts_deep_applies(ma);
+        if (deep) { walkers = mcts_deep_walkers(A, 0, ma.num_searches, true); tbl_entries = mcts_deep_table_entries(ma.num_searches, ma.max_expand_depth); }
+    }
+    const size_t o_cnt = seg(mcts ? 136 : 0),
+                 o_arena = seg(!mcts ? 0 : deep ? (size_t)walkers * mcts_deep_arena_bytes(node_cap) : (size_t)(A * node_cap) * node_bytes),
+                 o_tbl = seg(deep ? (size_t)walkers * tbl_entries * 32 : 0), o_init = seg(deep && !from_state ? n_episodes * 8 : 0), o_queue = seg(deep ? 4 : 0),
+                 o_sv = seg(deep ? sizeof(MctsSolve) : 0);
     uint8_t *buf = nullptr;
     TW_HIP(hipMalloc((void **)&buf, cur ? cur : 256));
     sa.success = reinterpret_cast<float *>(buf + o_s); sa.total = reinterpret_cast<float *>(buf + o_r);
@@ -1508,20 +1526,29 @@ int run_solve(const PuzzleConsts &envc, const tw_policy *policy, const tw_solve_
     }
     int rc;
     if (mcts) {
-        MctsArgs ma{};
-        ma.env = envc; ma.pol = sa.pol; ma.num_episodes = A; ma.episode_offset = episode_offset; ma.seed = prm->seed;
-        ma.num_searches = prm->num_mcts_searches; ma.max_expand_depth = prm->max_expand_depth; ma.C = prm->C;
-        ma.arena = reinterpret_cast<MctsNode *>(buf + o_arena); ma.node_cap = (uint32_t)node_cap;
+        ma.arena = reinterpret_cast<MctsNode *>(buf + o_arena);
         ma.eval_count = reinterpret_cast<unsigned long long *>(buf + o_cnt);
-        ma.solve.on = 1; ma.solve.deterministic = sa.deterministic; ma.solve.num_searches = sa.num_searches;
-        ma.solve.from_state = sa.from_state; ma.solve.start_board = sa.start_board; ma.solve.start_zx = sa.start_zx; ma.solve.start_cells = sa.start_cells;
-        ma.solve.start_zy = sa.start_zy; ma.solve.start_depth = sa.start_depth;
+        ma.solve.start_cells = sa.start_cells;
         ma.solve.success = sa.success; ma.solve.total = sa.total; ma.solve.n_steps = sa.n_steps; ma.solve.actions = sa.actions;
-        ma.solve.act_pad = sa.t_pad;
-        ma.reuse_mode = (uint32_t)launch_options().az_reuse;
-        hipError_t me = hipMemsetAsync(buf + o_cnt, 0, 128, s);
-        if (me != hipSuccess) { (void)hipFree(buf); return hip_fail(me, "hipMemsetAsync(eval counter)", __FILE__, __LINE__); }
-        rc = big_mcts ? launch_mcts_big(ma, nullptr, s, nullptr, nullptr) : launch_mcts_f32(ma, s, nullptr, nullptr);
+        hipError_t me = hipMemsetAsync(buf + o_cnt, 0, 136, s);
+        if (me == hipSuccess && deep) {             // walker arenas need no clearing; their output tables start empty; the queue starts behind the first walkers
+            ma.tbl = buf + o_tbl; ma.tbl_entries = tbl_entries;
+            me = hipMemsetAsync(buf + o_tbl, 0, (size_t)walkers * tbl_entries * 32, s);
+            ma.queue = reinterpret_cast<unsigned int *>(buf + o_queue);
+            const unsigned int first = (unsigned int)(walkers < A ? walkers : A);
+            if (me == hipSuccess) me = hipMemcpyAsync(buf + o_queue, &first, 4, hipMemcpyHostToDevice, s);
+            if (me == hipSuccess) me = hipMemcpyAsync(buf + o_sv, &ma.solve, sizeof(MctsSolve), hipMemcpyHostToDevice, s);      // (see MctsArgs::solve_dev)
+            ma.solve_dev = reinterpret_cast<const MctsSolve *>(buf + o_sv);
+            if (me == hipSuccess) me = hipStreamSynchronize(s);                               // (`first` is a local)
+        }
+        if (me != hipSuccess) { (void)hipFree(buf); return hip_fail(me, "solve: MCTS workspace", __FILE__, __LINE__); }
+        rc = TW_OK;
+        if (deep && !from_state) {
+            ma.init_boards = reinterpret_cast<const uint64_t *>(buf + o_init);
+            rc = launch_init_boards(envc, prm->seed, episode_offset, n_episodes, reinterpret_cast<uint64_t *>(buf + o_init), s);
+        }
+        if (rc == TW_OK)
+            rc = big_mcts ? launch_mcts_big(ma, nullptr, s, nullptr, nullptr) : deep ? launch_mcts_deep(ma, s, nullptr, nullptr) : launch_mcts_f32(ma, s, nullptr, nullptr);
     } else rc = sa.env.n_cells > 16 ? launch_solve_big(sa, s) : launch_solve_f32(sa, s);
     std::vector<float> hs(A), hr(A); std::vector<uint32_t> hn(A);
     hipError_t e = hipSuccess;

@@ -513,12 +513,14 @@ struct MctsArgs {
     uint32_t        tbl_entries;       // ... entries per walker (a power of two)
     uint32_t        reuse_mode;        // lane-per-episode kernel: how a node that takes its parent's move back finds its grandparent's output (TW_OPT_AZ_REUSE)
     const uint32_t *order;             // deep shape: the order in which the walkers take the episodes (launch_episode_order), or null = by index
+    const MctsSolve *solve_dev;        // deep shape in solve mode: a copy of `solve` in device memory (null: self-play) -- the walker kernel has no registers to
+                                       //   keep twenty more launch constants in; it reads them where a move or an attempt ends
     uint32_t        order_across;      // ... the first ones dealt out across the workgroups (walker w of workgroup b: number w * workgroups + b) instead of in a row
 };
 size_t mcts_node_bytes();
 // the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue
 bool     mcts_deep_applies(const MctsArgs &a);
-uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches);   // tree arenas = episodes in flight
+uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false);   // tree arenas = episodes in flight
 size_t   mcts_deep_node_bytes();
 // bytes of one walker's tree arena (72 per node, see tw_mcts_deep.hip), a multiple of 16
 __host__ __device__ inline size_t mcts_deep_arena_bytes(uint64_t node_cap) { return (size_t)((node_cap * 72 + 15) / 16 * 16); }

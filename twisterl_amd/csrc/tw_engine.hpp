@@ -1006,7 +1006,9 @@ struct Engine3G : Engine3<NT, NC, 0, 4> {
 // =====================================================================================================
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int NT, int NC>
+// FS ("force scalar"): the scalar operands of the DMA ops through v_readfirstlane -- for a kernel whose control flow made the compiler
+// carry the engine's running source pointer in vector registers (the walker kernel in solve mode: an "s" asm operand cannot take those)
+template <int NT, int NC, bool FS = false>
 struct Engine3T : Engine3<NT, NC, 0, 4> {
     using B = Engine3<NT, NC, 0, 4>;
     static constexpr int NS = 4, EPB = 16, TPW = NT / 2, KC = B::KC, NQ = B::NQ, WSLOT = B::WSLOT, H = NT * 32;
@@ -1065,8 +1067,14 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
     __device__ __forceinline__ void stream() const
     {
         constexpr int HALF = OP / TOPS, K = OP % TOPS;
+        const uint8_t *src = stp; uint32_t mk = mT[K];
+        if constexpr (FS) {
+            const uint64_t u = (uint64_t)(uintptr_t)stp;
+            src = reinterpret_cast<const uint8_t *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
+            mk = (uint32_t)__builtin_amdgcn_readfirstlane((int)mT[K]);
+        }
         asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
-                     :: "v"(voffT[K] + (uint32_t)(HALF * R3_TSLOT * 4)), "s"(mT[K]), "i"((2 * SLOT + HALF) * R3_TSLOT * 4), "s"(stp) : "memory", "m0", "scc");
+                     :: "v"(voffT[K] + (uint32_t)(HALF * R3_TSLOT * 4)), "s"(mk), "i"((2 * SLOT + HALF) * R3_TSLOT * 4), "s"(src) : "memory", "m0", "scc");
     }
     // the DMA ops of MFMA slot m of M: ops [m*NOPS/M, (m+1)*NOPS/M) of this wave
     template <int SLOT, int OP = 0>
@@ -1291,6 +1299,7 @@ template <int NT, int NC, int DBG, int NW> struct Geom { using Eng = Engine3<NT,
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -4> { using Eng = Engine3S<NT, NC, 4>; static constexpr int WAVES = 4; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -2> { using Eng = Engine3S<NT, NC, 2>; static constexpr int WAVES = 2; };
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -16> { using Eng = Engine3T<NT, NC>; static constexpr int WAVES = 4; };   // 16 episodes per workgroup
+template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -17> { using Eng = Engine3T<NT, NC, true>; static constexpr int WAVES = 4; };   // ... its scalar DMA operands forced (walker kernel, solve mode)
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -5> { using Eng = Engine3G<NT, NC>; static constexpr int WAVES = 4; };    // four waves share 32, two workgroups per CU
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -64> { using Eng = EngineV<NC, true>; static constexpr int WAVES = 4; };   // generic stacks, inline-asm MFMAs: not used any more (tw_engine_generic.hpp)
 template <int NT, int NC, int DBG> struct Geom<NT, NC, DBG, -65> { using Eng = EngineV<NC, false>; static constexpr int WAVES = 4; }; // generic stacks (any Sequential depth)

@@ -112,7 +112,7 @@ __device__ unsigned long long g_deep_stamps[16];
 __device__ unsigned long long g_deep_extra[4];
 #endif
 
-template <int NT, int NC, int NW, int NWK>
+template <int NT, int NC, int NW, int NWK, bool SOLVE = false>
 __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(const MctsArgs a)
 {
     using Eng = typename Geom<NT, NC, 0, NW>::Eng;
@@ -220,16 +220,52 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     // have an episode (4, 5, 8 or 16 each) -- at the tail of a collect the long episodes get the look-ahead of the finished ones
     int my_base = 0, my_share = 0; uint32_t trip = 0;
 
-    auto take = [&](uint64_t e) {
-        e_local = e; e_global = a.episode_offset + e; rec_base = e * (uint64_t)a.out.t_pad;
-        {   // (wave-uniform values the search branches on are made provably uniform where they come from memory: the walk
-            //  then runs on scalar branches instead of exec masks)
-            const uint64_t b0 = a.init_boards[e];
-            st.board = ((uint64_t)uniu((uint32_t)(b0 >> 32)) << 32) | uniu((uint32_t)b0);
+    // MCTS-guided inference (MctsArgs::solve.on; single_solve over predict_probs_mcts, rust/src/rl/solve.rs:17-71): an "episode" of the
+    // queue is an ATTEMPT (episode, search) -- its draws keyed like single_solve's (tw_solve.hip), its start the episode's reset or
+    // the caller's state --, a move is argmax | sample of the MCTS probs, and what is kept is (success, summed rewards, steps, actions)
+    // (a kernel instantiation of its own, SOLVE: the self-play instantiations stay what they were; the launch constants of this mode
+    //  are read from device memory where a move or an attempt ends -- MctsArgs::solve_dev)
+    const MctsSolve *svp = SOLVE ? a.solve_dev : nullptr;
+    constexpr bool sv_on = SOLVE;
+    float total = 0.0f;                                                             // solve mode: summed rewards (solve.rs:25-34)
+    auto take1 = [&](uint64_t e) {
+        e_local = e;
+        uint64_t b0;
+        int depth_start = env.depth0;
+        if (sv_on) {
+            const uint32_t ns = uniu(svp->num_searches);
+            const uint64_t ep = e / ns;
+            e_global = (a.episode_offset + ep) * (uint64_t)ns + e % ns; rec_base = 0;
+            if (uniu(svp->from_state)) { b0 = svp->start_board; depth_start = uni(svp->start_depth); }
+            else b0 = a.init_boards[ep];
+        } else {
+            e_global = a.episode_offset + e; rec_base = e * (uint64_t)a.out.t_pad;
+            b0 = a.init_boards[e];
         }
+        // (wave-uniform values the search branches on are made provably uniform where they come from memory: the walk
+        //  then runs on scalar branches instead of exec masks)
+        st.board = ((uint64_t)uniu((uint32_t)(b0 >> 32)) << 32) | uniu((uint32_t)b0);
         const int z = blank_cell(st.board);
-        st.zx = z % env.width; st.zy = z / env.width; st.depth = env.depth0;
-        t = 0; phase = DP_ROOT;
+        st.zx = z % env.width; st.zy = z / env.width; st.depth = depth_start;
+        t = 0; phase = DP_ROOT; total = 0.0f;
+    };
+    // solve mode: the attempt is over (solve.rs:65-68); AZ mode: nothing to write here
+    auto finish_attempt = [&]() {
+        total = total + puzzle_reward(st, env);
+        if (lane == 0) {
+            svp->success[e_local] = puzzle_solved(st, env) ? 1.0f : 0.0f;
+            svp->total[e_local] = total; svp->n_steps[e_local] = (uint32_t)t;
+        }
+    };
+    auto take = [&](uint64_t e) {
+        take1(e);
+        // `while !env.is_final()` (solve.rs:30): an attempt that starts in a final state is over at once -- on to the next one
+        while (sv_on && phase != DP_DEAD && puzzle_final(st, env)) {
+            finish_attempt();
+            unsigned got = 0xffffffffu;
+            if (more) { if (lane == 0) got = atomicAdd(a.queue, 1u); got = (unsigned)uni((int)got); }
+            if ((uint64_t)got < E) take1((uint64_t)got); else { more = false; phase = DP_DEAD; }
+        }
     };
     // The walkers take the episodes in MctsArgs::order, the ones that look longest first; MctsArgs::order_across: dealt out ACROSS
     // the workgroups at launch (walker w of workgroup b starts with number w * workgroups + b), from the queue afterwards.
@@ -324,7 +360,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 pkw[26] = (uint32_t)evals; pkw[27] = (uint32_t)(evals >> 32); pkw[28] = (uint32_t)spec_evals; pkw[29] = (uint32_t)(spec_evals >> 32);
                 pkw[30] = (more ? 1u : 0u) | (overflow ? 2u : 0u) | (yielded ? 4u : 0u);
                 pkw[31] = (uint32_t)plen; pkw[32] = pool_head; pkw[33] = (uint32_t)n_spec; pkw[34] = (uint32_t)my_base; pkw[35] = (uint32_t)my_share; pkw[36] = trip;
-                pkw[37] = (uint32_t)reused; pkw[38] = (uint32_t)(reused >> 32); pkw[39] = root_best;
+                pkw[37] = (uint32_t)reused; pkw[38] = (uint32_t)(reused >> 32); pkw[39] = root_best; pkw[40] = __float_as_uint(total);
             }
         }
     };
@@ -333,7 +369,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             st.board = ((uint64_t)uniu(pkw[1]) << 32) | uniu(pkw[0]); st.zx = (int)uniu(pkw[2]); st.zy = (int)uniu(pkw[3]); st.depth = (int)uniu(pkw[4]);
             cur.board = ((uint64_t)uniu(pkw[6]) << 32) | uniu(pkw[5]); cur.zx = (int)uniu(pkw[7]); cur.zy = (int)uniu(pkw[8]); cur.depth = (int)uniu(pkw[9]);
             e_local = ((uint64_t)uniu(pkw[11]) << 32) | uniu(pkw[10]);
-            e_global = a.episode_offset + e_local; rec_base = e_local * (uint64_t)a.out.t_pad;
+            if (sv_on) { const uint32_t ns = uniu(svp->num_searches); e_global = (a.episode_offset + e_local / ns) * (uint64_t)ns + e_local % ns; rec_base = 0; }
+            else { e_global = a.episode_offset + e_local; rec_base = e_local * (uint64_t)a.out.t_pad; }
             phase = (int)uniu(pkw[12]); t = (int)uniu(pkw[13]); it = uniu(pkw[14]); expanded = uniu(pkw[15]); node = uniu(pkw[16]); n_nodes = uniu(pkw[17]);
             cursor = uniu(pkw[18]); cur_link = uniu(pkw[19]);
             value = __uint_as_float(uniu(pkw[20])); root_vs = __uint_as_float(uniu(pkw[21])); root_visit = uniu(pkw[22]); root_cb = uniu(pkw[23]);
@@ -344,7 +381,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
             plen = (int)uniu(pkw[31]); pool_head = uniu(pkw[32]); n_spec = (int)uniu(pkw[33]); my_base = (int)uniu(pkw[34]); my_share = (int)uniu(pkw[35]);
             trip = uniu(pkw[36]);
             reused = ((unsigned long long)uniu(pkw[38]) << 32) | uniu(pkw[37]);
-            root_best = uniu(pkw[39]);
+            root_best = uniu(pkw[39]); total = __uint_as_float(uniu(pkw[40]));
             rng_base = 0xffffffffu;                                      // (the buffered draws are not kept across a forward in this shape)
         }
     };
@@ -645,16 +682,37 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 #pragma unroll
                             for (int i = 0; i < 4; ++i) mp[i] = 1.0f / 4.0f;
                         }
-                        // az.rs:72-81: action = sample(mcts_probs); val = env.reward(); store the record
-                        const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
-                        const int action = sample_weighted4(mp, 4, u32_to_unit(w.x));
-                        if (lane == 0) {
-                            uint32_t pk[4];
-                            obs_bytes(st.board, obs_base, pk);
-                            store_rec(a.out.rec + rec_base + (uint64_t)t, pk, mp, 0.0f, puzzle_reward(st, env), 0, -1);
+                        int action = 0;
+                        bool over;
+                        if (sv_on) {
+                            // solve.rs:31-58: total += reward; action = argmax | sample of the MCTS probs; step
+                            total = total + puzzle_reward(st, env);
+                            if (uniu(svp->deterministic)) {
+                                float bv = mp[0];
+#pragma unroll
+                                for (int i = 1; i < 4; ++i) if (mp[i] > bv) { bv = mp[i]; action = i; }
+                            } else {
+                                const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_SOLVE);
+                                action = sample_weighted4(mp, 4, u32_to_unit(w.x));
+                            }
+                            if (svp->actions && lane == 0) svp->actions[e_local * (uint64_t)svp->act_pad + (uint64_t)t] = (uint8_t)action;
+                            puzzle_step(st, env, action);
+                            ++t;
+                            over = puzzle_final(st, env);
+                            if (over) finish_attempt();
+                        } else {
+                            // az.rs:72-81: action = sample(mcts_probs); val = env.reward(); store the record
+                            const u32x4 w = rng_draw(a.seed, e_global, (uint32_t)t, STREAM_AZ_ACT);
+                            action = sample_weighted4(mp, 4, u32_to_unit(w.x));
+                            if (lane == 0) {
+                                uint32_t pk[4];
+                                obs_bytes(st.board, obs_base, pk);
+                                store_rec(a.out.rec + rec_base + (uint64_t)t, pk, mp, 0.0f, puzzle_reward(st, env), 0, -1);
+                            }
+                            over = puzzle_final(st, env);                                                // az.rs:84
+                            if (over && lane == 0) a.out.ep_len[e_local] = (uint32_t)t + 1u;
                         }
-                        if (puzzle_final(st, env)) {                                                     // az.rs:84
-                            if (lane == 0) a.out.ep_len[e_local] = (uint32_t)t + 1u;
+                        if (over) {
                             unsigned got = 0xffffffffu;
                             if (more) {
                                 if (lane == 0) got = atomicAdd(a.queue, 1u);
@@ -665,8 +723,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                             TW_DS(y9); TW_DA(c_fin, y2, y9);
                             break;
                         }
-                        puzzle_step(st, env, action);                                                   // az.rs:89
-                        ++t;
+                        if (!sv_on) { puzzle_step(st, env, action); ++t; }                               // az.rs:89
                         // The next move's root holds a board this episode has most likely expanded a node with (the child just
                         // chosen, if a search went through it): the new tree then starts from the table's output at once
                         // instead of waiting for a forward.
@@ -799,7 +856,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 bool mcts_deep_applies(const MctsArgs &a)
 {
     const int force = launch_options().force_geom;
-    if (a.solve.on || (a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;
+    if ((a.pol.hidden != 128 && a.pol.hidden != 256) || a.num_episodes == 0) return false;      // (solve mode: num_episodes = attempts)
     if (force == 8 || force == 1 || (launch_options().az_variant & 7) == 2) return false;     // diagnostic: pin the lane-per-episode shapes
     if ((launch_options().az_variant & 7) >= 3) return true;                              // diagnostic: a pinned walker shape, whatever the batch
     // (eight walkers per workgroup against lane-per-episode: 8,192 x 100 45.9 / 61.1 ms, 12,288 x 100 64.1 / 68.0, 16,384 x 100 81.4 / 78.6,
@@ -835,7 +892,7 @@ bool mcts_deep_applies(const MctsArgs &a)
 //                   4,096: 324 241 197 | 330 225 174 187
 //   4,096 x 200: 94 70 58 | 97 67 51.9 47.3     3,072 x 200: 73 54 43 | 75 52 39.4 41.0     4,096 x 400: 157 114 91 | 160 110 84.0 82.5
 struct DeepShape { int walkers; bool wide; };
-static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num_searches)
+static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false)
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
@@ -869,25 +926,26 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     if (v & 16) sh.wide = false;
     if (v & 32) sh.wide = true;
     if (!(v & 48) && launch_options().force_geom == 32) sh.wide = true;
+    if (solve) { sh.wide = false; if (sh.walkers == 8) sh.walkers = 4; }       // solve mode: the 16-column engine, one / two / four walkers
     return sh;
 }
-static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus, uint32_t num_searches) { return deep_shape(num_episodes, reserve_cus, num_searches).walkers; }
+static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false) { return deep_shape(num_episodes, reserve_cus, num_searches, solve).walkers; }
 
-uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches)
+uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve)
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
-    const uint64_t nwk = (uint64_t)deep_walkers_per_group(num_episodes, reserve_cus, num_searches);
+    const uint64_t nwk = (uint64_t)deep_walkers_per_group(num_episodes, reserve_cus, num_searches, solve);
     const uint64_t blocks = (num_episodes + nwk - 1) / nwk;
     return (blocks < (uint64_t)(cus - r) ? blocks : (uint64_t)(cus - r)) * nwk;
 }
 
-template <int NT, int NC, int NW, int NWK>
+template <int NT, int NC, int NW, int NWK, bool SOLVE = false>
 static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     using G = Geom<NT, NC, 0, NW>;
     constexpr int C = G::Eng::EPB;
-    const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus, a.num_searches) / NWK;
+    const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus, a.num_searches, SOLVE) / NWK;
     // the hot quads of the first lds_nodes nodes of every tree live in LDS: as many as fit beside the engine
     MctsArgs b = a;
     const size_t eng_floats = G::Eng::lds_floats(a.pol);
@@ -906,12 +964,12 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     //  1,024 x 1,000 76.1 / 76.9 / 77.3 / 77.8 / 81.1, 1,024 x 100 10.3 / 10.3 / 10.5 / 10.6 / 11.1: 48 k stays, eight walkers take 56 k)
     if (NWK == 8 && launch_options().az_tree_budget_min == 0 && b.tree_budget > 56000u) b.tree_budget_min = 56000u;
     const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK)) * sizeof(float);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK>), lds_bytes)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK, SOLVE>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
     unsigned long long zeros[16] = {0};
     if (getenv("TW_STAMPS")) { TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros))); TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_extra), zeros, 32)); }
 #endif
-    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK>), dim3((unsigned)nb), dim3(NWK > DEEP_WAVES ? 64 * NWK : 64 * DEEP_WAVES), lds_bytes, s, b);
+    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK, SOLVE>), dim3((unsigned)nb), dim3(NWK > DEEP_WAVES ? 64 * NWK : 64 * DEEP_WAVES), lds_bytes, s, b);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
@@ -939,6 +997,13 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
 template <int NT, int NC, int NW>
 static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
+    if constexpr (NW == -17) {       // solve mode (MCTS-guided evaluate / solve): its own instantiations, one / two / four walkers
+        switch (deep_walkers_per_group(a.num_episodes, a.reserve_cus, a.num_searches, true)) {
+            case 1: return launch_deep_nwk<NT, NC, NW, 1, true>(a, s, blocks, threads);
+            case 2: return launch_deep_nwk<NT, NC, NW, 2, true>(a, s, blocks, threads);
+            default: return launch_deep_nwk<NT, NC, NW, 4, true>(a, s, blocks, threads);
+        }
+    }
     switch (deep_walkers_per_group(a.num_episodes, a.reserve_cus, a.num_searches)) {
         case 1: return launch_deep_nwk<NT, NC, NW, 1>(a, s, blocks, threads);
         case 2: return launch_deep_nwk<NT, NC, NW, 2>(a, s, blocks, threads);
@@ -951,11 +1016,16 @@ template <int NT>
 static int launch_deep_nt(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     const int nc = a.env.n_cells;
-    const bool wide = deep_shape(a.num_episodes, a.reserve_cus, a.num_searches).wide;
+    const bool wide = deep_shape(a.num_episodes, a.reserve_cus, a.num_searches, a.solve.on != 0).wide;
     if (wide) {
         if (nc <= 4) return launch_deep_geom<NT, 4, -4>(a, s, blocks, threads);
         if (nc <= 9) return launch_deep_geom<NT, 9, -4>(a, s, blocks, threads);
         return launch_deep_geom<NT, 16, -4>(a, s, blocks, threads);
+    }
+    if (a.solve.on) {
+        if (nc <= 4) return launch_deep_geom<NT, 4, -17>(a, s, blocks, threads);
+        if (nc <= 9) return launch_deep_geom<NT, 9, -17>(a, s, blocks, threads);
+        return launch_deep_geom<NT, 16, -17>(a, s, blocks, threads);
     }
     if (nc <= 4) return launch_deep_geom<NT, 4, -16>(a, s, blocks, threads);
     if (nc <= 9) return launch_deep_geom<NT, 9, -16>(a, s, blocks, threads);
@@ -966,8 +1036,11 @@ int launch_mcts_deep(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_
 {
     const uint64_t need = 5ull + 4ull * a.num_searches * (a.max_expand_depth ? a.max_expand_depth : 1u);
     if (a.env.n_cells < 1 || a.env.n_cells > 16 || a.pol.obs_size != a.env.n_cells * a.env.n_cells || a.pol.obs_size > 256 ||
-        a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 || a.out.t_pad < a.env.depth0 + 1 || a.node_cap < need ||
-        !a.arena || !a.eval_count || !a.queue || !a.init_boards || a.solve.on || !a.tbl || a.tbl_entries == 0 || (a.tbl_entries & (a.tbl_entries - 1u))) {
+        a.pol.n_actions != 4 || a.pol.emb % 32 != 0 || a.pol.emb < 32 || (!a.solve.on && a.out.t_pad < a.env.depth0 + 1) || a.node_cap < need ||
+        !a.arena || !a.eval_count || !a.queue || (!a.init_boards && !(a.solve.on && a.solve.from_state)) || !a.tbl || a.tbl_entries == 0 ||
+        (a.tbl_entries & (a.tbl_entries - 1u)) ||
+        (a.solve.on && (!a.solve.success || !a.solve.total || !a.solve.n_steps || a.solve.num_searches == 0 || a.order || !a.solve_dev)) ||
+        (!a.solve.on && a.solve_dev)) {
         set_error("mcts (deep): unsupported shape (n_cells=%d obs_size=%d actions=%d emb=%d hidden=%d t_pad=%d node_cap=%u need=%llu)",
                   a.env.n_cells, a.pol.obs_size, a.pol.n_actions, a.pol.emb, a.pol.hidden, a.out.t_pad, a.node_cap, (unsigned long long)need);
         return TW_ERR_UNSUPPORTED;
