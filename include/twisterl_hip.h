@@ -85,7 +85,8 @@ enum {
     TW_OPT_AZ_VARIANT = 2   /* self-play with few deep searches: 0 automatic (walker-per-wave kernel where it applies),    */
                             /* 2 always the lane-per-episode kernel; walker kernel with a pinned shape: 3 / 4 / 5 / 6 =    */
                             /* two / one / four / eight walkers per workgroup, + 16 / + 32 = the 16- / 32-column engine,   */
-                            /* + 64 = the walkers take the episodes by index instead of longest-looking first              */
+                            /* + 64 = the walkers (and the PPO rollouts' persistent lanes) take the episodes by index      */
+                            /*        instead of longest-looking first                                                     */
 };
 int tw_set_launch_option(int option, int value);
 /* Diagnostic counters of the last self-play launch of this process (MctsArgs::eval_count[0..15]); test hook. */

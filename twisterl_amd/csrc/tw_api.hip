@@ -1094,10 +1094,11 @@ extern "C" int tw_debug_episode_order(const tw_puzzle_desc *env, uint64_t seed, 
     PuzzleConsts envc; rc = make_env_consts(env, &envc, 16); if (rc) return rc;
     hipStream_t s = current_stream();
     void *buf = nullptr;
-    TW_HIP(hipMalloc(&buf, n * 12));
+    TW_HIP(hipMalloc(&buf, n * 12 + 256 + episode_order_scratch_bytes(n)));
     uint64_t *b = reinterpret_cast<uint64_t *>(buf); uint32_t *o = reinterpret_cast<uint32_t *>(b + n);
+    void *scr = reinterpret_cast<uint8_t *>(buf) + align_up(n * 12, 256);
     rc = launch_init_boards(envc, seed, episode_offset, n, b, s);
-    if (!rc) rc = launch_episode_order(envc, b, n, o, s);
+    if (!rc) rc = launch_episode_order(envc, b, n, o, scr, s);
     hipError_t e = rc ? hipSuccess : hipMemcpyAsync(boards_out, b, n * 8, hipMemcpyDeviceToHost, s);
     if (!rc && e == hipSuccess) e = hipMemcpyAsync(order_out, o, n * 4, hipMemcpyDeviceToHost, s);
     if (!rc && e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1200,7 +1201,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     const bool persist = E > resident && !launch_options().no_persist && !big;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
                  o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0),
-                 o_obs16 = seg(big ? R * cells * 2 : 0);
+                 o_obs16 = seg(big ? R * cells * 2 : 0), o_order = seg(persist ? E * 4 : 0), o_ordscr = seg(persist ? episode_order_scratch_bytes(E) : 0);
     void *wsp = nullptr;
     rc = ws_reserve(cur, &wsp); if (rc) return rc;
     uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
@@ -1218,6 +1219,15 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
         TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
         rc = launch_init_boards(ra.env, ra.seed, ra.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
         if (rc) return rc;
+        // the lanes take the episodes longest-looking first (as the self-play walkers do): with a policy that solves the puzzle an episode
+        // is about as long as its start board is far from the solved one, and the collect ends with its last long episode -- trained
+        // Puzzle-8 policy, 262,144 envs: D = 32 12.2 -> 11.5 ms, D = 12 4.85 -> 3.36 ms; 1,048,576 envs 25.2 -> 22.8 ms
+        // (scripts/ragged_trained.py).  Diagnostic, TW_OPT_AZ_VARIANT + 64: by index
+        if (!(launch_options().az_variant & 64)) {
+            rc = launch_episode_order(ra.env, ra.init_boards, E, reinterpret_cast<uint32_t *>(ws + o_order), ws + o_ordscr, s);
+            if (rc) return rc;
+            ra.order = reinterpret_cast<const uint32_t *>(ws + o_order);
+        }
     }
     TW_HIP(hipEventRecord(ev.ev[0], s));
     rc = big                               ? launch_rollout_big(ra, reinterpret_cast<uint16_t *>(ws + o_obs16), s, &st.rollout_blocks, &st.rollout_threads)
@@ -1329,7 +1339,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8),
                  o_total = seg(136), o_scan = seg(scan_scratch_bytes(E)),
                  o_arena = seg(big ? arenas * cap64 * mcts_big_node_bytes() : deep ? arenas * mcts_deep_arena_bytes(cap64) : arenas * cap64 * mcts_node_bytes()),
-                 o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0), o_order = seg(deep ? E * 4 : 0),
+                 o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0), o_order = seg(deep ? E * 4 : 0), o_ordscr = seg(deep ? episode_order_scratch_bytes(E) : 0),
                  o_obs16 = seg(big ? R * cells * 2 : 0);
     const uint32_t tbl_entries = deep ? mcts_deep_table_entries(ma.num_searches, ma.max_expand_depth) : 0;
     const size_t tbl_bytes = (size_t)arenas * tbl_entries * 32;
@@ -1372,7 +1382,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
         // walker kernel: longest-looking episodes first (diagnostic, TW_OPT_AZ_VARIANT + 64: by index).  (The lane-per-episode kernel's
         // queue gains nothing from it: 16,384 x 100 71.5 against 75.3 ms, but 262,144 x 32 186.9 against 182.2, 32,768 x 32 47.1 against 46.0)
         if (deep && !(launch_options().az_variant & 64)) {
-            rc = launch_episode_order(ma.env, ma.init_boards, E, reinterpret_cast<uint32_t *>(ws + o_order), s);
+            rc = launch_episode_order(ma.env, ma.init_boards, E, reinterpret_cast<uint32_t *>(ws + o_order), ws + o_ordscr, s);
             if (rc) return rc;
             ma.order = reinterpret_cast<const uint32_t *>(ws + o_order);
             ma.order_across = 1;
