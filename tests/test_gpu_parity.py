@@ -1249,8 +1249,9 @@ def test_f16x2_full_size_sample(tw, oracle):
 
 def test_persistent_lane_mode_bit_exact(tw, oracle):
     """More episodes than resident lanes (65,536): the f32 kernel runs 256 persistent workgroups whose lanes take the next
-    episode from a queue when theirs is over (ragged lengths: Puzzle-8, one scramble move, depth 24).  Which lane runs an
-    episode must not matter: bit-identical to the oracle, and to the non-persistent launch."""
+    episode from a queue when theirs is over (ragged lengths: Puzzle-8, one scramble move, depth 24) -- longest-looking episodes
+    first.  Which lane runs an episode must not matter: bit-identical to the oracle, to the non-persistent launch and to the queue in
+    index order."""
     import os
     gp, op = _pair(oracle, 9, 5, 32, 32, twists=True)
     E = 70_000
@@ -1264,6 +1265,10 @@ def test_persistent_lane_mode_bit_exact(tw, oracle):
     with _lib.launch_option(_lib.TW_OPT_NO_PERSIST, 1):
         h = coll.collect(genv, gp, seed=17).to_numpy()
     a = g.to_numpy()
+    for k in a:
+        assert np.array_equal(a[k], h[k]), k
+    with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, 64):        # the queue in index order instead of longest-looking first: the same bytes
+        h = coll.collect(genv, gp, seed=17).to_numpy()
     for k in a:
         assert np.array_equal(a[k], h[k]), k
     # the f16-matrix-core kernels have the same mode (their lane halves own one episode each): identical to their
