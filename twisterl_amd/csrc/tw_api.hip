@@ -1200,8 +1200,8 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
                                                                   : rollout_f32_resident_episodes(ra.reserve_cus);
     const bool persist = E > resident && !launch_options().no_persist && !big;
     const size_t o_rec = seg(R * sizeof(PaddedRec)), o_len = seg(E * 4), o_start = seg(E * 8), o_total = seg(8),
-                 o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 8 : 0), o_queue = seg(persist ? 4 : 0),
-                 o_obs16 = seg(big ? R * cells * 2 : 0), o_order = seg(persist ? E * 4 : 0), o_ordscr = seg(persist ? episode_order_scratch_bytes(E) : 0);
+                 o_scan = seg(scan_scratch_bytes(E)), o_init = seg(persist ? E * 16 : 0), o_queue = seg(persist ? 4 : 0),
+                 o_obs16 = seg(big ? R * cells * 2 : 0), o_boards = seg(persist ? E * 8 : 0), o_ordscr = seg(persist ? episode_order_scratch_bytes(E) : 0);
     void *wsp = nullptr;
     rc = ws_reserve(cur, &wsp); if (rc) return rc;
     uint8_t *ws = reinterpret_cast<uint8_t *>(wsp);
@@ -1213,20 +1213,21 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     EventSet ev; rc = ev.init(); if (rc) return rc;
     tw_collect_stats st{};
     if (persist) {
-        ra.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);
+        ra.init_boards = reinterpret_cast<const uint4 *>(ws + o_init);
         ra.queue = reinterpret_cast<unsigned int *>(ws + o_queue);
         const unsigned int first = (unsigned int)resident;      // episodes handed out at launch
         TW_HIP(hipMemcpyAsync(ws + o_queue, &first, 4, hipMemcpyHostToDevice, s));
-        rc = launch_init_boards(ra.env, ra.seed, ra.episode_offset, E, reinterpret_cast<uint64_t *>(ws + o_init), s);
-        if (rc) return rc;
         // the lanes take the episodes longest-looking first (as the self-play walkers do): with a policy that solves the puzzle an episode
         // is about as long as its start board is far from the solved one, and the collect ends with its last long episode -- trained
         // Puzzle-8 policy, 262,144 envs: D = 32 12.2 -> 11.5 ms, D = 12 4.85 -> 3.36 ms; 1,048,576 envs 25.2 -> 22.8 ms
         // (scripts/ragged_trained.py).  Diagnostic, TW_OPT_AZ_VARIANT + 64: by index
-        if (!(launch_options().az_variant & 64)) {
-            rc = launch_episode_order(ra.env, ra.init_boards, E, reinterpret_cast<uint32_t *>(ws + o_order), ws + o_ordscr, s);
+        const bool ordered = !(launch_options().az_variant & 64);
+        rc = launch_init_boards(ra.env, ra.seed, ra.episode_offset, E, ordered ? reinterpret_cast<uint64_t *>(ws + o_boards) : nullptr, s,
+                                ordered ? nullptr : reinterpret_cast<uint4 *>(ws + o_init));
+        if (rc) return rc;
+        if (ordered) {
+            rc = launch_episode_order(ra.env, reinterpret_cast<const uint64_t *>(ws + o_boards), E, nullptr, ws + o_ordscr, s, reinterpret_cast<uint4 *>(ws + o_init));
             if (rc) return rc;
-            ra.order = reinterpret_cast<const uint32_t *>(ws + o_order);
         }
     }
     TW_HIP(hipEventRecord(ev.ev[0], s));

@@ -420,9 +420,9 @@ struct RolloutArgs {
     // persistent-lane mode (f32 kernel, more episodes than resident lanes): a lane whose episode is over takes the next
     // one from `queue` -- ragged episode lengths then cost the MEAN length, as with the reference's work stealing
     // (ppo.rs:110-124), not the maximum of every 256-episode workgroup.  Start boards come from init_boards_kernel.
-    const uint64_t *init_boards;   // [num_episodes] scrambled start boards, or null
-    unsigned int   *queue;         // next unassigned episode, or null
-    const uint32_t *order;         // persistent mode: the order in which the lanes take the episodes (launch_episode_order), or null = by index
+    const uint4    *init_boards;   // [num_episodes] the episodes in the order the lanes take them: {start board lo, hi, episode, 0}, or null
+                                   //   (one array, one pointer: a second one for the order cost the 8-wave kernel 0.6 %)
+    unsigned int   *queue;         // next unassigned entry of init_boards, or null
     int32_t         reserve_cus;   // persistent mode: CUs left without a workgroup (room for RCCL's send/recv kernels, dist.py)
 };
 
@@ -444,11 +444,11 @@ uint64_t rollout_generic_resident_episodes(const PolicyDev &pol, int n_cells, in
 int launch_rollout_big(const RolloutArgs &a, uint16_t *obs16, hipStream_t s, uint32_t *blocks, uint32_t *threads);
 int launch_compact_obs16(const uint16_t *obs16, const uint32_t *ep_len, const uint64_t *ep_start, uint64_t E, int t_pad, int n_cells,
                          uint16_t *out, hipStream_t s);
-int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s);
+int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s, uint4 *entries = nullptr);   // entries: {board, episode i} in index order
 // episodes by decreasing distance of their start board from the solved one (sum of the tiles' Manhattan distances): the order the
 // self-play walkers take them in -- the episodes that are likely to run to the depth limit start first (tw_rollout.hip)
 size_t episode_order_scratch_bytes(uint64_t n);
-int launch_episode_order(const PuzzleConsts &env, const uint64_t *boards, uint64_t n, uint32_t *order, void *scratch, hipStream_t s);
+int launch_episode_order(const PuzzleConsts &env, const uint64_t *boards, uint64_t n, uint32_t *order, void *scratch, hipStream_t s, uint4 *entries = nullptr);   // order and / or entries {board, episode} in that order
 uint64_t rollout_f32_resident_episodes(int reserve_cus = 0);   // episodes the f32 rollout keeps resident at once (persistent mode above that)
 // Lanes the exact-f32 kernels (rollout, self-play) keep resident for a batch: episodes beyond that wait in the queue of the
 // persistent-lane mode.  CUs x 256 for the 256-episode shape; between CUs x 32 and 3/4 of that the small-batch shape

@@ -36,19 +36,20 @@
 namespace tw {
 
 // scrambled start boards of episodes [offset, offset+n) (Env::reset, puzzle.rs:119-133) for the persistent-lane mode
-__global__ void __launch_bounds__(256) init_boards_kernel(const PuzzleConsts env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out)
+__global__ void __launch_bounds__(256) init_boards_kernel(const PuzzleConsts env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, uint4 *entries)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     PuzzleLane st;
     puzzle_reset(st, env, seed, episode_offset + i);
-    out[i] = st.board;
+    if (out) out[i] = st.board;
+    if (entries) entries[i] = make_uint4((uint32_t)st.board, (uint32_t)(st.board >> 32), (uint32_t)i, 0u);
 }
 
-int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s)
+int launch_init_boards(const PuzzleConsts &env, uint64_t seed, uint64_t episode_offset, uint64_t n, uint64_t *out, hipStream_t s, uint4 *entries)
 {
     if (n == 0) return TW_OK;
-    hipLaunchKernelGGL(init_boards_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env, seed, episode_offset, n, out);
+    hipLaunchKernelGGL(init_boards_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, env, seed, episode_offset, n, out, entries);
     TW_HIP(hipGetLastError());
     return TW_OK;
 }
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(64) episode_order_prefix_kernel(uint32_t *cnt,
 }
 
 __global__ void __launch_bounds__(1024) episode_order_scatter_kernel(const PuzzleConsts env, const uint64_t *boards, uint32_t n, uint32_t span, const uint32_t *base,
-                                                                      uint32_t *order)
+                                                                      uint32_t *order, uint4 *entries)
 {
     __shared__ uint32_t cur[ORD_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -130,7 +131,8 @@ __global__ void __launch_bounds__(1024) episode_order_scatter_kernel(const Puzzl
     for (uint32_t i0 = lo; i0 < hi; i0 += 64) {                 // (wave-uniform trip count)
         const uint32_t i = i0 + lane;
         const bool on = i < hi;
-        const uint32_t k = on ? key(boards[i]) : 64u;
+        const uint64_t bd = on ? boards[i] : 0ull;
+        const uint32_t k = on ? key(bd) : 64u;
         unsigned long long peers = __builtin_amdgcn_ballot_w64(on);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -139,7 +141,9 @@ __global__ void __launch_bounds__(1024) episode_order_scatter_kernel(const Puzzl
         }
         if (on) {
             const uint32_t rank = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1ull));
-            order[cur[wave][k] + rank] = i;
+            const uint32_t pos = cur[wave][k] + rank;
+            if (order) order[pos] = i;
+            if (entries) entries[pos] = make_uint4((uint32_t)bd, (uint32_t)(bd >> 32), i, 0u);
         }
         __builtin_amdgcn_wave_barrier();
         if (on && rank_is_leader(peers, lane)) cur[wave][k] += (uint32_t)__builtin_popcountll(peers);
@@ -163,7 +167,7 @@ size_t episode_order_scratch_bytes(uint64_t n)
     return (size_t)blocks * ORD_WAVES * 64 * sizeof(uint32_t);
 }
 
-int launch_episode_order(const PuzzleConsts &env, const uint64_t *boards, uint64_t n, uint32_t *order, void *scratch, hipStream_t s)
+int launch_episode_order(const PuzzleConsts &env, const uint64_t *boards, uint64_t n, uint32_t *order, void *scratch, hipStream_t s, uint4 *entries)
 {
     if (n == 0) return TW_OK;
     if (n > 0xffffffffull || env.n_cells < 1 || env.n_cells > 16 || !scratch) { set_error("episode order: unsupported shape"); return TW_ERR_INVALID; }
@@ -171,7 +175,7 @@ int launch_episode_order(const PuzzleConsts &env, const uint64_t *boards, uint64
     uint32_t *cnt = reinterpret_cast<uint32_t *>(scratch);
     hipLaunchKernelGGL(episode_order_count_kernel, dim3(blocks), dim3(1024), 0, s, env, boards, (uint32_t)n, span, cnt);
     hipLaunchKernelGGL(episode_order_prefix_kernel, dim3(1), dim3(64), 0, s, cnt, blocks * ORD_WAVES);
-    hipLaunchKernelGGL(episode_order_scatter_kernel, dim3(blocks), dim3(1024), 0, s, env, boards, (uint32_t)n, span, (const uint32_t *)cnt, order);
+    hipLaunchKernelGGL(episode_order_scatter_kernel, dim3(blocks), dim3(1024), 0, s, env, boards, (uint32_t)n, span, (const uint32_t *)cnt, order, entries);
     TW_HIP(hipGetLastError());
     return TW_OK;
 }
@@ -201,7 +205,10 @@ __global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), ((NW == 8
     uint32_t e_local = (uint32_t)e_first;                 // (launch_geom bounds the episode count of a launch to 2^31)
     uint64_t board = env.ident; int depth = 0;
     if (valid) {
-        if constexpr (PERSIST) { if (a.order) e_local = a.order[e_local]; board = a.init_boards[e_local]; depth = env.depth0; }      // start boards from the pre-pass
+        if constexpr (PERSIST) {              // the episode and its start board from the pre-pass (RolloutArgs::init_boards: in the order the lanes take them)
+            const uint4 ib = a.init_boards[e_local];
+            e_local = ib.z; board = ((uint64_t)ib.y << 32) | ib.x; depth = env.depth0;
+        }
         else { PuzzleLane s0; puzzle_reset(s0, env, a.seed, a.episode_offset + e_first); board = s0.board; depth = s0.depth; }
     }
 
@@ -270,8 +277,8 @@ __global__ void __launch_bounds__((Geom<NT, NC, DBG, NW>::WAVES * 64), ((NW == 8
             } else got = (unsigned)__shfl((int)got, j, 64);
             if (want) {
                 if ((uint64_t)got < a.num_episodes) {
-                    e_local = a.order ? a.order[got] : got;
-                    board = a.init_boards[e_local]; depth = env.depth0;
+                    const uint4 ib = a.init_boards[got];
+                    e_local = ib.z; board = ((uint64_t)ib.y << 32) | ib.x; depth = env.depth0;
                     alive = true; t = 0;
                 } else more = false;
             }

@@ -43,9 +43,10 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
     PuzzleLane own;
     own.board = env.ident; own.zx = 0; own.zy = 0; own.depth = 0;
     if (v_own) {
-        if constexpr (PERSIST) {             // (the lanes take the episodes in RolloutArgs::order: the longest-looking ones first)
-            if (a.order) { e_own = a.order[e_own]; eg_own = a.episode_offset + e_own; }
-            own = from_board(a.init_boards[e_own]);
+        if constexpr (PERSIST) {             // (RolloutArgs::init_boards: the episodes in the order the lanes take them, the longest-looking ones first)
+            const uint4 ib = a.init_boards[e_own];
+            e_own = ib.z; eg_own = a.episode_offset + e_own;
+            own = from_board(((uint64_t)ib.y << 32) | ib.x);
         } else puzzle_reset(own, env, a.seed, eg_own);
     }
     // both halves keep both episodes' state (the one-hot operands of both tiles are built on every lane)
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(256, 1) rollout_f16_kernel(const RolloutArgs a
             const bool took = (uint64_t)got < a.num_episodes;
             more = more && !(idle_own && !took);
             uint64_t nb = 0;
-            if (took) { e_own = a.order ? a.order[got] : got; eg_own = a.episode_offset + e_own; rec_base = e_own * (uint64_t)a.out.t_pad; t = 0; nb = a.init_boards[e_own]; }
+            if (took) { const uint4 ib = a.init_boards[got]; e_own = ib.z; eg_own = a.episode_offset + e_own; rec_base = e_own * (uint64_t)a.out.t_pad; t = 0; nb = ((uint64_t)ib.y << 32) | ib.x; }
             const bool took_oth = __shfl_xor(took ? 1 : 0, 32, 64) != 0;
             const uint64_t nb_oth = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(nb >> 32), 32, 64) << 32) |
                                     (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)nb, 32, 64);
