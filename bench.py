@@ -157,6 +157,26 @@ def side_configs(twisterl, torch):
                                      "frac_outputs_of_a_forward_only": fwd_only * FLOP_PER_RECORD[16] / k / 1e12 / PEAK_TFLOPS["fp32"]}}
     except Exception as e:
         out["config5_error"] = str(e)
+    try:
+        # the reference's default evaluations (src/twisterl/defaults.py:27-57: 100 episodes each; `learn_step` runs them beside the collect,
+        # algorithm.py:117-121) on the same Puzzle-15 policy: best of three calls after one warm-up, ms per call
+        arrs = synthetic_weights(16, seed=0)
+        pol = build_policy(arrs, [], [])
+        env = twisterl.env.Puzzle(4, 4, 8, 2, 256)
+        ev = {}
+        for name, kw in (("ppo_deterministic", dict(deterministic=True, num_searches=1, num_mcts_searches=0)), ("ppo_1", dict(deterministic=False, num_searches=1, num_mcts_searches=0)),
+                         ("ppo_10", dict(deterministic=False, num_searches=10, num_mcts_searches=0)), ("mcts_100", dict(deterministic=True, num_searches=1, num_mcts_searches=100))):
+            args = dict(num_episodes=100, seed=0, C=1.41, max_expand_depth=1, num_cores=32, **kw)
+            twisterl.collector.evaluate(env, pol, **args)
+            ts = []
+            for i in range(3):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                r = twisterl.collector.evaluate(env, pol, **args)
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+            ev[name] = {"ms": min(ts) * 1e3, "success_rate": float(r[0]), "mean_reward": float(r[1])}
+        out["evaluations_100_episodes"] = ev
+    except Exception as e:
+        out["evaluations_error"] = str(e)
     return out
 
 

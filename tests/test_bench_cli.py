@@ -75,7 +75,8 @@ def test_side_config_schema():
             return _Data(10 * self.E, {"ms_rollout": 1.0, "forward_evals": 40 * self.E, "reused_evals": 10 * self.E, "speculative_evals": 0,
                                        "rollout_blocks": 256, "rollout_threads": 512})
 
-    fake = types.SimpleNamespace(collector=types.SimpleNamespace(PPOCollector=_Coll, AZCollector=_Coll), env=types.SimpleNamespace(Puzzle=lambda *a: None))
+    fake = types.SimpleNamespace(collector=types.SimpleNamespace(PPOCollector=_Coll, AZCollector=_Coll, evaluate=lambda env, pol, **kw: (0.5, -0.25)),
+                                 env=types.SimpleNamespace(Puzzle=lambda *a: None))
     real_build, real_sync = bench.build_policy, torch.cuda.synchronize
     bench.build_policy, torch.cuda.synchronize = (lambda *a: None), (lambda: None)
     try:
@@ -83,7 +84,9 @@ def test_side_config_schema():
     finally:
         bench.build_policy, torch.cuda.synchronize = real_build, real_sync
     assert set(out) == {"config1_puzzle8_1k_f32", "config2_puzzle8_65k_fp16", "config2_puzzle8_65k_f32", "config5_az_4096x100", "config5_az_4096x1000",
-                        "config5_az_512x1000_reference_default"}
+                        "config5_az_512x1000_reference_default", "evaluations_100_episodes"}
+    ev = out.pop("evaluations_100_episodes")
+    assert set(ev) == {"ppo_deterministic", "ppo_1", "ppo_10", "mcts_100"} and all({"ms", "success_rate", "mean_reward"} <= set(v) and v["ms"] >= 0 for v in ev.values())
     for k, v in out.items():
         assert {"value", "unit", "ms_per_step", "kernel_ms", "records", "roofline"} <= set(v), k
         assert {"bound", "achieved", "peak", "unit", "frac"} <= set(v["roofline"]) and 0 < v["roofline"]["frac"]
