@@ -95,3 +95,18 @@ def test_compiled_c_host_builds_and_fails_loudly_without_a_gpu():
         return                                  # on the GPU box the parity test runs it for real
     r = subprocess.run([exe, "4", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert r.returncode == 2 and "no GPU" in r.stderr and "records" not in r.stdout
+
+
+def test_stub_transport_exports_what_the_library_resolves():
+    """tests/stub_rccl.hip (the stand-in for RCCL behind TW_RCCL_LIBRARY in the multi-rank GPU tests) compiles with hipcc and exports
+    every nccl* symbol tw_comm.hip resolves with dlsym -- no more, no fewer."""
+    import re
+    import subprocess
+    from tests.util import build_stub_rccl
+    src = open(os.path.join(ROOT, "twisterl_amd", "csrc", "tw_comm.hip")).read()
+    wanted = set(re.findall(r'sym\("(nccl\w+)"\)', src))
+    assert len(wanted) == 11 and "ncclCommAbort" in wanted
+    out = subprocess.run(["nm", "-D", "--defined-only", build_stub_rccl()], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("nccl")}
+    assert exported == wanted
+    assert "TW_RCCL_LIBRARY" in src

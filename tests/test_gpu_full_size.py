@@ -220,3 +220,72 @@ def test_selfplay_lane_per_episode_kernel_full_size_vs_oracle(tw, oracle, reques
         assert np.array_equal(sl("obs").astype(np.int64), o.obs), e
         assert np.array_equal(f32_bits(sl("logits")), f32_bits(o.logits)), e
         assert np.array_equal(f32_bits(sl("remaining_values")), f32_bits(o.additional_data["remaining_values"])), e
+
+
+@pytest.mark.parametrize("transport", ["torch", "cabi"])
+def test_config4_rank_share_full_size(tw, oracle, transport):
+    """BASELINE config 4's PER-RANK code path exactly as `bench.py --gpus 8` runs it on each GPU, at world 1: 262,144 envs of
+    Puzzle-15 (difficulty 128, twists) collected by `collect_sharded(step_episodes=(CUs-8)*256, reserve_cus=8,
+    max_episode_records=257)` -- five pipeline steps, the persistent grid on CUs-8 compute units in all but the last step, each
+    step's chunk received at its final offset in the pre-allocated result (the torch.distributed transport bench.py defaults to,
+    and the library's own tw_gather_* over RCCL that TW_GATHER=cabi selects).  The merged result must be BYTE-EQUAL to the
+    un-sharded collect of the same seed, and sampled episodes bit-equal to the oracle (reference merge order, collector.rs:40-46)."""
+    import os
+    import torch.distributed as dist
+    import twisterl_amd
+    from twisterl_amd.dist import Comm, collect_sharded, pipeline_steps
+    gp, op = _bench_policy(oracle, twists=True)
+    E, D = 262_144, 128
+    t_max = 2 * D + 1
+    env, oenv = tw.env.Puzzle(4, 4, D, 2, 256), oracle.Puzzle(4, 4, D, 2, 256)
+    coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32})
+    cus = twisterl_amd.device_info()["compute_units"]
+    reserve, step_eps = 8, (cus - 8) * 256
+    assert pipeline_steps(E, 1, 1, step_eps) == 5
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        comm = Comm() if transport == "cabi" else None
+        merged, parts = collect_sharded(coll, env, gp, seed=1000, dst=0, max_episode_records=t_max, reserve_cus=reserve,
+                                        step_episodes=step_eps, comm=comm)
+        # five steps; all but the last leave 8 CUs to the transfer kernels
+        assert [p.stats["episodes"] for p in parts] == [step_eps] * 4 + [E - 4 * step_eps]
+        assert [p.stats["rollout_blocks"] for p in parts] == [cus - reserve] * 4 + [cus]
+        # 248 x 256 episodes = every lane of the 8-wave shape resident once; the 8,192 left over: 256 workgroups of 32 episodes
+        assert [p.stats["rollout_threads"] for p in parts] == [512] * 4 + [256]
+        n = sum(len(p) for p in parts)
+        assert merged["obs"].shape[0] == n
+        del parts
+        whole = coll.collect(env, gp, seed=1000)
+        w = whole.to_torch()
+        assert len(whole) == n
+        for k in ("obs", "logits", "perms", "values", "rewards", "actions", "advs", "rets"):
+            assert torch.equal(merged[k], w[k]), k
+        L = w["ep_len"].cpu().numpy().astype(np.int64)
+        S = w["ep_start"].cpu().numpy().astype(np.int64)
+        if transport == "cabi":                      # the library's gather also rebuilds the per-episode tables of the merged order
+            assert torch.equal(merged["ep_len"].to(w["ep_len"].dtype), w["ep_len"]) and torch.equal(merged["ep_start"].to(w["ep_start"].dtype), w["ep_start"])
+        order = np.concatenate([[E - 1], np.arange(E - 1)])
+        assert np.array_equal(S[order], np.concatenate([[0], np.cumsum(L[order])[:-1]]))
+        del whole, w
+        # sampled episodes (among them the first and last of every step) against the oracle, every field, bit for bit
+        edges = [e for s in range(1, 5) for e in (s * step_eps - 1, s * step_eps)]
+        for e in sorted(set(edges + _sample_episodes(E, 22, seed=4))):
+            s, ln = int(S[e]), int(L[e])
+            o = oracle.ppo_collect(oenv, op, 1, 0.995, 0.995, seed=1000, episode_offset=e, arith=oracle.ARITH_CHAIN, det_log=True,
+                                   merge_order=False)
+            assert ln == int(o.ep_len[0]) == o.obs.shape[0], e
+            sl = lambda k: merged[k][s:s + ln].cpu().numpy()
+            assert np.array_equal(sl("obs").astype(np.int64), o.obs), e
+            assert np.array_equal(sl("actions").astype(np.int64), o.actions), e
+            assert np.array_equal(sl("perms").astype(np.int32), o.perms), e
+            assert np.array_equal(f32_bits(sl("rewards")), f32_bits(o.rewards)), e
+            assert np.array_equal(f32_bits(sl("logits")), f32_bits(o.logits)), e
+            assert np.array_equal(f32_bits(sl("values")), f32_bits(o.values)), e
+            assert np.array_equal(f32_bits(sl("advs")), f32_bits(o.additional_data["advs"])), e
+            assert np.array_equal(f32_bits(sl("rets")), f32_bits(o.additional_data["rets"])), e
+        if comm is not None:
+            comm.close()
+    finally:
+        dist.destroy_process_group()

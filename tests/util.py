@@ -94,3 +94,21 @@ def trained_puzzle8_arrays():
     lin = lambda name, relu: (np.ascontiguousarray(g(name + ".weight").T).reshape(-1), g(name + ".bias"), relu)
     return (np.ascontiguousarray(g("embeddings.weight").T), g("embeddings.bias"),
             [lin("common.0", True)], [lin("action.0", False)], [lin("value.0", False)])
+
+
+def build_stub_rccl():
+    """tests/stub_rccl.hip -> tests/_build/libstub_rccl.so (hipcc, gfx950): the host-staged stand-in for RCCL that lets 2 and 3
+    ranks exchange through tw_comm_* / tw_gather_* on one GPU.  Test infrastructure; selected with TW_RCCL_LIBRARY."""
+    import os
+    import subprocess
+    from twisterl_amd.build import hipcc
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, out = os.path.join(here, "stub_rccl.hip"), os.path.join(here, "_build", "libstub_rccl.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        cmd = [hipcc(), "-O2", "--offload-arch=gfx950", "-Wall", "-fPIC", "-shared", src, "-o", out + ".tmp", "-lpthread"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on tests/stub_rccl.hip:\n" + r.stdout)
+        os.replace(out + ".tmp", out)
+    return out

@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -51,8 +52,17 @@ int rccl_load()
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return TW_OK;
+    // TW_RCCL_LIBRARY names the library that provides the nccl* symbols (a path dlopen takes).  A host sets it to pick one RCCL
+    // build out of several; tests/test_gpu_multirank.py sets it to a host-staged stand-in (tests/stub_rccl.hip) so that two and
+    // three ranks can exchange through tw_comm_* / tw_gather_* on ONE GPU, which RCCL itself refuses.  A named library that does
+    // not load is an error, never a silent switch to another one.
+    void *h = nullptr;
+    if (const char *named = getenv("TW_RCCL_LIBRARY"); named && *named) {
+        h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { set_error("TW_RCCL_LIBRARY=%s does not load (%s)", named, dlerror()); return TW_ERR_UNSUPPORTED; }
+    }
     // a process that already holds an RCCL (PyTorch-ROCm bundles one) must keep using THAT one
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -160,6 +170,10 @@ struct tw_comm {
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;          // the exchange runs beside the collectors' stream
     uint64_t *counts_dev = nullptr;        // [TW_GATHER_COUNTS] mine | [world][TW_GATHER_COUNTS] all
+    // The same, PINNED on the host, + one word for a chunk's last episode length.  Copies from / to pageable memory are not
+    // asynchronous: the call itself waits until the stream gets there, i.e. for ever behind the transfer of a peer that died, and
+    // the bounded wait below would never be reached (found by tests/test_gpu_multirank.py: a rank killed before a count exchange).
+    uint64_t *counts_host = nullptr;
     uint32_t timeout_ms = 0;               // tw_comm_set_timeout_ms: how long tw_gather_finish waits for the transfers (0 = for ever)
     bool dead = false;                     // aborted (a local failure inside a group, or a timeout): every later call fails
 };
@@ -199,6 +213,7 @@ extern "C" int tw_comm_init(int rank, int world, const tw_comm_id *id, tw_comm *
     hipError_t e = hipGetDevice(&c->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&c->counts_dev, (size_t)(world + 1) * TW_GATHER_COUNTS * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->counts_host, ((size_t)(world + 1) * TW_GATHER_COUNTS + 1) * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) { rc = hip_fail(e, "tw_comm_init", __FILE__, __LINE__); tw_comm_destroy(c); return rc; }
     ncclUniqueId nid;
     memcpy(nid.internal, id->bytes, sizeof(nid.internal));
@@ -213,6 +228,7 @@ extern "C" void tw_comm_destroy(tw_comm *c)
     if (!c) return;
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     if (c->counts_dev) (void)hipFree(c->counts_dev);
+    if (c->counts_host) (void)hipHostFree(c->counts_host);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -291,15 +307,42 @@ static int gather_alloc(tw_gather *g)
     return TW_OK;
 }
 
+// Waits for everything queued on the exchange stream.  With tw_comm_set_timeout_ms the wait is bounded: a peer that failed or was
+// killed never posts what this rank waits for, so after the limit the communicator is aborted and the call fails (TW_ERR_HIP)
+// instead of hanging the host.
+static int wait_exchange(tw_comm *c, const char *what)
+{
+    hipError_t e = hipSuccess;
+    if (c->timeout_ms) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(c->timeout_ms)) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (e == hipErrorNotReady) {
+            (void)hipGetLastError();
+            set_error("%s did not complete within %u ms (a peer failed?); communicator aborted", what, c->timeout_ms);
+            comm_abort(c);                                   // (ncclCommAbort returns once this rank's RCCL kernels have ended)
+            (void)hipStreamSynchronize(c->stream);           // what was queued behind them (copies into host memory of the caller) drains
+            return TW_ERR_HIP;
+        }
+    } else e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(e, what, __FILE__, __LINE__);
+    return TW_OK;
+}
+
 // one ncclAllGather of TW_GATHER_COUNTS numbers per rank on the exchange stream, read back
 static int exchange_counts(tw_comm *c, const uint64_t (&mine)[TW_GATHER_COUNTS], std::vector<uint64_t> &all)
 {
     hipStream_t s = c->stream;
-    all.assign((size_t)c->world * TW_GATHER_COUNTS, 0);
-    TW_HIP(hipMemcpyAsync(c->counts_dev, mine, sizeof(mine), hipMemcpyHostToDevice, s));
+    const size_t n_all = (size_t)c->world * TW_GATHER_COUNTS;
+    memcpy(c->counts_host, mine, sizeof(mine));
+    TW_HIP(hipMemcpyAsync(c->counts_dev, c->counts_host, sizeof(mine), hipMemcpyHostToDevice, s));
     TW_NCCL(g_rccl.AllGather(c->counts_dev, c->counts_dev + TW_GATHER_COUNTS, TW_GATHER_COUNTS, ncclUint64, c->comm, s));
-    TW_HIP(hipMemcpyAsync(all.data(), c->counts_dev + TW_GATHER_COUNTS, all.size() * 8, hipMemcpyDeviceToHost, s));
-    TW_HIP(hipStreamSynchronize(s));
+    TW_HIP(hipMemcpyAsync(c->counts_host + TW_GATHER_COUNTS, c->counts_dev + TW_GATHER_COUNTS, n_all * 8, hipMemcpyDeviceToHost, s));
+    int rc = wait_exchange(c, "the count exchange");          // bounded: a peer that died never joins the all-gather
+    if (rc) return rc;
+    all.assign(c->counts_host + TW_GATHER_COUNTS, c->counts_host + TW_GATHER_COUNTS + n_all);
     return TW_OK;
 }
 
@@ -324,11 +367,13 @@ extern "C" int tw_gather_submit(tw_gather *g, const tw_collected *local, uint64_
     uint64_t mine[TW_GATHER_COUNTS] = {status ? 0 : n_local, 0, status ? 0 : e_local, episode_offset, ow, na, status, 0};
     hipStream_t s = c->stream;
     if (local && e_local && !status) {
-        uint32_t last_len = 0;
-        hipError_t e = hipMemcpyAsync(&last_len, reinterpret_cast<const uint32_t *>(collected_field(local, TW_F_EP_LEN)) + (e_local - 1), 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        // (behind the previous step's transfer on the exchange stream: the wait is the bounded one)
+        uint32_t *last_len = reinterpret_cast<uint32_t *>(c->counts_host + (size_t)(world + 1) * TW_GATHER_COUNTS);
+        *last_len = 0;
+        hipError_t e = hipMemcpyAsync(last_len, reinterpret_cast<const uint32_t *>(collected_field(local, TW_F_EP_LEN)) + (e_local - 1), 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) { const int wrc = wait_exchange(c, "tw_gather_submit: the previous step's transfer"); if (wrc) return wrc; }
         if (e != hipSuccess) { (void)hip_fail(e, "tw_gather_submit: reading the last episode length", __FILE__, __LINE__); mine[0] = mine[2] = 0; mine[6] = status = 2; }
-        mine[1] = last_len;
+        mine[1] = *last_len;
     }
     std::vector<uint64_t> all;
     int rc = exchange_counts(c, mine, all);
@@ -417,21 +462,8 @@ extern "C" int tw_gather_finish(tw_gather *g, tw_collected **merged)
     if (c->dead) { set_error("tw_gather_finish: the communicator was aborted"); rc = TW_ERR_HIP; }
     else if (g->st.step != g->st.steps) { set_error("tw_gather_finish: %u of %u steps submitted", g->st.step, g->st.steps); rc = TW_ERR_INVALID; }
     hipError_t e = hipSuccess;
-    if (rc == TW_OK && c->timeout_ms) {
-        // bounded wait: a peer that aborted never sends what this rank is waiting for
-        const auto t0 = std::chrono::steady_clock::now();
-        while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(c->timeout_ms)) break;
-            std::this_thread::sleep_for(std::chrono::microseconds(200));
-        }
-        if (e == hipErrorNotReady) {
-            (void)hipGetLastError();
-            set_error("tw_gather_finish: the transfers did not complete within %u ms (a peer failed?); communicator aborted", c->timeout_ms);
-            comm_abort(c);
-            rc = TW_ERR_HIP; e = hipSuccess;
-        }
-    } else if (!c->dead) e = hipStreamSynchronize(c->stream);
-    if (rc == TW_OK && e != hipSuccess) rc = hip_fail(e, "tw_gather_finish", __FILE__, __LINE__);
+    if (rc == TW_OK) rc = wait_exchange(c, "tw_gather_finish: the transfers");
+    else if (!c->dead) (void)wait_exchange(c, "tw_gather_finish");     // (steps missing: what WAS posted still targets the arena freed below)
     if (rc == TW_OK && c->rank == g->root && merged) {
         if (!g->allocated) { set_error("tw_gather_finish: no records were submitted"); rc = TW_ERR_EMPTY; }
     }

@@ -222,6 +222,11 @@ class Comm:
 
     __del__ = close
 
+    def set_timeout_ms(self, ms: int) -> None:
+        """Bound of every wait of the exchange (tw_comm_set_timeout_ms): past it the communicator is aborted and the call raises."""
+        from . import _lib
+        _lib.check(_lib.lib().tw_comm_set_timeout_ms(self._h, int(ms)))
+
     def broadcast_policy(self, policy, root: int = 0) -> None:
         """Policy sync across GPUs: the root's weight images replace everybody's (one ncclBroadcast)."""
         from . import _lib
