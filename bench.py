@@ -180,6 +180,56 @@ def side_configs(twisterl, torch):
     return out
 
 
+def headline(args, world, use_dist, total_records, wall, records, ms_rollout, E_total, gather_info):
+    """The contract line of rank 0 (without the side entries): pure arithmetic on what the timed region measured, so that the CPU
+    tests can run it for every documented choice of arguments (tests/test_bench_cli.py)."""
+    side = 4 if args.puzzle == 15 else 3
+    n2 = side * side
+    envs_per_gpu = E_total / world
+    kern_s = float(np.mean(ms_rollout)) * 1e-3
+    rec_per_launch = records / args.steps
+    tpr, tpr_file = measured_traffic_per_record({"fp32": "rollout_f32", "fp16": "rollout_f16", "fp16x2": "rollout_f16x2"}[args.precision]) if args.puzzle == 15 else (None, None)
+    achieved = rec_per_launch * FLOP_PER_RECORD[n2] / kern_s / 1e12
+    peak = PEAK_TFLOPS[args.precision]
+    return {
+        "metric": "env-steps/s (whole node) Puzzle-15 PPO rollout" if args.puzzle == 15 else "env-steps/s Puzzle-8 PPO rollout",
+        "value": total_records / wall,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": {"fp32": "f32", "fp16": "f16", "fp16x2": "f16x2 (f32-equivalent: two f16 terms per operand)"}[args.precision],
+        "data": "synthetic",
+        "config": {
+            "workload": f"Puzzle-{args.puzzle} PPO rollout + GAE + merge: {envs_per_gpu:g} envs/GPU, difficulty {args.difficulty} "
+                        f"(<= {2 * args.difficulty + 1} records/episode), twists "
+                        f"{'none' if args.no_twists else '{identity, transpose}'}, BasicPolicy {n2 * n2}->512->256->4|1, "
+                        f"gamma=lambda=0.995, torch-default-init weights seed 0",
+            "envs_per_gpu": envs_per_gpu, "total_envs": E_total, "records_per_step": total_records / args.steps,
+            "mean_records_per_episode": total_records / args.steps / E_total, "parallelism": f"episodes sharded x{world}",
+            "gather": gather_info,
+        },
+        "roofline": {
+            "bound": "mfma", "kernel": "tw::rollout_f32_kernel" if args.precision == "fp32" else "tw::rollout_f16_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak,
+            # HBM bytes per launch -- NOT a counter read in this run (PMC passes need rocprofv3 around the process): the
+            # PMC-measured bytes per record of the committed profile x the records of this launch
+            "traffic": (tpr * rec_per_launch) if tpr is not None else None,
+            "traffic_from_profile": tpr is not None,
+            "traffic_source": None if tpr is None else
+                              f"{tpr_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (FETCH x2 per the gfx950 note), "
+                              "bytes per record x the records of this run's launch; not measured in this run",
+            "kernel_ms": kern_s * 1e3, "flop_per_record": FLOP_PER_RECORD[n2],
+            "hbm_bytes_per_record": BYTES_PER_RECORD[n2],
+            "hbm_frac": rec_per_launch * BYTES_PER_RECORD[n2] / kern_s / 8e12,
+        },
+    }
+
+
 STRONG_TOTAL_ENVS = 2_097_152      # BASELINE.json config 4: "2M envs sharded over 8 x MI355X"
 
 
@@ -355,49 +405,9 @@ def main():
     total_records, wall = float(rec_t.item()), float(dt_t.item())
 
     if rank == 0:
-        kern_s = float(np.mean(ms_rollout)) * 1e-3
-        rec_per_launch = records / args.steps
-        tpr, tpr_file = measured_traffic_per_record({"fp32": "rollout_f32", "fp16": "rollout_f16", "fp16x2": "rollout_f16x2"}[args.precision]) if args.puzzle == 15 else None
-        achieved = rec_per_launch * FLOP_PER_RECORD[n2] / kern_s / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        out = {
-            "metric": "env-steps/s (whole node) Puzzle-15 PPO rollout" if args.puzzle == 15 else "env-steps/s Puzzle-8 PPO rollout",
-            "value": total_records / wall,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": {"fp32": "f32", "fp16": "f16", "fp16x2": "f16x2 (f32-equivalent: two f16 terms per operand)"}[args.precision],
-            "data": "synthetic",
-            "config": {
-                "workload": f"Puzzle-{args.puzzle} PPO rollout + GAE + merge: {envs_per_gpu:g} envs/GPU, difficulty {args.difficulty} "
-                            f"(<= {2 * args.difficulty + 1} records/episode), twists "
-                            f"{'none' if args.no_twists else '{identity, transpose}'}, BasicPolicy {n2 * n2}->512->256->4|1, "
-                            f"gamma=lambda=0.995, torch-default-init weights seed 0",
-                "envs_per_gpu": envs_per_gpu, "total_envs": E_total, "records_per_step": total_records / args.steps,
-                "mean_records_per_episode": total_records / args.steps / E_total, "parallelism": f"episodes sharded x{world}",
-                "gather": None if not use_dist else {"pipeline_steps": gatherer.steps, "episodes_per_rank_and_step": step_eps,
-                                                    "reserved_cus": reserve,
-                                                    "transport": "RCCL send/recv at final offsets, issued by " + ("the library (tw_gather_*)" if comm is not None else "torch.distributed")},
-            },
-            "roofline": {
-                "bound": "mfma", "kernel": "tw::rollout_f32_kernel" if args.precision == "fp32" else "tw::rollout_f16_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                # HBM bytes per launch -- NOT a counter read in this run (PMC passes need rocprofv3 around the process): the
-                # PMC-measured bytes per record of the committed profile x the records of this launch
-                "traffic": (tpr * rec_per_launch) if tpr is not None else None,
-                "traffic_from_profile": True,
-                "traffic_source": f"{tpr_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (FETCH x2 per the gfx950 note), "
-                                  "bytes per record x the records of this run's launch; not measured in this run",
-                "kernel_ms": kern_s * 1e3, "flop_per_record": FLOP_PER_RECORD[n2],
-                "hbm_bytes_per_record": BYTES_PER_RECORD[n2],
-                "hbm_frac": rec_per_launch * BYTES_PER_RECORD[n2] / kern_s / 8e12,
-            },
-        }
+        gather_info = None if not use_dist else {"pipeline_steps": gatherer.steps, "episodes_per_rank_and_step": step_eps, "reserved_cus": reserve,
+                                                 "transport": "RCCL send/recv at final offsets, issued by " + ("the library (tw_gather_*)" if comm is not None else "torch.distributed")}
+        out = headline(args, world, use_dist, total_records, wall, records, ms_rollout, E_total, gather_info)
         if world == 1 and args.precision == "fp32" and not use_dist:
             # side measurements, not the headline: the same workload in the two f16-matrix-core modes.
             #   fp16x2: every f32 operand as two f16 terms -- logits within 5e-8 of the reference f32 arithmetic on sampled

@@ -97,3 +97,30 @@ def test_side_config_schema():
             assert abs(v["kernel_ms"] - 1.0) < 1e-9 and len(v["per_collect"]) == 3
             assert v["roofline"]["frac_outputs_of_a_forward_only"] < v["roofline"]["frac"]
     json.dumps(out)
+
+
+def test_headline_line_for_every_documented_choice():
+    """bench.headline (rank 0's contract line) for both puzzles, every precision, one rank and several: JSON-serialisable, the
+    contract's keys present, `traffic` null with its source null where no PMC profile exists (Puzzle-8: ADVICE r03, the line used
+    to die on an un-packable None after all the timed work)."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+    for puzzle in (8, 15):
+        for prec in ("fp32", "fp16", "fp16x2"):
+            for world in (1, 8):
+                args = bench.parse_args(["--puzzle", str(puzzle), "--precision", prec, "--gpus", str(world), "--steps", "4"])
+                gi = None if world == 1 else {"pipeline_steps": 5, "episodes_per_rank_and_step": 63488, "reserved_cus": 8, "transport": "x"}
+                out = bench.headline(args, world, world > 1, 4.0e6 * world, 0.5, 4.0e6, [100.0, 102.0, 98.0, 100.0], 262_144 * world, gi)
+                json.dumps(out)
+                assert need <= set(out) and out["n_gpus"] == world and out["vs_baseline"] is None and out["higher_is_better"] is True
+                assert out["value"] == 4.0e6 * world / 0.5 and abs(out["ms_per_step"] - 125.0) < 1e-9
+                rf = out["roofline"]
+                assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+                assert abs(rf["achieved"] - 1.0e6 * bench.FLOP_PER_RECORD[16 if puzzle == 15 else 9] / 0.1 / 1e12) < 1e-9
+                if puzzle == 8:
+                    assert rf["traffic"] is None and rf["traffic_source"] is None and rf["traffic_from_profile"] is False
+                else:
+                    assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+                assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["gather"] == gi

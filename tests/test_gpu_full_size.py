@@ -289,3 +289,52 @@ def test_config4_rank_share_full_size(tw, oracle, transport):
             comm.close()
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------- bench.py's side entries, at exactly the shapes it times
+def test_bench_side_entry_config1_puzzle8_1k_whole_collect_vs_oracle(tw, oracle):
+    """BASELINE config 1's batch on the GPU as bench.side_configs times it ("config1_puzzle8_1k_f32"): Puzzle-8
+    (examples/ppo_puzzle8_v1.json:3-9,21-26: 3x3, depth_slope 2, max_depth 256, gamma = lambda = 0.995) at difficulty 32, 1,024
+    envs, BasicPolicy 81->512->256->4|1 with torch-default-init weights seed 0, no twists, f32.  The launch is the 16-episode
+    workgroup shape (64 workgroups of four waves, Engine3T); the WHOLE collect (every record, every field) is bit-equal to the
+    oracle, for each of the seeds the bench times."""
+    import bench
+    arrs = bench.synthetic_weights(9, seed=0)
+    gp, op = bench.build_policy(arrs, [], []), oracle.Policy(*arrs, [], [])
+    E, D = 1024, 32
+    env, oenv = tw.env.Puzzle(3, 3, D, 2, 256), oracle.Puzzle(3, 3, D, 2, 256)
+    coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.995, "lambda": 0.995, "num_cores": 32}, precision="fp32")
+    for seed in (2, 3, 4):
+        g = coll.collect(env, gp, seed=seed)
+        assert (g.stats["rollout_blocks"], g.stats["rollout_threads"]) == (64, 256)
+        o = oracle.ppo_collect(oenv, op, E, 0.995, 0.995, seed=seed, arith=oracle.ARITH_CHAIN, det_log=True, num_threads=8, merge_order=True)
+        a = g.to_numpy()
+        assert len(g) == o.obs.shape[0] and 40_000 < len(g) <= E * (2 * D + 1)
+        assert np.array_equal(a["ep_len"], o.ep_len)
+        assert np.array_equal(a["obs"].astype(np.int64), o.obs)
+        assert np.array_equal(a["actions"].astype(np.int64), o.actions)
+        assert np.array_equal(a["perms"].astype(np.int32), o.perms) and np.all(a["perms"] == -1)
+        for k, ref in (("rewards", o.rewards), ("logits", o.logits), ("values", o.values), ("advs", o.additional_data["advs"]),
+                       ("rets", o.additional_data["rets"])):
+            assert np.array_equal(f32_bits(a[k]), f32_bits(ref)), (seed, k)
+
+
+def test_bench_side_entry_default_evaluations_vs_oracle(tw, oracle):
+    """The four `evaluations_100_episodes` numbers bench.side_configs prints (the reference's default evaluations,
+    src/twisterl/defaults.py:27-57, run beside every collect by learn_step, src/twisterl/rl/algorithm.py:117-121) on the
+    Puzzle-15 512/256 seed-0 policy at difficulty 8, 100 episodes, seed 0: (success_rate, mean_reward) bit-equal to the oracle's
+    evaluate (rust/src/rl/evaluate.rs:22-89) for the same draws."""
+    import bench
+    arrs = bench.synthetic_weights(16, seed=0)
+    gp, op = bench.build_policy(arrs, [], []), oracle.Policy(*arrs, [], [])
+    env, oenv = tw.env.Puzzle(4, 4, 8, 2, 256), oracle.Puzzle(4, 4, 8, 2, 256)
+    seen = {}
+    for name, det, ns, S in (("ppo_deterministic", True, 1, 0), ("ppo_1", False, 1, 0), ("ppo_10", False, 10, 0), ("mcts_100", True, 1, 100)):
+        g = tw.collector.evaluate(env, gp, num_episodes=100, deterministic=det, num_searches=ns, num_mcts_searches=S, seed=0, C=1.41,
+                                  max_expand_depth=1, num_cores=32)
+        o = oracle.evaluate(oenv, op, 100, det, ns, num_mcts_searches=S, seed=0, Cc=1.41, max_expand_depth=1, arith=oracle.ARITH_CHAIN, det_math=True)
+        assert f32_bits(g[0]) == f32_bits(o[0]) and f32_bits(g[1]) == f32_bits(o[1]), (name, g, o)
+        assert 0.0 <= g[0] <= 1.0
+        seen[name] = g
+    # the searches help on this policy (what the bench line shows): best-of-10 and MCTS-guided solve more than one greedy attempt
+    assert seen["ppo_10"][0] > seen["ppo_1"][0] and seen["mcts_100"][0] > seen["ppo_deterministic"][0]

@@ -49,6 +49,48 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+ASM_DIR = os.path.join(LIB_DIR, "asm")          # the device assembly of every object (what scripts/scan_mfma_hazards.py reads)
+_TEMP_SUFFIXES = (".bc", ".hipi", ".out", ".out.resolution.txt", ".hipfb", "-host-x86_64-unknown-linux-gnu.s", "-hip-amdgcn-amd-amdhsa-gfx950.o")
+
+
+def _keep_device_asm(stem: str) -> None:
+    """-save-temps=obj leaves every intermediate file beside the object: the gfx950 assembly (the text the object was assembled
+    from) moves to lib/asm/, the rest goes."""
+    os.makedirs(ASM_DIR, exist_ok=True)
+    for f in os.listdir(LIB_DIR):
+        if not f.startswith(stem + "-") and not f.startswith(stem + ".hip-"):
+            continue
+        path = os.path.join(LIB_DIR, f)
+        if f == stem + "-hip-amdgcn-amd-amdhsa-gfx950.s":
+            os.replace(path, os.path.join(ASM_DIR, stem + ".s"))
+        elif f.endswith(_TEMP_SUFFIXES):
+            os.remove(path)
+
+
+def scan_hazards(verbose: bool = False) -> int:
+    """MFMA wait-state check of the assembly the library was built from (scripts/scan_mfma_hazards.py): inline-asm MFMAs get no
+    padding from hipcc, so a hazard there is a BUILD ERROR, not something a parity test may or may not catch."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import scan_mfma_hazards as scan
+    finally:
+        sys.path.pop(0)
+    files = sorted(glob.glob(os.path.join(ASM_DIR, "*.s")))
+    missing = [s for s in SOURCES if not os.path.exists(os.path.join(ASM_DIR, s.replace(".hip", ".s")))]
+    if missing:
+        raise RuntimeError(f"no device assembly for {missing}: rebuild with --force")
+    report, mfmas = [], 0
+    for f in files:
+        hits, counts = scan.scan_file(f)
+        mfmas += sum(counts.values())
+        report += [f"{os.path.basename(f)}: {h}" for h in hits]
+    if report:
+        raise RuntimeError("MFMA hazards in the compiled kernels (scripts/scan_mfma_hazards.py):\n" + "\n".join(report[:40]))
+    if verbose:
+        print(f"[build] MFMA hazard scan: 0 in {mfmas} MFMAs of {len(files)} files")
+    return mfmas
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     flags = list(FLAGS)
@@ -64,7 +106,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIB_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
-            cmd = [hipcc(), *flags, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+            cmd = [hipcc(), *flags, "-save-temps=obj", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -74,6 +116,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {name}:\n{out}")
         if verbose and out.strip():
             print(out)
+        _keep_device_asm(name.replace(".hip", ""))
+    # The scan belongs to the compile: whenever an object was rebuilt, all of the library's assembly is checked.  (A tree that
+    # holds objects without their assembly -- the snapshot on the GPU box leaves lib/asm/ behind, .gpurunignore -- is not
+    # recompiled for it; tests/test_mfma_hazards.py insists on the assembly where the library is built.)
+    if procs:
+        scan_hazards(verbose)
     if force or procs or _stale(LIB_PATH, objs):
         cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH, *objs]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

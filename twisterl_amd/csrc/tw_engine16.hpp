@@ -319,6 +319,11 @@ struct Engine16 {
             // ---- side work B: conversion of the embedding tile computed in this phase
             if (E_P && M_P && p > LE + 1) {
                 const int lim = (p - LE - 1) * UPP < 16 ? (p - LE - 1) * UPP : 16;
+                // One hidden tile: only two common-layer pairs follow the last embedding pair, and hipcc moves these conversions in
+                // front of them (they do not depend on each other) -- straight behind the asm MFMA of e1, 8 wait states where the
+                // XDL write -> VALU read needs 12 (scripts/scan_mfma_hazards.py found it; with more tiles the pairs stay in between
+                // and the build's scan keeps watching).  The pad is part of the dependency chain of e0 / e1, so it cannot move.
+                if (NHT < 2 && udone == 0 && lim > 0) asm volatile("s_nop 11" : "+v"(e0), "+v"(e1));
                 for (; udone < lim; ++udone) unit(udone);
             }
             __builtin_amdgcn_sched_barrier(0);
