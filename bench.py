@@ -36,9 +36,12 @@ PEAK_TFLOPS = {"fp32": 157.3, "fp16": 2500.0, "fp16x2": 2500.0}     # MI355X_MIC
 def measured_traffic_per_record(kernel="rollout_f32"):
     """HBM bytes per record of the rollout kernel from the committed rocprofv3 PMC passes (the latest round's
     profiles/rNN_hbm_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes)."""
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    import glob
+    # the NEWEST round's file (tests/test_bench_cli.py fails when it is older than the newest committed BENCH round)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")), reverse=True):
+        name = os.path.basename(path)
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            d = json.load(open(path))
             for k, v in d.items():
                 if isinstance(v, dict) and (k.endswith(kernel) or (kernel == "rollout_f32" and kernel in k)):
                     return float(v["bytes_per_record"]), "profiles/" + name
@@ -145,16 +148,21 @@ def side_configs(twisterl, torch):
             dt1 = sum(r[0] for r in rs); n = sum(r[1] for r in rs)
             k = sum(r[2]["ms_rollout"] for r in rs) * 1e-3
             consumed = sum(r[2]["forward_evals"] for r in rs); reused = sum(r[2]["reused_evals"] for r in rs)
+            # EXECUTED useful work: outputs the searches consumed that came out of a forward of this collect.  The outputs served from the
+            # board-keyed table (`reused_evals`) were never computed again: they count in the reference-equivalent RATE (what the
+            # reference would have evaluated, `value`), not in a roofline fraction.
             fwd_only = consumed - reused
-            tf = consumed * FLOP_PER_RECORD[16] / k / 1e12
+            tf_exec = fwd_only * FLOP_PER_RECORD[16] / k / 1e12
+            tf_ref = consumed * FLOP_PER_RECORD[16] / k / 1e12
             st = rs[1][2]
             out[key] = {"value": consumed / dt1, "unit": "leaf evaluations/s (Policy::full_predict calls the searches consume = what the reference evaluates)",
                         "ms_per_step": dt1 * 1e3 / len(rs), "kernel_ms": k * 1e3 / len(rs), "collects": len(rs), "records": n, "episodes": E, "searches": S,
                         "forward_evals": consumed, "reused_evals": reused, "speculative_evals": sum(r[2]["speculative_evals"] for r in rs),
                         "per_collect": [{"ms": round(r[0] * 1e3, 3), "forward_evals": r[2]["forward_evals"]} for r in rs],
                         "launch": [st["rollout_blocks"], st["rollout_threads"]],
-                        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["fp32"],
-                                     "frac_outputs_of_a_forward_only": fwd_only * FLOP_PER_RECORD[16] / k / 1e12 / PEAK_TFLOPS["fp32"]}}
+                        "roofline": {"bound": "mfma", "achieved": tf_exec, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": tf_exec / PEAK_TFLOPS["fp32"],
+                                     "counts": "outputs consumed by the searches that a forward of this collect computed (forward_evals - reused_evals)",
+                                     "reference_equivalent_TFLOPs": tf_ref, "reference_equivalent_frac": tf_ref / PEAK_TFLOPS["fp32"]}}
     except Exception as e:
         out["config5_error"] = str(e)
     try:

@@ -4,7 +4,7 @@
 //
 // *** NOT COMPILED, NOT TESTED: this image has no Rust toolchain (rustc / cargo absent, no network).  The C ABI it binds is
 // *** exercised from compiled C (examples/collect_from_c.c) and from Python (twisterl_amd/_lib.py, the whole test suite);
-// *** struct layouts below are field-for-field copies of include/twisterl_hip.h at ABI version 5 (no struct has changed since 4).
+// *** struct layouts below are field-for-field copies of include/twisterl_hip.h at ABI version 6 (6: tw_env_vtable grew the rest of the trait).
 //
 // What else the reference needs (three small additions, all `pub(crate)`):
 //   rust/build.rs                 println!("cargo:rustc-link-search=native={}", env::var("TWISTERL_HIP_LIB_DIR").unwrap());
@@ -65,6 +65,11 @@ use crate::rl::env::Env;
     reward: extern "C" fn(*mut c_void) -> f32,
     is_final: extern "C" fn(*mut c_void) -> c_int,
     success: Option<extern "C" fn(*mut c_void) -> c_int>,
+    // the rest of the trait (rl/env.rs:30,58-66); None = the trait's default body (ABI 6)
+    track_solution: Option<extern "C" fn(*mut c_void) -> c_int>,
+    solution: Option<extern "C" fn(*mut c_void, *mut u32, u32) -> u32>,
+    set_state: Option<extern "C" fn(*mut c_void, *const i64, u32)>,
+    twists: Option<extern "C" fn(*mut c_void, *mut i32, *mut i32, u32) -> u32>,
 }
 
 // fields of the result (TW_F_*)
@@ -148,6 +153,28 @@ extern "C" fn env_masks(e: *mut c_void, out: *mut u8) { let m = unsafe { (*(e as
 extern "C" fn env_reward(e: *mut c_void) -> f32 { unsafe { (*(e as *mut Box<dyn Env>)).reward() } }
 extern "C" fn env_is_final(e: *mut c_void) -> c_int { unsafe { (*(e as *mut Box<dyn Env>)).is_final() as c_int } }
 extern "C" fn env_success(e: *mut c_void) -> c_int { unsafe { (*(e as *mut Box<dyn Env>)).success() as c_int } }
+// Env::track_solution / Env::solution (rl/env.rs:61-66): tw_solve_env32 asks track_solution once per attempt, before its first move,
+// and returns solution() in place of the played actions when it is true -- single_solve (rl/solve.rs:28,57-64)
+extern "C" fn env_track_solution(e: *mut c_void) -> c_int { unsafe { (*(e as *mut Box<dyn Env>)).track_solution() as c_int } }
+extern "C" fn env_solution(e: *mut c_void, out: *mut u32, cap: u32) -> u32 {
+    let sol = unsafe { (*(e as *mut Box<dyn Env>)).solution() };
+    for (i, &v) in sol.iter().take(cap as usize).enumerate() { unsafe { *out.add(i) = v as u32 } }
+    sol.len() as u32
+}
+extern "C" fn env_set_state(e: *mut c_void, st: *const i64, n: u32) {
+    let v = unsafe { std::slice::from_raw_parts(st, n as usize) }.to_vec();
+    unsafe { (*(e as *mut Box<dyn Env>)).set_state(v) }
+}
+extern "C" fn env_twists(e: *mut c_void, obs_perms: *mut i32, act_perms: *mut i32, cap: u32) -> u32 {
+    let b = unsafe { &*(e as *mut Box<dyn Env>) };
+    let (op, ap) = b.twists();
+    let (obs_size, n_act) = (b.obs_shape().iter().product::<usize>(), b.num_actions());
+    for k in 0..op.len().min(cap as usize) {
+        for (i, &v) in op[k].iter().enumerate() { unsafe { *obs_perms.add(k * obs_size + i) = v as i32 } }
+        for (i, &v) in ap[k].iter().enumerate() { unsafe { *act_perms.add(k * n_act + i) = v as i32 } }
+    }
+    op.len() as u32
+}
 
 fn vtable_of(env: &Box<dyn Env>) -> TwEnvVtable {
     TwEnvVtable {
@@ -155,6 +182,7 @@ fn vtable_of(env: &Box<dyn Env>) -> TwEnvVtable {
         num_actions: env.num_actions() as u32, n_obs: env.observe().len() as u32, obs_size: env.obs_shape().iter().product::<usize>() as u32,
         clone: env_clone, destroy: env_destroy, reset: env_reset, step: env_step, observe: env_observe, masks: env_masks,
         reward: env_reward, is_final: env_is_final, success: Some(env_success),
+        track_solution: Some(env_track_solution), solution: Some(env_solution), set_state: Some(env_set_state), twists: Some(env_twists),
     }
 }
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TW_ABI_VERSION 5   /* 5: tw_gather_plan, tw_comm_set_timeout_ms, tw_debug_counters, tw_debug_episode_order, TW_OPT_AZ_REUSE (no struct changed since 4) */
+#define TW_ABI_VERSION 6   /* 6: tw_env_vtable grew track_solution / solution / set_state / twists (the rest of `trait Env`), tw_solve_env32 */
 
 /* status codes */
 enum {
@@ -80,13 +80,16 @@ enum {
     TW_OPT_AZ_TREE_BUDGET_MIN = 4, /* walker kernel: cycles of tree walk after which a walker yields once another one waits; 0: auto */
     TW_OPT_AZ_TREE_BUDGET = 3, /* walker kernel: cycles of tree walk per forward before a walker yields; 0: automatic           */
     TW_OPT_AZ_REUSE = 5,    /* lane-per-episode self-play kernel, how a node whose move takes its parent's move back finds   */
-                            /* the stored output of its grandparent (same board): 0 product, 1 no reuse, 2 / 3 / 4 see      */
-                            /* tw_mcts.hip (diagnostic forms kept for the record of DESIGN 5.5)                             */
+                            /* the stored output of its grandparent (same board): 0 product, 1 no reuse, 3 by the link only, */
+                            /* 4 by the link while counting where the path level would have differed; 2 (the path level at   */
+                            /* any depth: returns different bytes, kept for the record) only in the TW_ABLATE build -- the   */
+                            /* product build refuses it with TW_ERR_INVALID                                                  */
     TW_OPT_AZ_VARIANT = 2   /* self-play with few deep searches: 0 automatic (walker-per-wave kernel where it applies),    */
                             /* 2 always the lane-per-episode kernel; walker kernel with a pinned shape: 3 / 4 / 5 / 6 =    */
                             /* two / one / four / eight walkers per workgroup, + 16 / + 32 = the 16- / 32-column engine,   */
                             /* + 64 = the walkers (and the PPO rollouts' persistent lanes) take the episodes by index      */
-                            /*        instead of longest-looking first                                                     */
+                            /*        instead of longest-looking first, + 128 / + 256 = the decoupled shape (engine-only   */
+                            /*        waves beside the walkers) pinned on / off                                            */
 };
 int tw_set_launch_option(int option, int value);
 /* Diagnostic counters of the last self-play launch of this process (MctsArgs::eval_count[0..15]); test hook. */
@@ -239,6 +242,20 @@ typedef struct {
     float  (*reward)(void *env);
     int    (*is_final)(void *env);
     int    (*success)(void *env);         /* Env::success; only tw_evaluate_env / tw_solve_env call it (may be NULL for the collectors) */
+    /* The rest of the trait (rust/src/rl/env.rs:30,58-66).  Every one may be NULL = the trait's default body. */
+    int      (*track_solution)(void *env);                          /* Env::track_solution (:62); NULL: false.  Asked once per   */
+                                                                    /* attempt, before its first move (rust/src/rl/solve.rs:28)  */
+    uint32_t (*solution)(void *env, uint32_t *out, uint32_t cap);   /* Env::solution (:65): writes at most `cap` entries, returns */
+                                                                    /* how many there are; NULL: empty.  tw_solve_env returns it  */
+                                                                    /* instead of the actions it played when the environment      */
+                                                                    /* tracks its own (solve.rs:57-64)                            */
+    void     (*set_state)(void *env, const int64_t *state, uint32_t n);   /* Env::set_state (:30).  Host-side member: the library  */
+                                                                    /* never calls it (solve starts from the prototype AS IT IS)  */
+    uint32_t (*twists)(void *env, int32_t *obs_perms, int32_t *act_perms, uint32_t cap);  /* Env::twists (:58-59): up to `cap`       */
+                                                                    /* permutations, obs_perms[k][obs_size], act_perms[k][num_actions]; */
+                                                                    /* returns how many there are; NULL: none.  Host-side member: */
+                                                                    /* the HOST builds the policy with them (tw_policy_create),   */
+                                                                    /* as src/twisterl/rl/algorithm.py does from env.twists()     */
 } tw_env_vtable;
 
 /* solve / evaluate (rust/src/rl/solve.rs:73-101, rust/src/rl/evaluate.rs:22-89; PyO3 functions
@@ -285,6 +302,10 @@ int tw_evaluate_env(const tw_env_vtable *env, const tw_policy *policy, const tw_
                     uint64_t episode_offset, uint32_t max_steps, float *success_rate, float *mean_reward);
 int tw_solve_env(const tw_env_vtable *env, const tw_policy *policy, const tw_solve_params *params, uint32_t max_steps,
                  float *success, float *reward, uint8_t *actions_out, uint32_t actions_cap, uint32_t *n_actions);
+/* The same with 32-bit entries: what an environment that tracks its own solution returns (Env::solution, Vec<usize>) need not be
+ * action indices.  tw_solve_env (8-bit) fails with TW_ERR_INVALID on an entry above 255. */
+int tw_solve_env32(const tw_env_vtable *env, const tw_policy *policy, const tw_solve_params *params, uint32_t max_steps,
+                   float *success, float *reward, uint32_t *solution_out, uint32_t solution_cap, uint32_t *n_solution);
 
 /* Fields of the result (device-resident, compact, in the order params.merge_order asked for) */
 enum {
@@ -332,7 +353,9 @@ typedef struct {
 int  tw_collected_stats(const tw_collected *c, tw_collect_stats *out);
 /* Releases the result.  Its device memory goes to a per-process pool (freed by tw_release_cached_memory, or when the device
  * runs out of memory inside the library) and is handed to a later collect, which waits for everything the LIBRARY's stream had
- * queued before this call.  Work of the caller on other streams that still reads the result must be finished first. */
+ * queued before this call -- on the stream that PRODUCED the result and on the calling thread's stream (tw_set_stream is
+ * thread-local; the free may come from another thread).  Work of the caller on other streams that still reads the result must
+ * be finished first. */
 void tw_collected_free(tw_collected *c);
 
 /* ---- trainer hand-off (replaces the list -> numpy -> tensor path of PPO.data_to_torch / AZ.data_to_torch,

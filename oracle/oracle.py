@@ -584,6 +584,7 @@ def solve_env(env, policy: Policy, deterministic, num_searches, num_mcts_searche
         e = env.copy()
         key = episode * num_searches + k
         total, acts, t = f32(0), [], 0
+        track = bool(e.track_solution()) if hasattr(e, "track_solution") else False     # solve.rs:28 (Env::track_solution, env.rs:62)
         while not e.is_final():
             total = f32(total + f32(e.value()))
             if num_mcts_searches == 0:
@@ -603,8 +604,11 @@ def solve_env(env, policy: Policy, deterministic, num_searches, num_mcts_searche
                 w = philox4x32_10([key & 0xFFFFFFFF, key >> 32, t, 5], [seed & 0xFFFFFFFF, seed >> 32])
                 action = sample_weighted(probs, float(f32(w[0] >> 8) * f32(1.0 / 16777216.0)))
             e.next(action)
-            acts.append(action)
+            if not track:                                   # solve.rs:57-59
+                acts.append(action)
             t += 1
+        if track:                                           # solve.rs:62-64: the environment's own record replaces the played actions
+            acts = [int(x) for x in e.solution()]
         total = f32(total + f32(e.value()))
         val = ((1.0 if e.success() else 0.0, float(total)), acts)
         if val[0] > best[0]:

@@ -98,3 +98,41 @@ class GridWorld:
             elif v == 3:
                 self.trap = p
         self.steps_left = self.max_steps
+
+
+class TrackingGridWorld(GridWorld):
+    """A GridWorld that keeps its own record of the way it was solved -- `Env::track_solution` / `Env::solution`
+    (rust/src/rl/env.rs:61-66): `single_solve` then returns THIS instead of the actions it played (rust/src/rl/solve.rs:28,
+    57-64).  An entry is 1000 x (cell entered) + action: not an action index, and above 255 on purpose (the 32-bit path).
+    It also names its symmetry as twists (mirror left <-> right): Env::twists (env.rs:58-59), which the host feeds the Policy."""
+
+    def __init__(self, width, height, max_steps):
+        super().__init__(width, height, max_steps)
+        self.path = []
+
+    def copy(self):
+        c = TrackingGridWorld(self.width, self.height, self.max_steps)
+        c.steps_left, c.agent, c.goal, c.trap = self.steps_left, self.agent, self.goal, self.trap
+        c.path = list(self.path)
+        return c
+
+    def reset(self, difficulty):
+        super().reset(difficulty)
+        self.path = []
+
+    def next(self, action):
+        super().next(action)
+        self.path.append(1000 * (self.agent[1] * self.width + self.agent[0]) + int(action))
+
+    def track_solution(self):
+        return True
+
+    def solution(self):
+        return list(self.path)
+
+    def twists(self):
+        n, w = self.width * self.height, self.width
+        mirror = lambda i: (i // w) * w + (w - 1 - i % w)
+        ident = list(range(n * n))
+        mir = [mirror(o // n) * n + (o % n) for o in range(n * n)]
+        return [ident, mir], [[0, 1, 2, 3], [0, 1, 3, 2]]

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the ctypes prototype table covers the header exactly
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.tw_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.tw_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_launch_options_are_validated():
@@ -41,10 +41,12 @@ def test_launch_options_are_validated():
     from twisterl_amd import _lib
     lib = _lib.lib()
     ok = [(_lib.TW_OPT_FORCE_GEOM, 8), (_lib.TW_OPT_FORCE_GEOM, 32), (_lib.TW_OPT_NO_PERSIST, 1), (_lib.TW_OPT_AZ_VARIANT, 2),
-          (_lib.TW_OPT_AZ_VARIANT, 16 + 5), (_lib.TW_OPT_AZ_VARIANT, 32 + 6), (_lib.TW_OPT_AZ_VARIANT, 64), (_lib.TW_OPT_AZ_VARIANT, 64 + 2), (_lib.TW_OPT_AZ_TREE_BUDGET, 72000), (_lib.TW_OPT_AZ_TREE_BUDGET_MIN, 8000),
+          (_lib.TW_OPT_AZ_VARIANT, 16 + 5), (_lib.TW_OPT_AZ_VARIANT, 32 + 6), (_lib.TW_OPT_AZ_VARIANT, 64), (_lib.TW_OPT_AZ_VARIANT, 64 + 2), (_lib.TW_OPT_AZ_VARIANT, 128 + 16 + 5), (_lib.TW_OPT_AZ_VARIANT, 256), (_lib.TW_OPT_AZ_TREE_BUDGET, 72000), (_lib.TW_OPT_AZ_TREE_BUDGET_MIN, 8000),
           (_lib.TW_OPT_AZ_REUSE, 1), (_lib.TW_OPT_AZ_REUSE, 4)]
-    bad = [(_lib.TW_OPT_FORCE_GEOM, 5), (_lib.TW_OPT_AZ_VARIANT, 7), (_lib.TW_OPT_AZ_VARIANT, 48 + 3), (_lib.TW_OPT_AZ_VARIANT, 128), (_lib.TW_OPT_AZ_VARIANT, -1),
+    bad = [(_lib.TW_OPT_FORCE_GEOM, 5), (_lib.TW_OPT_AZ_VARIANT, 7), (_lib.TW_OPT_AZ_VARIANT, 48 + 3), (_lib.TW_OPT_AZ_VARIANT, 512), (_lib.TW_OPT_AZ_VARIANT, 384), (_lib.TW_OPT_AZ_VARIANT, -1),
            (_lib.TW_OPT_AZ_TREE_BUDGET, 10), (_lib.TW_OPT_AZ_TREE_BUDGET_MIN, -5), (_lib.TW_OPT_AZ_REUSE, 5), (_lib.TW_OPT_AZ_REUSE, -1), (99, 0)]
+    if not os.environ.get("TW_ABLATE"):
+        bad.append((_lib.TW_OPT_AZ_REUSE, 2))      # the form that returns different bytes exists in the diagnostic build only
     try:
         for opt, v in ok:
             assert lib.tw_set_launch_option(opt, v) == 0, (opt, v)

@@ -95,7 +95,9 @@ def test_side_config_schema():
             # the three collects together: evaluations of all three over the time of all three
             assert v["collects"] == 3 and v["forward_evals"] == 3 * 40 * v["episodes"] and v["records"] == 3 * 10 * v["episodes"]
             assert abs(v["kernel_ms"] - 1.0) < 1e-9 and len(v["per_collect"]) == 3
-            assert v["roofline"]["frac_outputs_of_a_forward_only"] < v["roofline"]["frac"]
+            # roofline.frac is the EXECUTED fraction (outputs that came out of a forward); the reference-equivalent rate is a separate key
+            assert v["roofline"]["frac"] < v["roofline"]["reference_equivalent_frac"]
+            assert abs(v["roofline"]["frac"] / v["roofline"]["reference_equivalent_frac"] - 0.75) < 1e-9       # (40 consumed, 10 of them reused)
     json.dumps(out)
 
 

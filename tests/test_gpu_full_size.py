@@ -116,10 +116,11 @@ def test_config5_selfplay_full_size_vs_oracle(tw, oracle, searches, n_sample):
     probs = t["logits"]
     assert bool((probs >= 0).all()) and bool(((probs.sum(dim=1) - 1.0).abs() < 1e-5).all())     # visit counts / sum
     assert bool((t["perms"] == -1).all())                                                     # az.rs:95
-    # the walker kernel: one workgroup per CU; eight walkers (four of them walk-only waves) below 800 searches per move, four beyond
+    # the walker kernel: one workgroup per CU; eight walkers below 800 searches per move, four beyond
     import twisterl_amd
     assert g.stats["rollout_blocks"] == twisterl_amd.device_info()["compute_units"]
-    assert g.stats["rollout_threads"] == (512 if searches < 800 else 256)
+    # (the decoupled shape: four engine-only waves + eight walkers below 800 searches per move, + four beyond)
+    assert g.stats["rollout_threads"] == (768 if searches < 800 else 512)
     # one root evaluation + at most `searches` leaf evaluations per record, two twists each
     assert 2 * n <= g.stats["forward_evals"] <= 2 * n * (searches + 1)
     h = coll.collect(env, gp, seed=500).to_torch()

@@ -546,6 +546,64 @@ def test_ppo_collect_of_a_python_environment(tw, oracle, w, h, steps, emb, commo
         tw.collector.PPOCollector(4, 0.99, 0.95, 1).collect(tw.env.PyEnv(Broken(w, h, steps)), gp, seed=1)
 
 
+def test_solve_returns_the_solution_an_environment_tracks_itself(tw, oracle):
+    """`Env::track_solution` / `Env::solution` through tw_env_vtable (rust/src/rl/env.rs:61-66): single_solve asks once, before
+    the first move, and then returns the environment's own record instead of the actions it played (rust/src/rl/solve.rs:28,
+    57-64).  A GridWorld that records 1000 x cell + action: ((success, reward), solution) equal to the oracle's generic solve
+    over the same class, for greedy, best-of-N sampled and MCTS-guided solves; the 8-bit entry point refuses such a record; an
+    environment that does not track still gets the played actions; evaluate is unaffected."""
+    import ctypes as C
+    from tests.gridworld_env import GridWorld, TrackingGridWorld
+    from tests.util import make_deep_policy_arrays
+    from twisterl_amd import collector as col
+    w, h, steps = 4, 3, 9
+    n = w * h
+    arrs = make_deep_policy_arrays(n, seed=21, emb=48, common=(64,), scale=2.0)
+    gp, op = amd_policy(arrs), oracle_policy(oracle, arrs)
+    oracle.set_det_exp(True)
+    try:
+        for ep in range(4):
+            cur = TrackingGridWorld(w, h, steps); cur.seed_episode(11, ep); cur.reset(4)
+            plain = GridWorld(w, h, steps); plain.steps_left, plain.agent, plain.goal, plain.trap = cur.steps_left, cur.agent, cur.goal, cur.trap
+            for det, ns, S in ((True, 1, 0), (False, 4, 0), (False, 2, 5)):
+                (gs, gr), gsol = tw.collector.solve(tw.env.PyEnv(cur), gp, det, ns, S, 1.41, 1, seed=9)
+                (os_, or_), osol = oracle.solve_env(cur, op, det, ns, S, 1.41, 1, seed=9)
+                assert (gs, f32_bits(gr)) == (os_, f32_bits(or_)) and gsol == list(osol), (ep, det, ns, S)
+                (ps, pr), pact = tw.collector.solve(tw.env.PyEnv(plain), gp, det, ns, S, 1.41, 1, seed=9)
+                assert (ps, f32_bits(pr)) == (gs, f32_bits(gr))                         # the same attempts ...
+                assert all(a < 4 for a in pact) and [x % 1000 for x in gsol] == pact    # ... reported as played actions / as the env's record
+                assert not gsol or max(gsol) >= 1000 or all(x // 1000 == 0 for x in gsol)
+            assert cur.path == []                                                       # (the caller's object is not touched)
+        # the 8-bit entry point cannot carry this record: TW_ERR_INVALID, never a truncated list
+        cur = TrackingGridWorld(w, h, steps); cur.seed_episode(11, 0); cur.reset(4)
+        br = col._PyEnvBridge(tw.env.PyEnv(cur), prototype=cur.copy())
+        prm = col._solve_params(True, 1, 0, 1.41, 1, 9)
+        acts = (C.c_uint8 * 64)(); s_, r_, n_ = C.c_float(), C.c_float(), C.c_uint32()
+        rc = _lib.lib().tw_solve_env(C.byref(br.vt), gp._handle(), C.byref(prm), 64, C.byref(s_), C.byref(r_), acts, 64, C.byref(n_))
+        assert rc == _lib.TW_ERR_INVALID and b"tw_solve_env32" in _lib.lib().tw_last_error()
+        # evaluate runs the same single_solve (evaluate.rs:36-52): numbers equal to the oracle's with either class
+        proto = TrackingGridWorld(w, h, steps)
+        env = tw.env.PyEnv(proto); env.difficulty = 4
+        ge = tw.collector.evaluate(env, gp, num_episodes=10, deterministic=False, num_searches=2, num_mcts_searches=0, seed=5, C=1.41, max_expand_depth=1, num_cores=4)
+        oe = oracle.evaluate_env(proto, op, 10, False, 2, 0, 1.41, 1, seed=5, difficulty=4)
+        assert f32_bits(ge[0]) == f32_bits(oe[0]) and f32_bits(ge[1]) == f32_bits(oe[1])
+        # the other members of the trait the table now carries reach the Python object
+        assert env.track_solution() is True and tw.env.PyEnv(GridWorld(w, h, steps)).track_solution() is False
+        op_, ap_ = env.twists()
+        assert len(op_) == 2 and sorted(op_[1]) == list(range(n * n)) and ap_[1] == [0, 1, 3, 2] and tw.env.PyEnv(GridWorld(w, h, steps)).twists() == ([], [])
+        bridge = col._PyEnvBridge(env)
+        assert bool(bridge.vt.track_solution) and bool(bridge.vt.solution) and bool(bridge.vt.set_state) and bool(bridge.vt.twists)
+        obs_p, act_p = (C.c_int32 * (2 * n * n))(), (C.c_int32 * 8)()
+        assert bridge.vt.twists(1, obs_p, act_p, 2) == 2 and list(obs_p[n * n:]) == op_[1] and list(act_p[4:]) == [0, 1, 3, 2]
+        st = (C.c_int64 * n)(*([1] + [0] * (n - 3) + [2, 3]))
+        bridge.vt.set_state(1, st, n)
+        assert proto.agent == (0, 0) and proto.goal == ((n - 2) % w, (n - 2) // w) and proto.trap == ((n - 1) % w, (n - 1) // w)
+        plainb = col._PyEnvBridge(tw.env.PyEnv(GridWorld(w, h, steps)))
+        assert not bool(plainb.vt.track_solution) and not bool(plainb.vt.solution) and not bool(plainb.vt.twists) and bool(plainb.vt.set_state)
+    finally:
+        oracle.set_det_exp(False)
+
+
 def test_errors(tw, oracle):
     gp, _ = _pair(oracle, 9, 8, 32, 32)
     with pytest.raises(RuntimeError, match="No data in collected data chunks to merge"):
@@ -851,12 +909,14 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
     beyond, and beyond ten eight x 2 in workgroups of eight waves (from 400 searches on: one up to 3, two below 8) -- at most
     one workgroup per CU, the rest of the episodes comes off the queue.  The parity cases of test_az_collect_bit_exact_vs_oracle
     run all of them; this pins the launches the workgroup shape tells apart, and every pinned shape (TW_OPT_AZ_VARIANT: 4 / 3 /
-    5 / 6 = one / two / four / eight walkers, + 16 / + 32 = 16- / 32-column engine) gives the same bytes as the automatic choice."""
+    5 / 6 = one / two / four / eight walkers, + 16 / + 32 = 16- / 32-column engine, + 128 / + 256 = decoupled engine waves on / off)
+    gives the same bytes as the automatic choice."""
     import twisterl_amd
     cus = twisterl_amd.device_info()["compute_units"]
     gp, _ = _pair(oracle, 9, 2, 32, 128)
     env = tw.env.Puzzle(3, 3, 2, 2, 256)
-    for E, want in ((cus // 2, (cus // 2, 256)), (cus, (cus, 256)), (2 * cus, (cus, 256)), (3 * cus, (cus, 256)), (6 * cus, (cus, 256)), (13 * cus, (cus, 512))):
+    # (from two walkers on, the decoupled shape: four engine-only waves + the walkers = 64 x (4 + walkers) threads)
+    for E, want in ((cus // 2, (cus // 2, 256)), (cus, (cus, 256)), (2 * cus, (cus, 256)), (3 * cus, (cus, 384)), (6 * cus, (cus, 512)), (13 * cus, (cus, 768))):
         d = tw.collector.AZCollector(E, 4 if E <= 8 * cus else 24, 1.41, 1, 1).collect(env, gp, seed=3)     # (very short searches: walker kernel up to 8 episodes per CU)
         assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == want, (E, d.stats["rollout_blocks"], d.stats["rollout_threads"])
     # outputs taken from a grandparent / the chosen child (same board) are part of forward_evals, and counted in reused_evals
@@ -869,7 +929,8 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
     E = 3 * cus
     auto = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
     from twisterl_amd import _lib
-    for variant in (16 + 4, 16 + 3, 16 + 5, 16 + 6, 32 + 4, 32 + 3, 32 + 5, 32 + 6):
+    # ... + 128 / + 256: the decoupled shape (engine-only waves beside the walkers) pinned on / off
+    for variant in (16 + 4, 16 + 3, 16 + 5, 16 + 6, 32 + 4, 32 + 3, 32 + 5, 32 + 6, 256 + 16 + 3, 256 + 16 + 5, 256 + 16 + 6, 128 + 16 + 3, 128 + 16 + 5, 128 + 16 + 6, 256):
         with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, variant):
             pinned = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
         for k in auto:

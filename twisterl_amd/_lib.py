@@ -16,7 +16,7 @@ TW_OK, TW_ERR_INVALID, TW_ERR_UNSUPPORTED, TW_ERR_NO_DEVICE, TW_ERR_HIP, TW_ERR_
 TW_PREC_F32_EXACT, TW_PREC_F16, TW_PREC_F16X2 = 0, 1, 2
 TW_EVAL_FORWARD, TW_EVAL_PREDICT, TW_EVAL_FULL_PREDICT = 0, 1, 2
 TW_OPT_FORCE_GEOM, TW_OPT_NO_PERSIST, TW_OPT_AZ_VARIANT, TW_OPT_AZ_TREE_BUDGET, TW_OPT_AZ_TREE_BUDGET_MIN, TW_OPT_AZ_REUSE = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 5
+ABI_VERSION = 6
 (TW_F_OBS, TW_F_LOGITS, TW_F_PERMS, TW_F_VALUES, TW_F_REWARDS, TW_F_ACTIONS, TW_F_ADVS, TW_F_RETS,
  TW_F_REMAINING, TW_F_EP_LEN, TW_F_EP_START, TW_F_COUNT) = range(12)
 
@@ -83,7 +83,12 @@ class EnvVTable(C.Structure):
                 ("reset", C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)), ("step", C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)),
                 ("observe", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32))), ("masks", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8))),
                 ("reward", C.CFUNCTYPE(C.c_float, C.c_void_p)), ("is_final", C.CFUNCTYPE(C.c_int, C.c_void_p)),
-                ("success", C.CFUNCTYPE(C.c_int, C.c_void_p))]
+                ("success", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+                # the rest of `trait Env` (rust/src/rl/env.rs:30,58-66); NULL = the trait's default body
+                ("track_solution", C.CFUNCTYPE(C.c_int, C.c_void_p)),
+                ("solution", C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32)),
+                ("set_state", C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int64), C.c_uint32)),
+                ("twists", C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32))]
 
 
 class CommId(C.Structure):
@@ -140,6 +145,8 @@ SYMBOLS = {
                                   C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tw_solve_env": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(SolveParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "tw_solve_env32": (C.c_int, [C.POINTER(EnvVTable), _VP, C.POINTER(SolveParams), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                 C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
     "tw_evaluate": (C.c_int, [C.POINTER(PuzzleDesc), _VP, C.POINTER(SolveParams), C.c_uint64, C.c_uint64,
                               C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tw_solve": (C.c_int, [_VP, _VP, C.POINTER(SolveParams), C.POINTER(C.c_float), C.POINTER(C.c_float),

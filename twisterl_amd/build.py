@@ -21,8 +21,11 @@ CSRC = os.path.join(PKG, "csrc")
 # library in its own directory: the product library is never overwritten by an instrumented build, and a process loads the
 # instrumented one only while TW_ABLATE is set.
 ABLATE = bool(os.environ.get("TW_ABLATE"))
-LIB_DIR = os.path.join(PKG, "lib", "ablate") if ABLATE else os.path.join(PKG, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libtwisterl_hip_ablate.so" if ABLATE else "libtwisterl_hip.so")
+# A measurement variant (TW_VARIANT=<name> with TW_EXTRA_FLAGS=-D..., e.g. the builtin forms of the inline-asm MFMAs) likewise
+# builds into, and loads from, a directory of its own.
+VARIANT = os.environ.get("TW_VARIANT", "")
+LIB_DIR = os.path.join(PKG, "lib", "ablate") if ABLATE else os.path.join(PKG, "lib", "variants", VARIANT) if VARIANT else os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libtwisterl_hip_ablate.so" if ABLATE else f"libtwisterl_hip_{VARIANT}.so" if VARIANT else "libtwisterl_hip.so")
 SOURCES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip")))
 # every header is a dependency of every object (an edited header must never leave a stale object behind)
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
@@ -137,8 +140,11 @@ def build_c_example() -> str:
     if _stale(exe, [src, LIB_PATH, os.path.join(ROOT, "include", "twisterl_hip.h")]):
         cmd = ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-L", LIB_DIR, "-ltwisterl_hip",
                "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,$ORIGIN/../twisterl_amd/lib", "-lm", "-o", exe]
-        if ABLATE:
-            return exe                   # (the example links the product library only)
+        if ABLATE or VARIANT:
+            # the example links the PRODUCT library only: an instrumented or variant build neither builds nor uses it
+            if not os.path.exists(exe):
+                raise RuntimeError("examples/collect_from_c is built against the product library: run `python -m twisterl_amd.build` without TW_ABLATE / TW_VARIANT first")
+            return exe
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"gcc failed on collect_from_c.c:\n{r.stdout}")

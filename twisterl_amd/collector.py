@@ -403,15 +403,46 @@ class _PyEnvBridge:
         def f_success(h):
             return 1 if envs[h].success() else 0         # PyEnvImpl::success (pyenv.rs:141-149)
 
+        # The rest of `trait Env` (rust/src/rl/env.rs:30,58-66).  The reference's PyEnvImpl leaves track_solution / solution /
+        # twists at the trait's defaults (python_interface/pyenv.rs implements none of them), so these slots stay NULL unless the
+        # Python object defines the method -- a build extension that gives Python environments what Rust ones have.
+        @guard(0)
+        def f_track(h):
+            return 1 if envs[h].track_solution() else 0
+
+        @guard(0)
+        def f_solution(h, out_p, cap):
+            sol = [int(x) for x in envs[h].solution()]
+            for i in range(min(len(sol), int(cap))):
+                out_p[i] = sol[i]
+            return len(sol)
+
+        @guard()
+        def f_set_state(h, st_p, n):
+            envs[h].set_state([int(st_p[i]) for i in range(int(n))])
+
         n_obs, n_actions = len(proto.observe()), int(proto.num_actions())
         obs_size = 1
         for x in proto.obs_shape():
             obs_size *= int(x)
+
+        @guard(0)
+        def f_twists(h, obs_p, act_p, cap):
+            op, ap = envs[h].twists()
+            for k in range(min(len(op), int(cap))):
+                for i, v in enumerate(op[k]):
+                    obs_p[k * obs_size + i] = int(v)
+                for i, v in enumerate(ap[k]):
+                    act_p[k * n_actions + i] = int(v)
+            return len(op)
+
         fields = dict(V._fields_)
-        self._keep = (f_clone, f_destroy, f_reset, f_step, f_observe, f_masks, f_reward, f_final, f_success)
+        opt = lambda name, fn: fields[name](fn) if callable(getattr(proto, name, None)) else fields[name]()
+        self._keep = (f_clone, f_destroy, f_reset, f_step, f_observe, f_masks, f_reward, f_final, f_success, f_track, f_solution, f_set_state, f_twists)
         self.vt = V(1, n_actions, n_obs, obs_size, fields["clone"](f_clone), fields["destroy"](f_destroy), fields["reset"](f_reset),
                     fields["step"](f_step), fields["observe"](f_observe), fields["masks"](f_masks), fields["reward"](f_reward),
-                    fields["is_final"](f_final), fields["success"](f_success))
+                    fields["is_final"](f_final), fields["success"](f_success),
+                    opt("track_solution", f_track), opt("solution", f_solution), opt("set_state", f_set_state), opt("twists", f_twists))
         self.max_records = int(getattr(proto, "max_records", 1 << 16))
 
     def finish(self, rc):
@@ -499,9 +530,11 @@ def solve(py_env, policy: Policy, deterministic, num_searches, num_mcts_searches
     if isinstance(py_env, PyEnv):
         br = _PyEnvBridge(py_env, prototype=py_env._env.copy())             # (the caller's object is not touched)
         cap = br.max_records + 1
-        acts = (ctypes_u8 * cap)()
+        # 32-bit entries: an environment that tracks its own solution returns THAT (solve.rs:57-64), and its entries need not be actions
+        cap = max(cap, int(getattr(py_env._env, "max_solution", 0)))
+        acts = (_c.c_uint32 * cap)()
         s, r, n = _c.c_float(), _c.c_float(), _c.c_uint32()
-        br.finish(_lib.lib().tw_solve_env(_c.byref(br.vt), policy._handle(), _c.byref(prm), br.max_records, _c.byref(s), _c.byref(r), acts, cap, _c.byref(n)))
+        br.finish(_lib.lib().tw_solve_env32(_c.byref(br.vt), policy._handle(), _c.byref(prm), br.max_records, _c.byref(s), _c.byref(r), acts, cap, _c.byref(n)))
         return (float(s.value), float(r.value)), [int(acts[i]) for i in range(n.value)]
     get_env_desc(py_env)
     cap = int(py_env.depth) + 2

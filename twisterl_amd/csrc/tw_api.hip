@@ -182,11 +182,18 @@ static int arena_acquire(size_t bytes, void **out, size_t *cap)
     return TW_OK;
 }
 
-static void arena_release(void *ptr, size_t cap, int device)
+// `producer`: the stream the result was produced on.  tw_set_stream is thread-local, and a result may be freed by another thread
+// (a Python finalizer, a thread that never called tw_set_stream): the fence has to cover what the PRODUCING stream still has
+// queued on the arena as well as what the freeing thread's stream has (a pack kernel, a gather's copies), so the producer is
+// made to wait for the freeing stream and the release event is recorded on the producer.
+static void arena_release(void *ptr, size_t cap, int device, hipStream_t producer)
 {
     if (!ptr) return;
     hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, current_stream()) != hipSuccess) {
+    const hipStream_t here = current_stream();
+    bool ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    if (ok && here != producer) ok = hipEventRecord(ev, here) == hipSuccess && hipStreamWaitEvent(producer, ev, 0) == hipSuccess;
+    if (!ok || hipEventRecord(ev, producer) != hipSuccess) {
         (void)hipGetLastError();
         if (ev) (void)hipEventDestroy(ev);
         (void)hipFree(ptr);                          // no fence to hand on: let the driver's own (synchronising) free do it
@@ -239,7 +246,7 @@ extern "C" int tw_set_launch_option(int option, int value)
             g_force_geom.store(value); return TW_OK;
         case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
         case TW_OPT_AZ_VARIANT:
-            if (value < 0 || (value & 7) > 6 || (value & ~119) != 0 || (value & 48) == 48) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32) (+ 64)", value); return TW_ERR_INVALID; }
+            if (value < 0 || (value & 7) > 6 || (value & ~503) != 0 || (value & 48) == 48 || (value & 384) == 384) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32) (+ 64) (+ 128 | 256)", value); return TW_ERR_INVALID; }
             g_az_variant.store(value); return TW_OK;
         case TW_OPT_AZ_TREE_BUDGET:
             if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }
@@ -249,6 +256,11 @@ extern "C" int tw_set_launch_option(int option, int value)
             g_az_tree_budget_min.store(value); return TW_OK;
         case TW_OPT_AZ_REUSE:
             if (value < 0 || value > 4) { set_error("TW_OPT_AZ_REUSE: value %d not in {0 .. 4}", value); return TW_ERR_INVALID; }
+#ifndef TW_ABLATE
+            // 2 reads the path level whatever the depth -- another board's output below PATH_DEPTH -- and skips the board check: it
+            // returns different bytes (profiles/r03_az_reuse_probe.txt).  Kept for the record in the diagnostic build only.
+            if (value == 2) { set_error("TW_OPT_AZ_REUSE: 2 is a diagnostic form (wrong below the path depth); the product build takes 0, 1, 3 or 4"); return TW_ERR_INVALID; }
+#endif
             g_az_reuse.store(value); return TW_OK;
         default: set_error("tw_set_launch_option: unknown option %d", option); return TW_ERR_INVALID;
     }
@@ -909,6 +921,7 @@ extern "C" int tw_policy_evaluate(const tw_policy *p, int mode, uint32_t precisi
 struct tw_collected {
     void *arena = nullptr;                  // one allocation holding every compact field (from the arena pool)
     size_t arena_cap = 0; int device = -1;
+    hipStream_t stream = nullptr;           // the library stream of the thread that produced it (tw_set_stream is thread-local)
     uint32_t obs_width = 1;                 // bytes per obs id (2: an environment with more than 256 ids, tw_ppo_collect_env)
     void *field_ptr[TW_F_COUNT] = {};
     size_t field_bytes[TW_F_COUNT] = {};
@@ -1035,6 +1048,7 @@ int collected_adopt(void *arena, size_t arena_bytes, int device, int is_ppo, uin
                     uint64_t n_episodes, void *const (&field_ptr)[TW_F_COUNT], const size_t (&field_bytes)[TW_F_COUNT], tw_collected **out)
 {
     tw_collected *c = new tw_collected();
+    c->stream = current_stream();
     c->arena = arena; c->arena_cap = arena_bytes; c->device = device;
     c->is_ppo = is_ppo; c->n_cells = n_cells; c->n_actions = n_actions; c->n_records = n_records; c->n_episodes = n_episodes;
     for (int f = 0; f < TW_F_COUNT; ++f) { c->field_ptr[f] = field_ptr[f]; c->field_bytes[f] = field_bytes[f]; }
@@ -1047,7 +1061,7 @@ int collected_adopt(void *arena, size_t arena_bytes, int device, int is_ppo, uin
 extern "C" void tw_collected_free(tw_collected *c)
 {
     if (!c) return;
-    arena_release(c->arena, c->arena_cap, c->device);
+    arena_release(c->arena, c->arena_cap, c->device, c->stream);
     delete c;
 }
 
@@ -1247,6 +1261,7 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
 
     // ---- compact result ----------------------------------------------------------------------
     tw_collected *c = new tw_collected();
+    c->stream = current_stream();
     c->n_records = total; c->n_episodes = E; c->n_cells = (uint32_t)ra.env.n_cells; c->n_actions = 4; c->is_ppo = 1;
     size_t ccur = 0;
     auto cseg = [&](int f, size_t bytes) { c->field_bytes[f] = bytes; size_t o = ccur; ccur = align_up(ccur + bytes, 256); return o; };
@@ -1410,9 +1425,14 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
         set_error("az collect: %llu reused network outputs failed the board check", (unsigned long long)host_tot[1 + 12]);
         return TW_ERR_HIP;
     }
+    if (host_tot[1 + 13] != 0) {       // eval_count[13]: the decoupled walker shape's watchdog (a request / completion hand-shake that never completed)
+        set_error("az collect: the walker kernel's watchdog fired (%llu waves gave up waiting)", (unsigned long long)host_tot[1 + 13]);
+        return TW_ERR_HIP;
+    }
     if (total == 0 || total > R) { set_error("az collect: inconsistent record count %llu (max %llu)", (unsigned long long)total, (unsigned long long)R); return TW_ERR_HIP; }
 
     tw_collected *c = new tw_collected();
+    c->stream = current_stream();
     c->n_records = total; c->n_episodes = E; c->n_cells = (uint32_t)ma.env.n_cells; c->n_actions = 4; c->is_ppo = 0;
     size_t ccur = 0;
     auto cseg = [&](int f, size_t bytes) { c->field_bytes[f] = bytes; size_t o = ccur; ccur = align_up(ccur + bytes, 256); return o; };

@@ -15,6 +15,35 @@
 
 #include "twisterl_hip.h"
 
+// LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane from `src` + the lane's `voff` straight into LDS at the wave-uniform byte
+// address in M0 (+ 16 x lane).  Inline asm on purpose: the weight streams are waited for by hand (`s_waitcnt vmcnt(N)` at the points
+// the rings turn), and a load hipcc counted itself would be waited for at every use of LDS it cannot tell apart.  M0 is
+// compiler-reserved and not preserved around a statement, so each statement writes it, uses it and puts the old value back
+// (cdna_hip_programming.md §5.7: naming "m0" as a clobber only draws "clobber list contains reserved registers").  The s_nop 0
+// is the wait state between the SALU write of M0 and the LDS-DMA reading it.
+#define TW_GLDS16(voff, lds_dst, src)                                                                                         \
+    do {                                                                                                                      \
+        uint32_t tw_m0_keep_;                                                                                                 \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"     \
+                     : "=&s"(tw_m0_keep_) : "v"(voff), "s"(lds_dst), "s"(src) : "memory");                                   \
+    } while (0)
+// ... with the LDS address as base + compile-time offset (one SALU add, into M0 directly)
+#define TW_GLDS16_ADD(voff, lds_base, imm, src)                                                                               \
+    do {                                                                                                                      \
+        uint32_t tw_m0_keep_;                                                                                                 \
+        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(tw_m0_keep_) : "v"(voff), "s"(lds_base), "i"(imm), "s"(src) : "memory", "scc");                 \
+    } while (0)
+
+// Inline-asm MFMAs remain in the two f16 engines only (tw_engine16.hpp, tw_engine16x2.hpp: the accumulator as an in/out "v" operand;
+// with the builtin hipcc parks the embedding tiles in AGPRs and shuttles common-layer tiles around them: +17 % and 2.7 x,
+// profiles/r04_mfma_intrinsic_vs_asm.txt).  An asm MFMA gets no hazard padding from hipcc: twisterl_amd/build.py scans the assembly of
+// every build for that (scripts/scan_mfma_hazards.py).  -DTW_MFMA_INTRIN=<mask> compiles a site with the builtin instead (the
+// measurement: TW_VARIANT=intrin): bit 3 Engine16, bit 4 Engine16x2.  (Engine3S and Engine3T use the builtin since round 4.)
+#ifndef TW_MFMA_INTRIN
+#define TW_MFMA_INTRIN 0
+#endif
+
 namespace tw {
 
 // ---- error plumbing ------------------------------------------------------------------------

@@ -84,9 +84,7 @@ struct Engine16 {
     // (M0 = wave-uniform destination, the hardware adds lane*16).  Inline asm: see the LDS-DMA note in tw_engine.hpp.
     __device__ __forceinline__ void stream_op(const uint8_t *stage_base, uint32_t slot_m0, int op) const
     {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                     :: "v"(voff), "s"(slot_m0 + (uint32_t)op * (NW * 1024u)), "s"(stage_base + (size_t)op * (NW * 1024))
-                     : "memory");     // m0 is not saved: nothing hipcc emits for gfx950 in this kernel keeps a value in it
+        TW_GLDS16(voff, slot_m0 + (uint32_t)op * (NW * 1024u), stage_base + (size_t)op * (NW * 1024));      // (M0 saved and restored: tw_common.hpp)
     }
     __device__ __forceinline__ const uint8_t *stage_ptr(int stage) const { return pol.stage16 + (size_t)stage * SBYTES; }
     __device__ __forceinline__ uint32_t slot_m0(int slot) const { return lds_u32 + O_RING + (uint32_t)slot * SBYTES + (uint32_t)wave * 1024u; }
@@ -190,7 +188,8 @@ struct Engine16 {
     // The first MFMA of a chain takes the embedding bias (f32, accumulator-register order) as its C operand.
     static __device__ __forceinline__ void mfma_v(f32x16 &d, const h16x8 a, const h16x8 b, bool first, const f32x16 &c0)
     {
-        if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c0));
+        if constexpr (TW_MFMA_INTRIN & 8) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, first ? c0 : d, 0, 0, 0);
+        else if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c0));
         else       asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
     // one B register: accumulator registers (2q, 2q+1) of fragment m (+ bias), optional ReLU, to f16

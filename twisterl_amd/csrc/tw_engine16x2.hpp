@@ -61,9 +61,7 @@ struct EngineS {
 
     __device__ __forceinline__ void stream_op(const uint8_t *stage_base, uint32_t slot_m0, int op) const
     {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                     :: "v"(voff), "s"(slot_m0 + (uint32_t)op * (NW * 1024u)), "s"(stage_base + (size_t)op * (NW * 1024))
-                     : "memory");
+        TW_GLDS16(voff, slot_m0 + (uint32_t)op * (NW * 1024u), stage_base + (size_t)op * (NW * 1024));      // (M0 saved and restored: tw_common.hpp)
     }
     __device__ __forceinline__ const uint8_t *stage_ptr(int stage) const { return pol.stageS + (size_t)stage * SBYTES; }
     __device__ __forceinline__ uint32_t slot_m0(int slot) const { return lds_u32 + O_RING + (uint32_t)slot * SBYTES + (uint32_t)wave * 1024u; }
@@ -154,7 +152,8 @@ struct EngineS {
     __device__ __forceinline__ h16x8 ld8(uint32_t off) const { return *(const __attribute__((address_space(3))) h16x8 *)(L + off); }
     static __device__ __forceinline__ void mfma_v(f32x16 &d, const h16x8 a, const h16x8 b, bool first, const f32x16 &c0)
     {   // accumulator in architectural VGPRs (see tw_engine16.hpp)
-        if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c0));
+        if constexpr (TW_MFMA_INTRIN & 16) d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, first ? c0 : d, 0, 0, 0);
+        else if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c0));
         else       asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
     }
     // accumulator registers (2q, 2q+1) of fragment m -> one register of the hi fragment and one of the lo fragment:

@@ -478,7 +478,7 @@ extern "C" int tw_az_collect_env(const tw_env_vtable *env, const tw_policy *poli
 namespace {
 
 int run_attempts_env(const tw_env_vtable *env, const tw_policy *policy, const tw_solve_params *prm, uint64_t n_episodes, uint64_t episode_offset,
-                     bool from_state, uint32_t max_steps, std::vector<float> &best_s, std::vector<float> &best_r, std::vector<uint8_t> *best_actions)
+                     bool from_state, uint32_t max_steps, std::vector<float> &best_s, std::vector<float> &best_r, std::vector<uint32_t> *best_actions)
 {
     if (prm->precision != TW_PREC_F32_EXACT) { set_error("solve: f32 only for this environment"); return TW_ERR_UNSUPPORTED; }
     if (!env->success) { set_error("solve / evaluate: the environment table has no success()"); return TW_ERR_INVALID; }
@@ -490,7 +490,7 @@ int run_attempts_env(const tw_env_vtable *env, const tw_policy *policy, const tw
     const uint32_t A = env->num_actions, NO = env->n_obs;
     const uint64_t N = prm->num_searches, NA = n_episodes * N;
     const bool mcts = prm->num_mcts_searches != 0;
-    struct Att { void *env = nullptr; bool done = false; uint32_t t = 0; float total = 0.0f, success = 0.0f; HostMcts mc; std::vector<uint8_t> actions; int32_t perm = -1; };
+    struct Att { void *env = nullptr; bool done = false, track = false; uint32_t t = 0; float total = 0.0f, success = 0.0f; HostMcts mc; std::vector<uint32_t> actions; int32_t perm = -1; };
     std::vector<Att> at(NA);
     auto cleanup = [&]() { for (auto &a : at) { a.mc.clear(); if (a.env) { env->destroy(a.env); a.env = nullptr; } } };
     auto key_of = [&](uint64_t i) { return (episode_offset + i / N) * N + i % N; };
@@ -500,13 +500,25 @@ int run_attempts_env(const tw_env_vtable *env, const tw_policy *policy, const tw
         a.env = env->clone(env->prototype);                                  // solve.rs:85 / evaluate.rs:39
         if (!a.env) { cleanup(); set_error("solve: clone() returned null"); return TW_ERR_INVALID; }
         if (!from_state) env->reset(a.env, prm->seed, episode_offset + i / N);
+        a.track = env->track_solution && env->track_solution(a.env);        // solve.rs:28: asked once, before the first move
     }
     HostEvalBatch eb{env, pd, A, NO, current_stream()};
     rc = eb.init(NA); if (rc) { cleanup(); return rc; }
     std::vector<void *> want_state(NA, nullptr);
     std::vector<float> mp;
     bool overlong = false;
-    auto finish = [&](Att &a) { a.total = a.total + env->reward(a.env); a.success = env->success(a.env) ? 1.0f : 0.0f; a.done = true; };   // solve.rs:65-68
+    // the end of single_solve (solve.rs:62-70): an environment that tracks its own solution hands it over in place of the played actions
+    auto finish = [&](Att &a) {
+        if (a.track) {
+            a.actions.clear();
+            if (env->solution) {
+                const uint32_t n = env->solution(a.env, nullptr, 0);
+                a.actions.resize(n);
+                if (n) env->solution(a.env, a.actions.data(), n);
+            }
+        }
+        a.total = a.total + env->reward(a.env); a.success = env->success(a.env) ? 1.0f : 0.0f; a.done = true;
+    };
     // the move of attempt i given the action probabilities (solve.rs:31-58)
     auto move = [&](uint64_t i, const float *probs) {
         Att &a = at[i];
@@ -519,8 +531,8 @@ int run_attempts_env(const tw_env_vtable *env, const tw_policy *policy, const tw
             const u32x4 w = rng_draw(prm->seed, key_of(i), a.t, STREAM_SOLVE);
             action = sample_weighted_host(probs, (int)A, u32_to_unit(w.x));
         }
-        a.actions.push_back((uint8_t)action);
         env->step(a.env, (uint32_t)action);
+        if (!a.track) a.actions.push_back((uint32_t)action);                // solve.rs:57-59
         ++a.t;
         if (env->is_final(a.env)) finish(a);
         else if (a.t >= max_steps) { a.done = true; overlong = true; }
@@ -590,18 +602,37 @@ extern "C" int tw_evaluate_env(const tw_env_vtable *env, const tw_policy *policy
     return TW_OK;
 }
 
+extern "C" int tw_solve_env32(const tw_env_vtable *env, const tw_policy *policy, const tw_solve_params *prm, uint32_t max_steps,
+                              float *success, float *reward, uint32_t *solution_out, uint32_t solution_cap, uint32_t *n_solution)
+{
+    if (!env || !policy || !prm || !success || !reward) { set_error("tw_solve_env: null argument"); return TW_ERR_INVALID; }
+    std::vector<float> bs, br; std::vector<uint32_t> acts;
+    const int rc = run_attempts_env(env, policy, prm, 1, 0, true, max_steps ? max_steps : 1u, bs, br, &acts);
+    if (rc) return rc;
+    *success = bs[0]; *reward = br[0];
+    if (n_solution) *n_solution = (uint32_t)acts.size();
+    if (solution_out) {
+        if (acts.size() > solution_cap) { set_error("tw_solve_env: %zu entries, caller's buffer holds %u", acts.size(), solution_cap); return TW_ERR_INVALID; }
+        if (!acts.empty()) memcpy(solution_out, acts.data(), acts.size() * sizeof(uint32_t));
+    }
+    return TW_OK;
+}
+
 extern "C" int tw_solve_env(const tw_env_vtable *env, const tw_policy *policy, const tw_solve_params *prm, uint32_t max_steps,
                             float *success, float *reward, uint8_t *actions_out, uint32_t actions_cap, uint32_t *n_actions)
 {
     if (!env || !policy || !prm || !success || !reward) { set_error("tw_solve_env: null argument"); return TW_ERR_INVALID; }
-    std::vector<float> bs, br; std::vector<uint8_t> acts;
+    std::vector<float> bs, br; std::vector<uint32_t> acts;
     const int rc = run_attempts_env(env, policy, prm, 1, 0, true, max_steps ? max_steps : 1u, bs, br, &acts);
     if (rc) return rc;
     *success = bs[0]; *reward = br[0];
     if (n_actions) *n_actions = (uint32_t)acts.size();
     if (actions_out) {
         if (acts.size() > actions_cap) { set_error("tw_solve_env: %zu actions, caller's buffer holds %u", acts.size(), actions_cap); return TW_ERR_INVALID; }
-        if (!acts.empty()) memcpy(actions_out, acts.data(), acts.size());
+        for (size_t i = 0; i < acts.size(); ++i) {
+            if (acts[i] > 255u) { set_error("tw_solve_env: entry %zu of the tracked solution is %u; use tw_solve_env32", i, acts[i]); return TW_ERR_INVALID; }
+            actions_out[i] = (uint8_t)acts[i];
+        }
     }
     return TW_OK;
 }

@@ -7,7 +7,7 @@
 //    GAE recurrence exactly as written in rust/src/collector/ppo.rs:82-92 (sequential in t,
 //    no contraction: the library is built with -ffp-contract=off), and copies every field of
 //    the episode into its compact slot with coalesced loads/stores.  HBM-bound byte moving;
-//    algorithmic traffic = N^2+34 B written + one 48-B padded record read per record.
+//    algorithmic traffic = N^2+34 B written + one 48-B padded record read per record (each record is read ONCE).
 #include "tw_common.hpp"
 
 namespace tw {
@@ -132,14 +132,28 @@ int launch_scan(const uint32_t *ep_len, uint64_t E, int merge_order, uint64_t *e
 // ---- GAE + compaction ---------------------------------------------------------------------
 constexpr int FIN_WAVES = 4;   // episodes per workgroup (one per wave); fewer when the episode tile would not fit 64 KiB of LDS
 
+// bytes of LDS one episode (one wave) needs: [obs staging: 16 B per record, boards below 16 cells only] | rewards | values | advs |
+// rets | action/perm word -- rounded to 16 bytes so that the staging of the next wave stays aligned
+static __host__ __device__ inline size_t fin_wave_bytes(int t_pad, int n_cells)
+{
+    return (((size_t)(n_cells == 16 ? 5 : 9) * (size_t)t_pad * 4) + 15) / 16 * 16;
+}
+
+// One wave per episode.  Every 48-byte padded record is READ ONCE: the wave walks the episode's records as one run of 16-byte
+// words (lane i takes word i, i + 64, ..: full cache lines), and each word goes where it belongs -- word 0 (the board as obs
+// bytes) and word 1 (the four logits) straight to their compact rows, word 2 (value, reward, action | twist) into LDS for the
+// GAE chain.  (Until round 4 the three words were read in three passes at a 48-byte stride; with more episodes in flight than
+// L2 holds, each pass fetched every line again: 188 B of HBM traffic per record against 100 algorithmic.)
 __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const PaddedTraj in, const uint64_t *ep_start,
                                                                       uint64_t E, int n_cells, float gamma, float lambda,
                                                                       const CompactTraj out)
 {
-    extern __shared__ __attribute__((aligned(16))) float fin_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t fin_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int t_pad = in.t_pad;
-    float *sr = fin_lds + (size_t)wave * 5 * t_pad;   // rewards | values | advs | rets | action/perm word
+    uint8_t *base = fin_lds + (size_t)wave * fin_wave_bytes(t_pad, n_cells);
+    uint4 *so = reinterpret_cast<uint4 *>(base);                                            // (n_cells < 16 only)
+    float *sr = reinterpret_cast<float *>(base + (n_cells == 16 ? 0 : (size_t)t_pad * 16));    // rewards | values | advs | rets | action/perm word
     float *sv = sr + t_pad, *sa = sv + t_pad, *st = sa + t_pad;
     uint32_t *sz = reinterpret_cast<uint32_t *>(st + t_pad);
 
@@ -147,13 +161,20 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
         const int      n     = (int)in.ep_len[e];
         const uint64_t src   = e * (uint64_t)t_pad;
         const uint64_t dst   = ep_start[e];
-        for (int t = lane; t < n; t += 64) {
-            const uint4 w = reinterpret_cast<const uint4 *>(in.rec + src + t)[2];
-            sv[t] = __builtin_bit_cast(float, w.x); sr[t] = __builtin_bit_cast(float, w.y); sz[t] = w.z;
+        const uint4 *rec4 = reinterpret_cast<const uint4 *>(in.rec + src);
+        uint4 *obs4 = reinterpret_cast<uint4 *>(out.obs), *logits4 = reinterpret_cast<uint4 *>(out.logits);
+        for (int w = lane; w < 3 * n; w += 64) {
+            const uint4 v = rec4[w];
+            const int t = w / 3, part = w - 3 * t;
+            if (part == 2) { sv[t] = __builtin_bit_cast(float, v.x); sr[t] = __builtin_bit_cast(float, v.y); sz[t] = v.z; }
+            else if (part == 1) logits4[dst + t] = v;
+            else if (n_cells == 16) obs4[dst + t] = v;
+            else so[t] = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // GAE (ppo.rs:82-92): every lane walks the same chain (LDS broadcast reads); lane 0 stores
+        // GAE (ppo.rs:82-92): every lane walks the same chain (LDS broadcast reads); lane 0 stores.  A serial chain on purpose:
+        // a segmented scan would re-associate the sums (<= 1e-5 of this, not the same bits) for <= 2 ms of a 140 ms step.
         {
             float adv = sr[n - 1] - sv[n - 1];
             float ret = sr[n - 1];
@@ -174,19 +195,16 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
             out.rewards[dst + t] = sr[t];
             out.advs[dst + t]    = sa[t];
             out.rets[dst + t]    = st[t];
-            const uint32_t wz = sz[t];                 // (the third 16 bytes of the record were read once, above)
+            const uint32_t wz = sz[t];
             out.actions[dst + t] = (uint8_t)(wz & 0xffu);
             out.perms[dst + t]   = (int8_t)((wz >> 8) & 0xffu);
-            reinterpret_cast<uint4 *>(out.logits)[dst + t] = reinterpret_cast<const uint4 *>(in.rec + src + t)[1];
         }
-        if (n_cells == 16) {
-            for (int t = lane; t < n; t += 64)
-                reinterpret_cast<uint4 *>(out.obs)[dst + t] = reinterpret_cast<const uint4 *>(in.rec + src + t)[0];
-        } else {
+        if (n_cells != 16) {                           // compact rows of n_cells bytes out of the staged 16-byte ones
+            const uint8_t *sob = reinterpret_cast<const uint8_t *>(so);
             const int nb = n * n_cells;
             for (int i = lane; i < nb; i += 64) {
                 const int t = i / n_cells, c = i - t * n_cells;
-                out.obs[dst * n_cells + i] = in.rec[src + t].obs[c];
+                out.obs[dst * n_cells + i] = sob[t * 16 + c];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -197,9 +215,9 @@ int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t
                         float lambda, const CompactTraj &out, hipStream_t s)
 {
     if (E == 0) return TW_OK;
-    const size_t per_wave = (size_t)5 * in.t_pad * sizeof(float);
+    const size_t per_wave = fin_wave_bytes(in.t_pad, n_cells);
     int waves = FIN_WAVES;
-    while (waves > 1 && waves * per_wave > 64 * 1024) waves >>= 1;           // long horizons (t_pad > 819): fewer episodes per workgroup
+    while (waves > 1 && waves * per_wave > 64 * 1024) waves >>= 1;           // long horizons: fewer episodes per workgroup
     const size_t lds_bytes = waves * per_wave;
     if (lds_bytes > 64 * 1024) { set_error("finalize: t_pad %d too large for the LDS tile", in.t_pad); return TW_ERR_UNSUPPORTED; }
     uint64_t blocks = (E + waves - 1) / waves;

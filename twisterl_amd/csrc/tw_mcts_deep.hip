@@ -100,10 +100,12 @@ __device__ __forceinline__ uint32_t lk_nch(uint32_t link) { return (link >> 24) 
 __device__ __forceinline__ int      lk_act(uint32_t link) { return (int)((link >> 27) & 3u); }
 
 // floats of LDS beyond the engine's area: request boards [C][2] | results [C][8] | per walker: hot table [lds_nodes][4] | q / sqrt table [lds_nodes][2] | pool idx [POOL] | pool outputs [POOL][8]
-__host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers)
+__host__ __device__ inline size_t deep_extra_floats(int columns, uint32_t lds_nodes, int walkers, bool dec = false)
 {
-    // (+ 24: the walkers' alive flags and waiting flags; eight walkers: + 64 dwords each, where the wave-uniform walker state waits during a forward)
-    return (size_t)columns * 10 + 24 + (walkers > DEEP_WAVES ? (size_t)walkers * 64 : 0) +
+    // (+ 24: the walkers' alive flags and waiting flags -- decoupled shape: request / done sequence numbers and dead flags, + 16 for the
+    //  engine waves' barrier counter, batch word and snapshot; eight walkers, coupled: + 64 dwords each, where the wave-uniform walker
+    //  state waits during a forward)
+    return (size_t)columns * 10 + 24 + (dec ? 16 : 0) + ((!dec && walkers > DEEP_WAVES) ? (size_t)walkers * 64 : 0) +
            (size_t)walkers * ((size_t)lds_nodes * 6 + deep_pool(walkers) + deep_pool(walkers) * 8);
 }
 
@@ -112,8 +114,14 @@ __device__ unsigned long long g_deep_stamps[16];
 __device__ unsigned long long g_deep_extra[4];
 #endif
 
-template <int NT, int NC, int NW, int NWK, bool SOLVE = false>
-__global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(const MctsArgs a)
+// DEC, the decoupled shape (round 4): the four engine waves ONLY run forwards, NWK more waves ONLY walk (4 + NWK waves per workgroup).
+// A walker that needs an output posts its columns and waits for THAT forward; a walker that needs none is never stopped -- in the
+// coupled shapes every forward is a workgroup barrier, and 68 % of the walker trips of a 4,096 x 1,000 collect were walkers stopped in
+// the middle of a streak because a neighbour needed a forward (profiles/r03_az_walker_stamps.txt: "yielded").  The engine waves
+// synchronise among themselves through an LDS counter (Engine3T::fsync<true>): the hardware barrier counts every wave of the workgroup.
+// Requests / completions are sequence numbers in LDS; every spin is bounded (a watchdog sets MctsArgs::eval_count[13] and everybody leaves).
+template <int NT, int NC, int NW, int NWK, bool SOLVE = false, bool DEC = false>
+__global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256)), 1) mcts_deep_kernel(const MctsArgs a)
 {
     using Eng = typename Geom<NT, NC, 0, NW>::Eng;
     typedef unsigned int ux4 __attribute__((ext_vector_type(4)));
@@ -123,7 +131,8 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     typedef __attribute__((address_space(3))) float lds_f32;
     constexpr int C = Eng::EPB, CPW = C / NWK;             // MFMA columns of the workgroup, columns per walker
-    constexpr int TWV = NWK > DEEP_WAVES ? NWK : DEEP_WAVES;   // waves per workgroup
+    constexpr int TWV = DEC ? DEEP_WAVES + NWK : (NWK > DEEP_WAVES ? NWK : DEEP_WAVES);   // waves per workgroup
+    constexpr bool PARK = !DEC && TWV > DEEP_WAVES;            // coupled eight-walker shape: the walker state waits in LDS during a forward
     constexpr int DEEP_POOL = deep_pool(NWK);
     static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WAVES && NWK >= 1 && NWK <= 8 && CPW >= 2 && CPW <= 64, "one walker per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,13 +152,17 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     float *xbase = lds + Eng::lds_floats(a.pol);
     uint2 *req = reinterpret_cast<uint2 *>(xbase);                               // request boards [C]
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
-    const bool walker = wave < NWK;                                              // (waves NWK..3 only run the forward)
+    const bool walker = DEC ? wave >= DEEP_WAVES : wave < NWK;                   // (coupled: waves NWK..3 only run the forward; decoupled: waves 0..3)
+    const int  wk = walker ? (DEC ? wave - DEEP_WAVES : wave) : 0;               // this wave's walker number inside the workgroup
     int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][TWV waves]: walker still has an episode
     // [8]: walker w has stopped in front of a forward it needs (demand / new root).  An LDS-typed pointer: through a generic one the
     // eight polls of a search pass were eight serialised flat loads (hundreds of cycles each); now two 16-byte LDS reads
     volatile lds_u32 *wait_f = (volatile lds_u32 *)(res + 8 * C + 16);
-    float *park_base = res + 8 * C + 24;                                         // [TWV][64] parked walker state (eight-walker shape)
-    float *wbase = park_base + (TWV > DEEP_WAVES ? TWV * 64 : 0) + (size_t)(walker ? wave : 0) * ((size_t)NL * 6 + DEEP_POOL + DEEP_POOL * 8);
+    // decoupled shape: the same 24 dwords hold rq_seq[8] (walker w has posted request number ..) | dn_seq[8] (.. has been served up to ..) |
+    // dead_f[8], and 16 more: the engine waves' barrier counter, the batch word, the watchdog flag, the snapshot of rq_seq of a batch
+    volatile lds_u32 *ctl = (volatile lds_u32 *)(res + 8 * C);
+    float *park_base = res + 8 * C + 24 + (DEC ? 16 : 0);                        // [TWV][64] parked walker state (coupled eight-walker shape)
+    float *wbase = park_base + (PARK ? TWV * 64 : 0) + (size_t)wk * ((size_t)NL * 6 + DEEP_POOL + DEEP_POOL * 8);
     lds_u4  *tbl  = (lds_u4 *)wbase;                                             // hot quads of nodes 0 .. NL-1
     lds_u2  *tq   = (lds_u2 *)(wbase + (size_t)NL * 4);                          // q, sqrt(visit) of nodes 0 .. NL-1
     lds_u32 *pidx = (lds_u32 *)(wbase + (size_t)NL * 6);                         // pool: node index (DNONE = free)
@@ -157,7 +170,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 
     const uint32_t S = a.num_searches, MED = a.max_expand_depth;
     const uint64_t E = a.num_episodes;
-    const uint64_t slot = (uint64_t)blockIdx.x * NWK + (uint64_t)(walker ? wave : 0);     // walker = tree arena index
+    const uint64_t slot = (uint64_t)blockIdx.x * NWK + (uint64_t)wk;                      // walker = tree arena index
     uint8_t *arena_w = reinterpret_cast<uint8_t *>(a.arena) + slot * (uint64_t)mcts_deep_arena_bytes(a.node_cap);
     ux4   *hotq = reinterpret_cast<ux4 *>(arena_w);                                   // [node_cap] statistics
     uint4 *brdq = reinterpret_cast<uint4 *>(arena_w + (size_t)a.node_cap * 16);       // [node_cap] boards
@@ -270,11 +283,17 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     // The walkers take the episodes in MctsArgs::order, the ones that look longest first; MctsArgs::order_across: dealt out ACROSS
     // the workgroups at launch (walker w of workgroup b starts with number w * workgroups + b), from the queue afterwards.
     auto nth = [&](uint64_t q) -> uint64_t { return a.order ? (uint64_t)uniu(a.order[q]) : q; };
-    const uint64_t first = (a.order && a.order_across) ? (uint64_t)(walker ? wave : 0) * gridDim.x + blockIdx.x : slot;
+    const uint64_t first = (a.order && a.order_across) ? (uint64_t)wk * gridDim.x + blockIdx.x : slot;
     if (walker && first < E) take(nth(first));
     if (walker && lane < DEEP_POOL) pidx[lane] = DNONE;
     if (!walker) more = false;
-    if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[TWV + wave] = phase != DP_DEAD ? 1 : 0; wait_f[wave] = 0; if (wave + 4 < 8) wait_f[wave + 4] = 0; }
+    if constexpr (DEC) {
+        if (threadIdx.x < 40) ctl[threadIdx.x] = 0u;                               // sequence numbers, dead flags, barrier counter, batch, watchdog
+        if (threadIdx.x < C) req[threadIdx.x] = make_uint2((uint32_t)env.ident, (uint32_t)(env.ident >> 32));   // (a column nobody has asked for yet holds a valid board)
+        if constexpr (DEC) eng.ebar_cnt = ctl + 24;
+    } else {
+        if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[TWV + wave] = phase != DP_DEAD ? 1 : 0; wait_f[wave] = 0; if (wave + 4 < 8) wait_f[wave + 4] = 0; }
+    }
     __syncthreads();
 
     uint32_t obs_base[4];
@@ -288,6 +307,12 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     // request columns of this walker for the next forward: the demand + up to CPW-1 unevaluated frontier nodes in creation order
     auto assemble = [&]() {
         my_take = false; n_spec = 0;
+        if constexpr (DEC) {
+            // decoupled shape: walker w owns columns [w * CPW, (w + 1) * CPW) for good (a finished walker's columns idle)
+            if (!walker || phase == DP_DEAD) { my_share = 0; return; }
+            my_share = CPW; my_base = wk * CPW;
+            ++trip;
+        } else {
         // publish whether this walker still has an episode (read by everybody one trip later: a walker that ran out THIS trip
         // keeps its columns for one more forward and fills them with the identity board)
         alive_f[(trip & 1u) * TWV + wave] = (walker && phase != DP_DEAD) ? 1 : 0;      // (every lane stores the same value)
@@ -300,6 +325,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         if (!mine) { my_share = 0; return; }
         my_share = C / n_alive; my_base = rank_me * my_share;
         if (rank_me == n_alive - 1) my_share = C - my_base;                  // the last one takes the remainder (16 = 5 + 5 + 6)
+        }
         const uint64_t ident = env.ident;
         if (phase == DP_DEAD) {
             if (lane < my_share) req[my_base + lane] = make_uint2((uint32_t)ident, (uint32_t)(ident >> 32));
@@ -350,7 +376,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
     // while the forward runs: one dword per value and wave.
     volatile lds_u32 *pkw = (volatile lds_u32 *)(park_base + wave * 64);
     auto park = [&]() {
-        if constexpr (TWV > DEEP_WAVES) {
+        if constexpr (PARK) {
             {   // (every lane stores the same dword: no lane-0 branch in the walker's scalar control flow)
                 pkw[0] = (uint32_t)st.board; pkw[1] = (uint32_t)(st.board >> 32); pkw[2] = (uint32_t)st.zx; pkw[3] = (uint32_t)st.zy; pkw[4] = (uint32_t)st.depth;
                 pkw[5] = (uint32_t)cur.board; pkw[6] = (uint32_t)(cur.board >> 32); pkw[7] = (uint32_t)cur.zx; pkw[8] = (uint32_t)cur.zy; pkw[9] = (uint32_t)cur.depth;
@@ -365,7 +391,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         }
     };
     auto unpark = [&]() {
-        if constexpr (TWV > DEEP_WAVES) {
+        if constexpr (PARK) {
             st.board = ((uint64_t)uniu(pkw[1]) << 32) | uniu(pkw[0]); st.zx = (int)uniu(pkw[2]); st.zy = (int)uniu(pkw[3]); st.depth = (int)uniu(pkw[4]);
             cur.board = ((uint64_t)uniu(pkw[6]) << 32) | uniu(pkw[5]); cur.zx = (int)uniu(pkw[7]); cur.zy = (int)uniu(pkw[8]); cur.depth = (int)uniu(pkw[9]);
             e_local = ((uint64_t)uniu(pkw[11]) << 32) | uniu(pkw[10]);
@@ -386,10 +412,113 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         }
     };
 
+    // ---- Policy::full_predict of the C requested boards (policy.rs:102-126): the engine waves; `batch` (decoupled shape): bit w = walker w is served
+    auto run_forward = [&](uint32_t batch) {
+        (void)batch;
+        const uint2 rb = req[col];
+        const uint64_t board = ((uint64_t)rb.y << 32) | rb.x;
+        float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
+        const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
+        const float np = (float)eng.pol.n_perms;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const int perm = eng.pol.n_perms > 0 ? pass : -1;
+            int rowoff[NC];
+            eng.rows_of(board, env.n_cells, perm, rowoff);
+            float lg[4], v;
+            if constexpr (DEC) eng.template forward<true>(rowoff, lg, v); else eng.forward(rowoff, lg, v);     // (DEC: Engine3T with its engine-only barrier)
+            eng.act_perm(perm, lg);
+            if (eng.pol.n_perms > 0) {
+                vsum = vsum + v / np;                                            // policy.rs:111
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lsum[i] = lsum[i] + lg[i] / np;      // policy.rs:112-114
+            } else {
+                vsum = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lsum[i] = lg[i];
+            }
+        }
+        PuzzleLane lf; lf.board = board; lf.depth = 0;
+        const int z = blank_cell(board);
+        lf.zx = z % env.width; lf.zy = z / env.width;
+        float probs[4];
+        masked_softmax4(lsum, puzzle_maskbits(lf, env), probs);
+        // every engine wave holds every column's output: wave w publishes the columns of walker w, for itself -- or, when
+        // there are walkers beyond the engine waves, every fourth column for everybody
+        // (decoupled shape: only the columns of the walkers this forward serves -- the others may still be reading their last results)
+        const bool pub = DEC ? ((col & 3) == wave && ((batch >> (col / CPW)) & 1u) != 0u) : (TWV > DEEP_WAVES ? (col & 3) == wave : (col >= my_base && col < my_base + my_share));
+        if (eng.h == 0 && pub) {
+            float4 *dst = reinterpret_cast<float4 *>(res + col * 8);
+            dst[0] = make_float4(probs[0], probs[1], probs[2], probs[3]);
+            dst[1] = make_float4(vsum, 0.0f, 0.0f, 0.0f);
+        }
+    };
+
+    // ---- decoupled shape: request / completion hand-shake between the walkers and the engine waves (LDS, sequence numbers) -------------
+    uint32_t my_seq = 0;                                        // walker: requests posted so far
+    bool     aborted = false;
+    constexpr uint32_t SPIN_LIMIT = 1u << 25;                   // x >= ~100 cycles per poll: seconds -- a hand-shake bug ends the kernel instead of hanging the GPU
+    auto watchdog = [&]() { aborted = true; ctl[26] = 1u; if (lane == 0) atomicAdd(a.eval_count + 13, 1ull); };
+    auto post = [&]() {                                         // this walker's columns are in `req`: ask for a forward
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ++my_seq;
+        ctl[wk] = my_seq;
+    };
+    auto mark_dead = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ctl[16 + wk] = 1u;
+    };
+    auto wait_result = [&]() {
+        uint32_t spins = 0;
+        while (uniu(ctl[8 + wk]) != my_seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT || uniu(ctl[26]) != 0u) { if (spins > SPIN_LIMIT) watchdog(); aborted = true; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+
     if (engw) eng.begin2();
     assemble();
     int live = phase != DP_DEAD ? 1 : 0;
     park();
+    if constexpr (DEC) {
+        if (walker) { if (phase != DP_DEAD) post(); else mark_dead(); }
+        if (engw) {
+            // ---- the engine waves: serve forwards until every walker is done.  Wave 0 polls the walkers' request numbers and publishes
+            //      the batch (which walkers this forward serves) -- the other three wait for it in the engine barrier.
+            uint32_t served[NWK];
+#pragma unroll
+            for (int w = 0; w < NWK; ++w) served[w] = 0u;
+            for (;;) {
+                uint32_t mask = 0u;
+                if (wave == 0) {
+                    uint32_t spins = 0, ndead = 0;
+                    for (;;) {
+                        mask = 0u; ndead = 0u;
+#pragma unroll
+                        for (int w = 0; w < NWK; ++w) {
+                            const uint32_t r = uniu(ctl[w]);
+                            ndead += uniu(ctl[16 + w]);
+                            if (r != served[w]) { mask |= 1u << w; ctl[28 + w] = r; }
+                        }
+                        if (mask != 0u || ndead == (uint32_t)NWK || uniu(ctl[26]) != 0u) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > SPIN_LIMIT) { watchdog(); break; }
+                    }
+                    // (a walker posts before it can be dead: no request is pending once all are dead)
+                    ctl[25] = (mask != 0u && uniu(ctl[26]) == 0u) ? mask : 0x80000000u;
+                }
+                if constexpr (DEC) eng.template fsync<true, true>();    // (waves 1 .. 3 idle here, asleep between polls: they share their SIMDs with the walkers)
+                const uint32_t batch = uniu(ctl[25]);
+                if (batch & 0x80000000u) break;
+                run_forward(batch);
+                if constexpr (DEC) eng.template fsync<true>();    // every served column's result is in `res`
+                if (wave == 0) {
+#pragma unroll
+                    for (int w = 0; w < NWK; ++w) if ((batch >> w) & 1u) { served[w] = uniu(ctl[28 + w]); ctl[8 + w] = served[w]; }
+                }
+            }
+        }
+    }
 
 #ifdef TW_ABLATE
     unsigned long long c_fwd = 0, c_tree = 0, c_bar = 0, c_trips = 0, c_search = 0, c_hits = 0, c_asm = 0, c_yield = 0, c_root = 0, c_dead = 0, c_nspec = 0;
@@ -400,60 +529,35 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
 #define TW_DS(var)
 #define TW_DA(acc, x, y)
 #endif
-    for (;;) {
+    // (decoupled shape: only the walker waves run this loop -- the engine waves have served their last forward above)
+    if (!DEC || walker) for (;;) {
         TW_DS(z0);
-        if (!__syncthreads_or(live)) break;
+        if constexpr (DEC) {
+            if (phase == DP_DEAD) break;                       // (marked dead where the last episode ended)
+            wait_result();                                     // the forward that carries this walker's columns
+            if (aborted) break;
+        } else {
+            if (!__syncthreads_or(live)) break;
+        }
         TW_DS(z1);
         TW_DA(c_bar, z0, z1);
-        // ---- Policy::full_predict of the C requested boards (policy.rs:102-126) -------------------------------------
-        if (engw) {
-            const uint2 rb = req[col];
-            const uint64_t board = ((uint64_t)rb.y << 32) | rb.x;
-            float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
-            const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
-            const float np = (float)eng.pol.n_perms;
-            for (int pass = 0; pass < n_pass; ++pass) {
-                const int perm = eng.pol.n_perms > 0 ? pass : -1;
-                int rowoff[NC];
-                eng.rows_of(board, env.n_cells, perm, rowoff);
-                float lg[4], v;
-                eng.forward(rowoff, lg, v);
-                eng.act_perm(perm, lg);
-                if (eng.pol.n_perms > 0) {
-                    vsum = vsum + v / np;                                            // policy.rs:111
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) lsum[i] = lsum[i] + lg[i] / np;      // policy.rs:112-114
-                } else {
-                    vsum = v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) lsum[i] = lg[i];
-                }
+        if constexpr (!DEC) {
+            // ---- Policy::full_predict of the C requested boards (policy.rs:102-126) -------------------------------------
+            if (engw) {
+                run_forward(0u);
+            } else if constexpr (TWV > DEEP_WAVES) {
+                // a wave that only walks: the barriers of the forwards the engine waves run (nothing else synchronises in there)
+                const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
+                for (int pass = 0; pass < n_pass; ++pass) eng.idle_forward();
             }
-            PuzzleLane lf; lf.board = board; lf.depth = 0;
-            const int z = blank_cell(board);
-            lf.zx = z % env.width; lf.zy = z / env.width;
-            float probs[4];
-            masked_softmax4(lsum, puzzle_maskbits(lf, env), probs);
-            // every engine wave holds every column's output: wave w publishes the columns of walker w, for itself -- or, when
-            // there are walkers beyond the engine waves, every fourth column for everybody
-            const bool pub = TWV > DEEP_WAVES ? (col & 3) == wave : (col >= my_base && col < my_base + my_share);
-            if (eng.h == 0 && pub) {
-                float4 *dst = reinterpret_cast<float4 *>(res + col * 8);
-                dst[0] = make_float4(probs[0], probs[1], probs[2], probs[3]);
-                dst[1] = make_float4(vsum, 0.0f, 0.0f, 0.0f);
+            if constexpr (TWV > DEEP_WAVES) {
+                __syncthreads();
+                unpark();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-        } else if constexpr (TWV > DEEP_WAVES) {
-            // a wave that only walks: the barriers of the forwards the engine waves run (nothing else synchronises in there)
-            const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
-            for (int pass = 0; pass < n_pass; ++pass) eng.idle_forward();
-        }
-        if constexpr (TWV > DEEP_WAVES) {
-            __syncthreads();
-            unpark();
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         TW_DS(z2);
         TW_DA(c_fwd, z1, z2);
@@ -466,7 +570,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
         // ---- tree phase of this wave's walker ------------------------------------------------------------------------
         if (phase != DP_DEAD) {
             TW_DS(y0);
-            wait_f[wave] = 0;                                  // (every lane stores: a lane-0 branch here costs the walk its scalar branches)
+            if constexpr (!DEC) wait_f[wave] = 0;              // (every lane stores: a lane-0 branch here costs the walk its scalar branches)
             // outputs evaluated ahead of the search -> their nodes (arena) and the LDS pool; the node's hot quad gets the flag
             if (my_take) {
                 const float4 *src = reinterpret_cast<const float4 *>(res + (my_base + my_rank) * 8);
@@ -649,7 +753,7 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 bool need_nn = false;
                 TW_DS(y2);
                 if (!resume) {
-                    if (it != S && (NWK > 1 || a.tree_budget != 0xffffffffu)) {         // (a lone walker keeps nobody waiting)
+                    if (!DEC && it != S && (NWK > 1 || a.tree_budget != 0xffffffffu)) { // (a lone walker keeps nobody waiting; decoupled walkers never do)
                         const unsigned long long walked = __builtin_readcyclecounter() - tree_t0;
                         bool stop = walked > (unsigned long long)a.tree_budget;
                         if (!stop && walked > (unsigned long long)a.tree_budget_min) {        // somebody waits for a forward: do not keep it waiting
@@ -817,16 +921,21 @@ __global__ void __launch_bounds__((NWK > 4 ? 512 : 256), 1) mcts_deep_kernel(con
                 ++it;
                 TW_DS(y7); TW_DA(c_bp, y6, y7);
             }
-            wait_f[wave] = (phase != DP_DEAD && !yielded) ? 1 : 0;                        // stopped in front of a forward it needs
+            if constexpr (!DEC) wait_f[wave] = (phase != DP_DEAD && !yielded) ? 1 : 0;    // stopped in front of a forward it needs
         }
         TW_DS(z3);
         TW_DA(c_tree, z2, z3);
         assemble();
-        live = phase != DP_DEAD ? 1 : 0;
-        park();
+        if constexpr (DEC) {
+            if (phase != DP_DEAD) post(); else mark_dead();
+        } else {
+            live = phase != DP_DEAD ? 1 : 0;
+            park();
+        }
         TW_DS(z4);
         TW_DA(c_asm, z3, z4);
     }
+    if constexpr (DEC) { if (walker && aborted) mark_dead(); }     // (a walker that left through the watchdog must not keep the engine waves waiting)
     unpark();
     if (lane == 0) { atomicAdd(a.eval_count, evals); atomicAdd(a.eval_count + 1, spec_evals); atomicAdd(a.eval_count + 2, reused); }
 #ifdef TW_ABLATE
@@ -891,7 +1000,7 @@ bool mcts_deep_applies(const MctsArgs &a)
 //   1,000 searches  512: 96 103 129 | 97 97 115 129    1,024: 126 123 130 | 127 115 116 136    2,048: 195 153 157 | 197 148 139 140
 //                   4,096: 324 241 197 | 330 225 174 187
 //   4,096 x 200: 94 70 58 | 97 67 51.9 47.3     3,072 x 200: 73 54 43 | 75 52 39.4 41.0     4,096 x 400: 157 114 91 | 160 110 84.0 82.5
-struct DeepShape { int walkers; bool wide; };
+struct DeepShape { int walkers; bool wide; bool dec; };
 static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false)
 {
     const int cus = device_cus();
@@ -927,6 +1036,11 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     if (v & 32) sh.wide = true;
     if (!(v & 48) && launch_options().force_geom == 32) sh.wide = true;
     if (solve) { sh.wide = false; if (sh.walkers == 8) sh.walkers = 4; }       // solve mode: the 16-column engine, one / two / four walkers
+    // The decoupled shape (four engine-only waves + the walkers, mcts_deep_kernel<.., DEC>): from two walkers per workgroup on, 16-column engine,
+    // self-play.  TW_OPT_AZ_VARIANT + 128 pins it on (where it exists), + 256 pins it off.
+    sh.dec = !solve && !sh.wide && sh.walkers >= 2 && sh.walkers <= 8;
+    if (v & 256) sh.dec = false;
+    if ((v & 128) && !solve && !sh.wide && sh.walkers >= 2) sh.dec = true;
     return sh;
 }
 static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false) { return deep_shape(num_episodes, reserve_cus, num_searches, solve).walkers; }
@@ -940,18 +1054,19 @@ uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_
     return (blocks < (uint64_t)(cus - r) ? blocks : (uint64_t)(cus - r)) * nwk;
 }
 
-template <int NT, int NC, int NW, int NWK, bool SOLVE = false>
+template <int NT, int NC, int NW, int NWK, bool SOLVE = false, bool DEC = false>
 static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
 {
     using G = Geom<NT, NC, 0, NW>;
     constexpr int C = G::Eng::EPB;
+    constexpr unsigned THREADS = DEC ? 64u * (DEEP_WAVES + NWK) : (NWK > DEEP_WAVES ? 64u * NWK : 64u * DEEP_WAVES);
     const uint64_t nb = mcts_deep_walkers(a.num_episodes, a.reserve_cus, a.num_searches, SOLVE) / NWK;
     // the hot quads of the first lds_nodes nodes of every tree live in LDS: as many as fit beside the engine
     MctsArgs b = a;
     const size_t eng_floats = G::Eng::lds_floats(a.pol);
     const size_t budget = (size_t)159 * 1024 / sizeof(float);
-    if (eng_floats + deep_extra_floats(C, 0, NWK) > budget) { set_error("mcts (deep): the policy engine alone needs %zu bytes of LDS", eng_floats * 4); return TW_ERR_UNSUPPORTED; }
-    size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK)) / ((size_t)NWK * 6);
+    if (eng_floats + deep_extra_floats(C, 0, NWK, DEC) > budget) { set_error("mcts (deep): the policy engine alone needs %zu bytes of LDS", eng_floats * 4); return TW_ERR_UNSUPPORTED; }
+    size_t nl = (budget - eng_floats - deep_extra_floats(C, 0, NWK, DEC)) / ((size_t)NWK * 6);
     if (nl > a.node_cap) nl = a.node_cap;
     b.lds_nodes = (uint32_t)nl;
     deep_tree_budgets(&b.tree_budget_min, &b.tree_budget);
@@ -963,13 +1078,13 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     //  53.2 / 57.4; two and four walkers, 24 / 36 / 48 / 64 / 90 k: 4,096 x 1,000 96.6 / 97.9 / 100.4 / 100.7 / 102.1, 2,048 x 100 12.7 / 12.5 / 12.2 / 12.7 / 13.2,
     //  1,024 x 1,000 76.1 / 76.9 / 77.3 / 77.8 / 81.1, 1,024 x 100 10.3 / 10.3 / 10.5 / 10.6 / 11.1: 48 k stays, eight walkers take 56 k)
     if (NWK == 8 && launch_options().az_tree_budget_min == 0 && b.tree_budget > 56000u) b.tree_budget_min = 56000u;
-    const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK)) * sizeof(float);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK, SOLVE>), lds_bytes)) return rc;
+    const size_t lds_bytes = (eng_floats + deep_extra_floats(C, b.lds_nodes, NWK, DEC)) * sizeof(float);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, NW, NWK, SOLVE, DEC>), lds_bytes)) return rc;
 #ifdef TW_ABLATE
     unsigned long long zeros[16] = {0};
     if (getenv("TW_STAMPS")) { TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros))); TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_extra), zeros, 32)); }
 #endif
-    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK, SOLVE>), dim3((unsigned)nb), dim3(NWK > DEEP_WAVES ? 64 * NWK : 64 * DEEP_WAVES), lds_bytes, s, b);
+    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, NW, NWK, SOLVE, DEC>), dim3((unsigned)nb), dim3(THREADS), lds_bytes, s, b);
     TW_HIP(hipGetLastError());
 #ifdef TW_ABLATE
     if (getenv("TW_STAMPS")) {
@@ -990,7 +1105,7 @@ static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, u
     }
 #endif
     if (blocks) *blocks = (uint32_t)nb;
-    if (threads) *threads = NWK > DEEP_WAVES ? 64 * NWK : 64 * DEEP_WAVES;
+    if (threads) *threads = THREADS;
     return TW_OK;
 }
 
@@ -1004,7 +1119,15 @@ static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
             default: return launch_deep_nwk<NT, NC, NW, 4, true>(a, s, blocks, threads);
         }
     }
-    switch (deep_walkers_per_group(a.num_episodes, a.reserve_cus, a.num_searches)) {
+    const DeepShape sh = deep_shape(a.num_episodes, a.reserve_cus, a.num_searches);
+    if constexpr (NW == -16) {      // the decoupled shapes exist on the 16-column engine
+        if (sh.dec) switch (sh.walkers) {
+            case 2: return launch_deep_nwk<NT, NC, NW, 2, false, true>(a, s, blocks, threads);
+            case 8: return launch_deep_nwk<NT, NC, NW, 8, false, true>(a, s, blocks, threads);
+            default: return launch_deep_nwk<NT, NC, NW, 4, false, true>(a, s, blocks, threads);
+        }
+    }
+    switch (sh.walkers) {
         case 1: return launch_deep_nwk<NT, NC, NW, 1>(a, s, blocks, threads);
         case 2: return launch_deep_nwk<NT, NC, NW, 2>(a, s, blocks, threads);
         case 8: return launch_deep_nwk<NT, NC, NW, 8>(a, s, blocks, threads);

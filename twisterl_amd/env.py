@@ -187,7 +187,20 @@ class PyEnv:
         return [int(x) for x in self._env.observe()]
 
     def twists(self):
-        return ([], [])                                        # Env::twists default (rl/env.rs:59)
+        """Env::twists (rl/env.rs:58-59).  The reference's PyEnvImpl keeps the trait's default (no twists); a Python environment
+        that defines twists() is honoured here (build extension) -- the host builds its Policy with them."""
+        if callable(getattr(self._env, "twists", None)):
+            op, ap = self._env.twists()
+            return [[int(x) for x in p] for p in op], [[int(x) for x in p] for p in ap]
+        return ([], [])
+
+    def track_solution(self) -> bool:
+        """Env::track_solution (rl/env.rs:62): false unless the Python environment says otherwise (build extension)."""
+        return bool(self._env.track_solution()) if callable(getattr(self._env, "track_solution", None)) else False
+
+    def solution(self) -> list:
+        """Env::solution (rl/env.rs:65)."""
+        return [int(x) for x in self._env.solution()] if callable(getattr(self._env, "solution", None)) else []
 
 
 def get_env_desc(py_env) -> "_lib.PuzzleDesc":
