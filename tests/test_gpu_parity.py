@@ -675,7 +675,7 @@ def test_az_output_reuse_below_the_search_path_kept_in_lds(tw, oracle):
     move back finds its grandparent (whose stored output it reuses) at level plen-3 of that path -- while the path fits.  Below
     8 levels `push` stops recording and level plen-3 is an ancestor further up: the grandparent then comes from the parent
     links.  (Round 2's first form read the path level at any depth -- TW_OPT_AZ_REUSE = 2 -- and so took the output of the wrong
-    node in deep trees: the "schedule-dependent" results of DESIGN 5.5.)  Deep trees (400 searches, max_expand_depth 2) with
+    node in deep trees: the "schedule-dependent" results of docs/HISTORY.md 5.5.)  Deep trees (400 searches, max_expand_depth 2) with
     every way of finding the grandparent: the bytes of the oracle; the diagnostic form counts the disagreements."""
     import bench
     arrs = bench.synthetic_weights(16, seed=0)                   # the benchmark's 512 / 256 policy (as scripts/az_reuse_probe.py)

@@ -457,7 +457,7 @@ struct Engine3S : Engine3<NT, NC, 0, NS> {
     static_assert(NT % NS == 0 && (NTL == 1 || NTL == 2), "Engine3S: one or two row tiles per wave");
 
     float *lds_x, *lds_user;
-    // The same instruction diet as the 16-column shape (a lone wave per SIMD is bound by its instruction count):
+    // The same instruction diet as the 16-column shape (docs/HISTORY.md 5.1e; a lone wave per SIMD is bound by its instruction count):
     // ring positions are compile-time facts -- a forward always starts in slot 0, its chunk sequence padded to a multiple of three
     // steps with "bubble" steps that only stream -- so the slot offsets of all LDS reads are immediates, the gather keeps one LDS
     // address per row for the whole forward, a stream op is `s_add_u32 m0, piece, literal` + the DMA instruction with a per-op
@@ -750,7 +750,7 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
     static_assert(4 * R3_TSLOT <= 3 * WSLOT + 3 * R3_TSLOT, "table ring must fit the ring area of Engine3's LDS map");
 
     float *lds_x, *lds_user;
-    // What this shape does differently from the throughput shapes, and why.  A lone wave per SIMD issues one
+    // What this shape does differently from the throughput shapes, and why (docs/HISTORY.md 5.1e).  A lone wave per SIMD issues one
     // instruction every 4..5 cycles whatever its kind and cannot overlap its own stalls, so a step costs its instruction count
     // plus every round trip on its critical path (barrier -> B operands -> MFMAs -> gather adds -> exchange -> barrier):
     //   * a step is a PAIR of 16-wide chunks (32 MFMA slots between two barriers): half the barriers and B-operand round trips;
