@@ -126,3 +126,26 @@ def test_headline_line_for_every_documented_choice():
                 else:
                     assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
                 assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["gather"] == gi
+
+
+def test_traffic_profile_is_not_older_than_the_newest_bench_round():
+    """`roofline.traffic` is bytes per record of the newest committed PMC passes (profiles/rNN_hbm_traffic.json) x the run's records.
+    The kernels change between rounds: a traffic file from before the newest BENCH_rNN.json round describes another kernel (VERDICT r03
+    weak 5).  Refresh: scripts/profile_r04.sh (or scripts/pmc_traffic.sh) + scripts/summarize_traffic.py."""
+    import glob
+    import re
+    rounds = lambda pat, rx: sorted(int(re.search(rx, os.path.basename(p)).group(1)) for p in glob.glob(os.path.join(ROOT, pat)))
+    bench_rounds = rounds("BENCH_r[0-9][0-9].json", r"BENCH_r(\d+)")
+    traffic_rounds = rounds(os.path.join("profiles", "r[0-9][0-9]_hbm_traffic.json"), r"r(\d+)_hbm")
+    assert traffic_rounds, "no profiles/rNN_hbm_traffic.json"
+    if bench_rounds:
+        assert traffic_rounds[-1] >= bench_rounds[-1], f"profiles/r{traffic_rounds[-1]:02d}_hbm_traffic.json is older than BENCH_r{bench_rounds[-1]:02d}.json"
+    sys.path.insert(0, ROOT)
+    import bench
+    newest = f"profiles/r{traffic_rounds[-1]:02d}_hbm_traffic.json"
+    for kernel in ("rollout_f32", "rollout_f16", "rollout_f16x2"):
+        tpr, src = bench.measured_traffic_per_record(kernel)
+        assert src == newest and 58.0 <= tpr <= 200.0, (kernel, tpr, src)      # (58 B per record is the algorithmic minimum, SURVEY.md 8d)
+    d = json.load(open(os.path.join(ROOT, newest)))
+    fin = d["tw::finalize_ppo_kernel"]["bytes_per_record"]
+    assert 98.0 <= fin <= 120.0, fin                                            # each padded record is read once (round 4; 188 before)

@@ -139,11 +139,11 @@ static __host__ __device__ inline size_t fin_wave_bytes(int t_pad, int n_cells)
     return (((size_t)(n_cells == 16 ? 5 : 9) * (size_t)t_pad * 4) + 15) / 16 * 16;
 }
 
-// One wave per episode.  Every 48-byte padded record is READ ONCE: the wave walks the episode's records as one run of 16-byte
-// words (lane i takes word i, i + 64, ..: full cache lines), and each word goes where it belongs -- word 0 (the board as obs
+// One wave per episode.  Every 48-byte padded record is FETCHED ONCE: a lane takes a whole record -- its three 16-byte words in three
+// loads issued back to back, which cover the same cache lines -- and each word goes where it belongs: word 0 (the board as obs
 // bytes) and word 1 (the four logits) straight to their compact rows, word 2 (value, reward, action | twist) into LDS for the
-// GAE chain.  (Until round 4 the three words were read in three passes at a 48-byte stride; with more episodes in flight than
-// L2 holds, each pass fetched every line again: 188 B of HBM traffic per record against 100 algorithmic.)
+// GAE chain.  (Until round 4 the three words were read in three PASSES over the episode; with more episodes in flight than L2
+// holds, each pass fetched every line again: 188 B of HBM traffic per record by counter against 98 algorithmic; now 99.)
 __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const PaddedTraj in, const uint64_t *ep_start,
                                                                       uint64_t E, int n_cells, float gamma, float lambda,
                                                                       const CompactTraj out)
@@ -163,13 +163,13 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
         const uint64_t dst   = ep_start[e];
         const uint4 *rec4 = reinterpret_cast<const uint4 *>(in.rec + src);
         uint4 *obs4 = reinterpret_cast<uint4 *>(out.obs), *logits4 = reinterpret_cast<uint4 *>(out.logits);
-        for (int w = lane; w < 3 * n; w += 64) {
-            const uint4 v = rec4[w];
-            const int t = w / 3, part = w - 3 * t;
-            if (part == 2) { sv[t] = __builtin_bit_cast(float, v.x); sr[t] = __builtin_bit_cast(float, v.y); sz[t] = v.z; }
-            else if (part == 1) logits4[dst + t] = v;
-            else if (n_cells == 16) obs4[dst + t] = v;
-            else so[t] = v;
+        for (int t = lane; t < n; t += 64) {
+            // the three words of this lane's record, requested back to back: the wave's three loads cover the same 24 cache lines
+            // (64 records x 48 B), fetched once and hit in the vector cache twice -- no branch, stores of 16 contiguous bytes per lane
+            const uint4 w0 = rec4[3 * t], w1 = rec4[3 * t + 1], w2 = rec4[3 * t + 2];
+            sv[t] = __builtin_bit_cast(float, w2.x); sr[t] = __builtin_bit_cast(float, w2.y); sz[t] = w2.z;
+            logits4[dst + t] = w1;
+            if (n_cells == 16) obs4[dst + t] = w0; else so[t] = w0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

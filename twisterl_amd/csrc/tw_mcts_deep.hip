@@ -510,7 +510,11 @@ __global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256))
                 if constexpr (DEC) eng.template fsync<true, true>();    // (waves 1 .. 3 idle here, asleep between polls: they share their SIMDs with the walkers)
                 const uint32_t batch = uniu(ctl[25]);
                 if (batch & 0x80000000u) break;
+                // (the forward is on the critical path of every walker waiting for it; the walkers it shares its SIMDs with are bound by
+                //  latency, not by issue slots)
+                __builtin_amdgcn_s_setprio(2);
                 run_forward(batch);
+                __builtin_amdgcn_s_setprio(0);
                 if constexpr (DEC) eng.template fsync<true>();    // every served column's result is in `res`
                 if (wave == 0) {
 #pragma unroll
