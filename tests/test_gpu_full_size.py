@@ -116,11 +116,12 @@ def test_config5_selfplay_full_size_vs_oracle(tw, oracle, searches, n_sample):
     probs = t["logits"]
     assert bool((probs >= 0).all()) and bool(((probs.sum(dim=1) - 1.0).abs() < 1e-5).all())     # visit counts / sum
     assert bool((t["perms"] == -1).all())                                                     # az.rs:95
-    # the walker kernel: one workgroup per CU; eight walkers below 800 searches per move, four beyond
     import twisterl_amd
-    assert g.stats["rollout_blocks"] == twisterl_amd.device_info()["compute_units"]
-    # (the decoupled shape: four engine-only waves + eight walkers below 800 searches per move, + four beyond)
-    assert g.stats["rollout_threads"] == (768 if searches < 800 else 512)
+    cus = twisterl_amd.device_info()["compute_units"]
+    assert g.stats["rollout_blocks"] == (cus - cus // 2) * (2 if searches < 400 else 1)
+    # (the split shape: half of the CUs run engine workgroups; the walker kernel has two workgroups of twelve walker waves on each of the
+    #  other CUs below 400 searches per move, one of sixteen from there on)
+    assert g.stats["rollout_threads"] == (768 if searches < 400 else 1024)
     # one root evaluation + at most `searches` leaf evaluations per record, two twists each
     assert 2 * n <= g.stats["forward_evals"] <= 2 * n * (searches + 1)
     h = coll.collect(env, gp, seed=500).to_torch()

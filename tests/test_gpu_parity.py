@@ -546,6 +546,33 @@ def test_ppo_collect_of_a_python_environment(tw, oracle, w, h, steps, emb, commo
         tw.collector.PPOCollector(4, 0.99, 0.95, 1).collect(tw.env.PyEnv(Broken(w, h, steps)), gp, seed=1)
 
 
+@pytest.mark.parametrize("w,h,diff,emb,hidden,E,S,med,twists", [
+    (3, 3, 3, 64, 128, 70, 24, 1, False),      # Puzzle-8, fewer episodes than one walker workgroup holds
+    (3, 3, 4, 64, 128, 300, 40, 2, True),      # max_expand_depth 2, full_predict over two twists (two engine passes per forward)
+    (4, 4, 5, 128, 256, 500, 16, 1, False),    # Puzzle-15, many more requests than an engine packs into one forward
+    (2, 2, 2, 32, 128, 40, 10, 1, False),
+])
+def test_split_walker_shape_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E, S, med, twists):
+    """The split shape of the walker kernel (TW_OPT_AZ_VARIANT + 512; automatic from eight episodes per CU on): walker waves in a kernel of
+    their own -- 72 registers per lane, sixteen or twenty-four per CU --, engine workgroups in another, requests and outputs through
+    per-walker mailboxes in device memory.  Same reference semantics (rust/src/collector/az.rs:51-109 over rust/src/rl/search.rs:104-189),
+    same bytes as the oracle; a busy engine evaluates fewer look-ahead boards, which never changes a result."""
+    n2 = w * h
+    gp, op = _pair(oracle, n2, 21, emb, hidden, twists=twists)
+    genv, oenv = tw.env.Puzzle(w, h, diff, 2, 256), oracle.Puzzle(w, h, diff, 2, 256)
+    o = oracle.az_collect(oenv, op, E, S, 1.41, med, seed=31, arith=oracle.ARITH_CHAIN, num_threads=8, det_math=True)
+    with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, 512):
+        g = tw.collector.AZCollector(E, S, 1.41, med, 32).collect(genv, gp, seed=31)
+    assert g.stats["rollout_threads"] in (768, 1024) and g.stats["rollout_blocks"] == -(-E // (g.stats["rollout_threads"] // 64))
+    _assert_same_az(g, o, n2)
+    assert _lib.debug_counters(14)[13] == 0                      # no wait ran into its watchdog
+    with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, 512):        # determinism: which engine serves which request when must not matter
+        h2 = tw.collector.AZCollector(E, S, 1.41, med, 32).collect(genv, gp, seed=31).to_numpy()
+    a = g.to_numpy()
+    for k in a:
+        assert np.array_equal(a[k], h2[k]), k
+
+
 def test_solve_returns_the_solution_an_environment_tracks_itself(tw, oracle):
     """`Env::track_solution` / `Env::solution` through tw_env_vtable (rust/src/rl/env.rs:61-66): single_solve asks once, before
     the first move, and then returns the environment's own record instead of the actions it played (rust/src/rl/solve.rs:28,
@@ -915,9 +942,12 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
     cus = twisterl_amd.device_info()["compute_units"]
     gp, _ = _pair(oracle, 9, 2, 32, 128)
     env = tw.env.Puzzle(3, 3, 2, 2, 256)
-    # (from two walkers on, the decoupled shape: four engine-only waves + the walkers = 64 x (4 + walkers) threads)
+    # (from two walkers on, the decoupled shape: four engine-only waves + the walkers = 64 x (4 + walkers) threads; from eight episodes per CU
+    #  on the SPLIT shape: half of the CUs run engine workgroups (a kernel of their own), the others two workgroups of twelve walker waves)
     for E, want in ((cus // 2, (cus // 2, 256)), (cus, (cus, 256)), (2 * cus, (cus, 256)), (3 * cus, (cus, 384)), (6 * cus, (cus, 512)), (13 * cus, (cus, 768))):
         d = tw.collector.AZCollector(E, 4 if E <= 8 * cus else 24, 1.41, 1, 1).collect(env, gp, seed=3)     # (very short searches: walker kernel up to 8 episodes per CU)
+        if E >= 8 * cus:
+            want = (min(-(-E // 12), (cus - cus // 2) * 2), 768)
         assert (d.stats["rollout_blocks"], d.stats["rollout_threads"]) == want, (E, d.stats["rollout_blocks"], d.stats["rollout_threads"])
     # outputs taken from a grandparent / the chosen child (same board) are part of forward_evals, and counted in reused_evals
     # (walker kernel; the lane-per-episode kernel -- hidden 32 here -- takes the grandparent's only)
@@ -930,7 +960,8 @@ def test_walker_self_play_uses_as_few_walkers_per_workgroup_as_keep_the_chip_bus
     auto = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
     from twisterl_amd import _lib
     # ... + 128 / + 256: the decoupled shape (engine-only waves beside the walkers) pinned on / off
-    for variant in (16 + 4, 16 + 3, 16 + 5, 16 + 6, 32 + 4, 32 + 3, 32 + 5, 32 + 6, 256 + 16 + 3, 256 + 16 + 5, 256 + 16 + 6, 128 + 16 + 3, 128 + 16 + 5, 128 + 16 + 6, 256):
+    # ... + 512 / + 1024: the split shape (walkers and engine as two kernels, mailboxes in device memory) pinned on / off
+    for variant in (16 + 4, 16 + 3, 16 + 5, 16 + 6, 32 + 4, 32 + 3, 32 + 5, 32 + 6, 256 + 16 + 3, 256 + 16 + 5, 256 + 16 + 6, 128 + 16 + 3, 128 + 16 + 5, 128 + 16 + 6, 256, 512, 1024):
         with _lib.launch_option(_lib.TW_OPT_AZ_VARIANT, variant):
             pinned = tw.collector.AZCollector(E, 6, 1.41, 1, 1).collect(env, gp, seed=4).to_numpy()
         for k in auto:

@@ -246,7 +246,7 @@ extern "C" int tw_set_launch_option(int option, int value)
             g_force_geom.store(value); return TW_OK;
         case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
         case TW_OPT_AZ_VARIANT:
-            if (value < 0 || (value & 7) > 6 || (value & ~503) != 0 || (value & 48) == 48 || (value & 384) == 384) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32) (+ 64) (+ 128 | 256)", value); return TW_ERR_INVALID; }
+            if (value < 0 || (value & 7) > 6 || (value & ~2039) != 0 || (value & 48) == 48 || (value & 384) == 384 || (value & 1536) == 1536) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32) (+ 64) (+ 128 | 256) (+ 512 | 1024)", value); return TW_ERR_INVALID; }
             g_az_variant.store(value); return TW_OK;
         case TW_OPT_AZ_TREE_BUDGET:
             if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }
@@ -1360,6 +1360,8 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     const uint32_t tbl_entries = deep ? mcts_deep_table_entries(ma.num_searches, ma.max_expand_depth) : 0;
     const size_t tbl_bytes = (size_t)arenas * tbl_entries * 32;
     const size_t o_tbl = seg(tbl_bytes);
+    const bool split = deep && mcts_deep_split(E, ma.reserve_cus, ma.num_searches);      // walkers and engine as two kernels: a 256-byte mailbox per walker
+    const size_t o_mb = seg(split ? (size_t)arenas * 256 + 256 : 0);          // (+ the engines' residency counter)
     size_t free_b = 0, total_b = 0;
     TW_HIP(hipMemGetInfo(&free_b, &total_b));
     {   // what can actually be had: free memory plus the cached workspace this call would replace
@@ -1387,6 +1389,10 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
     if (deep) {          // the walkers' board-keyed output tables start empty (the policy may have changed since the last collect)
         ma.tbl = ws + o_tbl; ma.tbl_entries = tbl_entries;
         TW_HIP(hipMemsetAsync(ws + o_tbl, 0, tbl_bytes, s));
+    }
+    if (split) {
+        ma.mailbox = reinterpret_cast<uint32_t *>(ws + o_mb);
+        TW_HIP(hipMemsetAsync(ws + o_mb, 0, (size_t)arenas * 256 + 256, s));
     }
     if (persist) {
         ma.init_boards = reinterpret_cast<const uint64_t *>(ws + o_init);

@@ -547,11 +547,16 @@ struct MctsArgs {
     const MctsSolve *solve_dev;        // deep shape in solve mode: a copy of `solve` in device memory (null: self-play) -- the walker kernel has no registers to
                                        //   keep twenty more launch constants in; it reads them where a move or an attempt ends
     uint32_t        order_across;      // ... the first ones dealt out across the workgroups (walker w of workgroup b: number w * workgroups + b) instead of in a row
+    // deep shape, split form (walkers and engine as two kernels, tw_mcts_deep.hip): one 256-byte mailbox per walker, zeroed before the launch;
+    // the engine workgroup e serves the walkers [e * split_wpe, (e + 1) * split_wpe) of the split_walkers there are
+    uint32_t       *mailbox;
+    uint32_t        split_walkers, split_wpe;
 };
 size_t mcts_node_bytes();
 // the deep shape of self-play (tw_mcts_deep.hip): one wave per episode, 64-byte nodes, persistent walkers + episode queue
 bool     mcts_deep_applies(const MctsArgs &a);
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false);   // tree arenas = episodes in flight
+bool     mcts_deep_split(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false);     // the split form: MctsArgs::mailbox is needed (256 bytes per walker)
 size_t   mcts_deep_node_bytes();
 // bytes of one walker's tree arena (72 per node, see tw_mcts_deep.hip), a multiple of 16
 __host__ __device__ inline size_t mcts_deep_arena_bytes(uint64_t node_cap) { return (size_t)((node_cap * 72 + 15) / 16 * 16); }

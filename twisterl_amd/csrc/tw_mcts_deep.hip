@@ -35,6 +35,9 @@
 // 4,096 x 100 collect with 64-byte node records, scripts/pmc_az_l2.sh).
 #include "tw_engine.hpp"
 
+#include <cstdlib>
+#include <mutex>
+
 namespace tw {
 
 // arena of one walker: uint4 hot[node_cap] | uint4 brd[node_cap] | uint4 out[node_cap][2] | uint2 hot2[node_cap]
@@ -120,9 +123,18 @@ __device__ unsigned long long g_deep_extra[4];
 // the middle of a streak because a neighbour needed a forward (profiles/r03_az_walker_stamps.txt: "yielded").  The engine waves
 // synchronise among themselves through an LDS counter (Engine3T::fsync<true>): the hardware barrier counts every wave of the workgroup.
 // Requests / completions are sequence numbers in LDS; every spin is bounded (a watchdog sets MctsArgs::eval_count[13] and everybody leaves).
-template <int NT, int NC, int NW, int NWK, bool SOLVE = false, bool DEC = false>
-__global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256)), 1) mcts_deep_kernel(const MctsArgs a)
+//
+// SPL, the split shape (round 4; implies DEC): the walkers are a KERNEL OF THEIR OWN -- NWK walker waves per workgroup, no engine
+// wave, no engine LDS -- beside `mcts_engine_kernel` (below), whose workgroups only run forwards.  All waves of a workgroup share ONE
+// register allocation, and the walker code needs 67 registers per lane where the engine wants 370: in its own kernel a walker costs a
+// sixth of a wave slot and a CU holds 16 of them (an XCD's L2 latency is what a search mostly waits for: more waves in flight hide
+// it), with the whole 159 KB of LDS for tree statistics.  Requests and results travel through a 256-byte mailbox per walker in
+// device memory, written and polled with relaxed agent-scope atomics (coherent across XCDs without an L2 write-back) and ordered with
+// s_waitcnt; every spin is bounded (watchdog -> MctsArgs::eval_count[13], the collect fails).
+template <int NT, int NC, int NW, int NWK, bool SOLVE = false, bool DEC = false, bool SPL = false>
+__global__ void __launch_bounds__((SPL ? 64 * NWK : DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256)), 1) mcts_deep_kernel(const MctsArgs a)
 {
+    static_assert(!SPL || (DEC && !SOLVE), "the split shape is a decoupled self-play shape");
     using Eng = typename Geom<NT, NC, 0, NW>::Eng;
     typedef unsigned int ux4 __attribute__((ext_vector_type(4)));
     typedef unsigned int ux2 __attribute__((ext_vector_type(2)));
@@ -130,15 +142,18 @@ __global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256))
     typedef __attribute__((address_space(3))) ux2 lds_u2;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     typedef __attribute__((address_space(3))) float lds_f32;
-    constexpr int C = Eng::EPB, CPW = C / NWK;             // MFMA columns of the workgroup, columns per walker
-    constexpr int TWV = DEC ? DEEP_WAVES + NWK : (NWK > DEEP_WAVES ? NWK : DEEP_WAVES);   // waves per workgroup
+    constexpr int CPW = SPL ? 4 : Eng::EPB / NWK, C = SPL ? 4 * NWK : Eng::EPB;   // columns per walker (split: of a request), request columns of the workgroup
+    constexpr int TWV = SPL ? NWK : DEC ? DEEP_WAVES + NWK : (NWK > DEEP_WAVES ? NWK : DEEP_WAVES);   // waves per workgroup
     constexpr bool PARK = !DEC && TWV > DEEP_WAVES;            // coupled eight-walker shape: the walker state waits in LDS during a forward
     constexpr int DEEP_POOL = deep_pool(NWK);
-    static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WAVES && NWK >= 1 && NWK <= 8 && CPW >= 2 && CPW <= 64, "one walker per wave");
+    static_assert(Geom<NT, NC, 0, NW>::WAVES == DEEP_WAVES && NWK >= 1 && NWK <= (SPL ? 16 : 8) && CPW >= 2 && CPW <= 64, "one walker per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Eng eng;
     bool engw = true;                                          // this wave runs the forward
-    if constexpr (TWV > DEEP_WAVES) {
+    if constexpr (SPL) {
+        engw = false;
+        eng.begin_idle(a.pol);                                 // (the engine's constants only: its barrier is matched by every wave here)
+    } else if constexpr (TWV > DEEP_WAVES) {
         engw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) < DEEP_WAVES;
         if (engw) eng.begin1(a.pol, lds); else eng.begin_idle(a.pol);
     } else {
@@ -149,11 +164,11 @@ __global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256))
     const int lane = eng.lane, wave = eng.wave;
     const int col  = eng.ep_lane();                           // this lane's MFMA column in the engine's mapping
     const uint32_t NL = a.lds_nodes;                          // nodes of a tree whose hot quad lives in LDS
-    float *xbase = lds + Eng::lds_floats(a.pol);
+    float *xbase = SPL ? lds : lds + Eng::lds_floats(a.pol);
     uint2 *req = reinterpret_cast<uint2 *>(xbase);                               // request boards [C]
     float *res = xbase + 2 * C;                                                  // results [C][8 floats: probs, value, -]
-    const bool walker = DEC ? wave >= DEEP_WAVES : wave < NWK;                   // (coupled: waves NWK..3 only run the forward; decoupled: waves 0..3)
-    const int  wk = walker ? (DEC ? wave - DEEP_WAVES : wave) : 0;               // this wave's walker number inside the workgroup
+    const bool walker = SPL ? true : DEC ? wave >= DEEP_WAVES : wave < NWK;      // (coupled: waves NWK..3 only run the forward; decoupled: waves 0..3; split: none)
+    const int  wk = walker ? ((DEC && !SPL) ? wave - DEEP_WAVES : wave) : 0;     // this wave's walker number inside the workgroup
     int *alive_f = reinterpret_cast<int *>(res + 8 * C);                         // [2 trips][TWV waves]: walker still has an episode
     // [8]: walker w has stopped in front of a forward it needs (demand / new root).  An LDS-typed pointer: through a generic one the
     // eight polls of a search pass were eight serialised flat loads (hundreds of cycles each); now two 16-byte LDS reads
@@ -290,7 +305,7 @@ __global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256))
     if constexpr (DEC) {
         if (threadIdx.x < 40) ctl[threadIdx.x] = 0u;                               // sequence numbers, dead flags, barrier counter, batch, watchdog
         if (threadIdx.x < C) req[threadIdx.x] = make_uint2((uint32_t)env.ident, (uint32_t)(env.ident >> 32));   // (a column nobody has asked for yet holds a valid board)
-        if constexpr (DEC) eng.ebar_cnt = ctl + 24;
+        if constexpr (DEC && !SPL) eng.ebar_cnt = ctl + 24;
     } else {
         if (lane == 0) { alive_f[wave] = phase != DP_DEAD ? 1 : 0; alive_f[TWV + wave] = phase != DP_DEAD ? 1 : 0; wait_f[wave] = 0; if (wave + 4 < 8) wait_f[wave + 4] = 0; }
     }
@@ -456,22 +471,50 @@ __global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256))
     // ---- decoupled shape: request / completion hand-shake between the walkers and the engine waves (LDS, sequence numbers) -------------
     uint32_t my_seq = 0;                                        // walker: requests posted so far
     bool     aborted = false;
-    constexpr uint32_t SPIN_LIMIT = 1u << 25;                   // x >= ~100 cycles per poll: seconds -- a hand-shake bug ends the kernel instead of hanging the GPU
+    constexpr uint32_t SPIN_LIMIT = SPL ? 1u << 22 : 1u << 25;  // x >= ~100 cycles (split: ~1 us) per poll: seconds -- a hand-shake bug ends the kernel instead of hanging the GPU
     auto watchdog = [&]() { aborted = true; ctl[26] = 1u; if (lane == 0) atomicAdd(a.eval_count + 13, 1ull); };
+    // split shape: this walker's mailbox (MctsArgs::mailbox, 64 dwords: [0] request number (0xffffffff: the walker is done) | [2..9] up to four
+    // boards, the demand first | [32] number of the request served last | [33] how many of its boards were evaluated | [36..55] their outputs,
+    // five floats each).  Relaxed agent-scope atomics only: coherent across XCDs without the L2 write-back an agent-scope fence would do.
+    uint32_t *mbx = SPL ? a.mailbox + slot * 64 : nullptr;
     auto post = [&]() {                                         // this walker's columns are in `req`: ask for a forward
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         ++my_seq;
-        ctl[wk] = my_seq;
+        if constexpr (SPL) {
+            if (lane < CPW) {
+                const uint2 b = req[my_base + lane];
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(mbx + 2) + lane, ((unsigned long long)b.y << 32) | b.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (s_waitcnt: the boards are out before the number goes up)
+            if (lane == 0) __hip_atomic_store(mbx, my_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ctl[wk] = my_seq;
+        }
     };
     auto mark_dead = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        ctl[16 + wk] = 1u;
+        if constexpr (SPL) { if (lane == 0) __hip_atomic_store(mbx, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else ctl[16 + wk] = 1u;
     };
     auto wait_result = [&]() {
         uint32_t spins = 0;
-        while (uniu(ctl[8 + wk]) != my_seq) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_LIMIT || uniu(ctl[26]) != 0u) { if (spins > SPIN_LIMIT) watchdog(); aborted = true; break; }
+        if constexpr (SPL) {
+            while (uniu(__hip_atomic_load(mbx + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != my_seq) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SPIN_LIMIT || uniu(ctl[26]) != 0u) { if (spins > SPIN_LIMIT) watchdog(); aborted = true; break; }
+            }
+            // the outputs into the workgroup's staging area, where the tree phase reads them (as the engine waves leave them in the other shapes)
+            const uint32_t n_done = uniu(__hip_atomic_load(mbx + 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (lane < CPW * 5) {
+                const int c = lane / 5, i = lane - 5 * c;
+                res[(my_base + c) * 8 + i] = __uint_as_float(__hip_atomic_load(mbx + 36 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            if (my_take && (uint32_t)my_rank >= n_done) my_take = false;      // (a busy engine evaluates fewer of the look-ahead boards: they stay what they were)
+        } else {
+            while (uniu(ctl[8 + wk]) != my_seq) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > SPIN_LIMIT || uniu(ctl[26]) != 0u) { if (spins > SPIN_LIMIT) watchdog(); aborted = true; break; }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
@@ -482,7 +525,7 @@ __global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256))
     park();
     if constexpr (DEC) {
         if (walker) { if (phase != DP_DEAD) post(); else mark_dead(); }
-        if (engw) {
+        if constexpr (!SPL) if (engw) {
             // ---- the engine waves: serve forwards until every walker is done.  Wave 0 polls the walkers' request numbers and publishes
             //      the batch (which walkers this forward serves) -- the other three wait for it in the engine barrier.
             uint32_t served[NWK];
@@ -956,6 +999,147 @@ __global__ void __launch_bounds__((DEC ? 64 * (4 + NWK) : (NWK > 4 ? 512 : 256))
     if (engw) eng.end();
 }
 
+// ---- the engine of the split shape -----------------------------------------------------------------------------------------
+// One workgroup = the four engine waves of Engine3T and nothing else; it serves the walkers [e * split_wpe, (e + 1) * split_wpe) of
+// mcts_deep_kernel<.., SPL> through their mailboxes: every thread watches one walker's request number; up to sixteen pending requests
+// go into one forward -- four columns each (the demand and three boards evaluated ahead) while at most four wait, two for up to eight,
+// the demand alone beyond (a busy engine serves demands first) --, taken round-robin from behind the last one served.  Leaves when
+// every one of its walkers has posted 0xffffffff.  Every wait is bounded (watchdog -> eval_count[13]).
+// Holds the caller's stream until every engine workgroup is resident: with two walker workgroups per CU the walkers would otherwise be
+// free to take one slot on EVERY CU before the engines are placed, and an engine workgroup (127 KB of LDS) fits beside none of them.
+__global__ void split_gate_kernel(const uint32_t *resident, uint32_t engines, unsigned long long *eval_count)
+{
+    uint32_t spins = 0;
+    while (__hip_atomic_load(resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < engines) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1u << 22)) { if (threadIdx.x == 0) atomicAdd(eval_count + 13, 1ull); break; }      // (seconds: the collect fails instead of hanging)
+    }
+}
+
+template <int NT, int NC>
+__global__ void __launch_bounds__(256, 1) mcts_engine_kernel(const MctsArgs a)
+{
+    using Eng = Engine3T<NT, NC>;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Eng eng;
+    eng.begin1(a.pol, lds);
+    const PuzzleConsts env = a.env;
+    const int tid = threadIdx.x, lane = eng.lane, wave = eng.wave, col = eng.ep_lane();
+    float *xbase = lds + Eng::lds_floats(a.pol);
+    uint2 *req = reinterpret_cast<uint2 *>(xbase);                       // [16] boards of this forward
+    volatile lds_u32 *sel = (volatile lds_u32 *)(xbase + 32);             // [16][2]: walker (thread number) and request number served in column group r
+    volatile lds_u32 *wcnt = (volatile lds_u32 *)(xbase + 64);            // [4] pending requests per wave | [4] shape of the forward: k, columns per request
+    const uint32_t w0 = blockIdx.x * a.split_wpe;
+    const uint32_t nW = w0 >= a.split_walkers ? 0u : (a.split_walkers - w0 < a.split_wpe ? a.split_walkers - w0 : a.split_wpe);
+    uint32_t *mb = a.mailbox + ((size_t)w0 + (size_t)tid) * 64;           // this thread's walker
+    uint32_t served = 0u, rr = 0u, idle = 0u;
+    bool aborted = false;
+    if (tid < 16) req[tid] = make_uint2((uint32_t)env.ident, (uint32_t)(env.ident >> 32));
+    if (tid == 0) atomicAdd(a.mailbox + (size_t)a.split_walkers * 64, 1u);          // this engine workgroup is resident (split_gate_kernel waits for all of them)
+    eng.begin2();
+    __syncthreads();
+    for (;;) {
+        uint32_t r = 0xffffffffu;
+        if ((uint32_t)tid < nW) r = __hip_atomic_load(mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool dead = r == 0xffffffffu;
+        const bool pending = !dead && r != served;
+        if (__syncthreads_and(dead ? 1 : 0)) break;                        // every walker of this engine is done
+        // rank of the pending requests, counted round-robin from thread rr on (fairness: nobody waits for more than one round)
+        const uint32_t pos = ((uint32_t)tid + 256u - rr) & 255u;          // position in the rotated order
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pending);
+        if (lane == 0) wcnt[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        const uint32_t n_pending = c0 + c1 + c2 + c3;
+        if (n_pending == 0u) {
+            __syncthreads();                                               // (wcnt is rewritten next round)
+            __builtin_amdgcn_s_sleep(8);
+            if (++idle > (1u << 21)) { aborted = true; if (tid == 0) atomicAdd(a.eval_count + 13, 1ull); break; }     // (seconds without a request)
+            continue;
+        }
+        idle = 0u;
+        // pending requests in front of this thread in the rotated order: those of earlier positions.  The rotation splits the threads in two
+        // runs -- [rr, 256) then [0, rr) --, so: (pending threads t' >= rr with t' < tid, if tid >= rr) or (all pending >= rr + pending t' < tid, if tid < rr)
+        const uint32_t wave_base = wave == 0 ? 0u : wave == 1 ? c0 : wave == 2 ? c0 + c1 : c0 + c1 + c2;
+        const uint32_t before_me = wave_base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));      // pending threads below tid
+        // pending threads below rr: computed by thread rr's own before_me -- publish it
+        if ((uint32_t)tid == rr) wcnt[6] = before_me;
+        __syncthreads();
+        const uint32_t below_rr = wcnt[6];
+        const uint32_t rank = (uint32_t)tid >= rr ? before_me - below_rr : before_me + (n_pending - below_rr);
+        (void)pos;
+        const uint32_t k = n_pending < 16u ? n_pending : 16u;
+        const uint32_t cols = k <= 4u ? 4u : (k <= 8u ? 2u : 1u);
+        const bool take = pending && rank < k;
+        if (take) {
+            sel[2 * rank] = (uint32_t)tid; sel[2 * rank + 1] = r;
+            for (uint32_t c = 0; c < cols; ++c) {
+                const unsigned long long b = __hip_atomic_load(reinterpret_cast<unsigned long long *>(mb + 2) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                req[rank * cols + c] = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+            }
+        }
+        if (tid == 0) { wcnt[4] = k; wcnt[5] = cols; }
+        __syncthreads();
+        // ---- Policy::full_predict of the 16 boards (policy.rs:102-126), as the walker kernel's own forward
+        {
+            const uint2 rb = req[col];
+            const uint64_t board = ((uint64_t)rb.y << 32) | rb.x;
+            float lsum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vsum = 0.0f;
+            const int n_pass = eng.pol.n_perms > 0 ? eng.pol.n_perms : 1;
+            const float np = (float)eng.pol.n_perms;
+            for (int pass = 0; pass < n_pass; ++pass) {
+                const int perm = eng.pol.n_perms > 0 ? pass : -1;
+                int rowoff[NC];
+                eng.rows_of(board, env.n_cells, perm, rowoff);
+                float lg[4], v;
+                eng.forward(rowoff, lg, v);
+                eng.act_perm(perm, lg);
+                if (eng.pol.n_perms > 0) {
+                    vsum = vsum + v / np;                                            // policy.rs:111
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lsum[i] = lsum[i] + lg[i] / np;      // policy.rs:112-114
+                } else {
+                    vsum = v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lsum[i] = lg[i];
+                }
+            }
+            PuzzleLane lf; lf.board = board; lf.depth = 0;
+            const int z = blank_cell(board);
+            lf.zx = z % env.width; lf.zy = z / env.width;
+            float probs[4];
+            masked_softmax4(lsum, puzzle_maskbits(lf, env), probs);
+            // every engine wave holds every column's output: wave w writes every fourth column into its request's mailbox
+            const uint32_t kk = wcnt[4], cc = wcnt[5];
+            const uint32_t rq = (uint32_t)col / cc, ci = (uint32_t)col - rq * cc;
+            if (eng.h == 0 && (col & 3) == wave && rq < kk) {
+                uint32_t *dst = a.mailbox + ((size_t)w0 + (size_t)sel[2 * rq]) * 64 + 36 + 5 * ci;
+                __hip_atomic_store(dst + 0, __float_as_uint(probs[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, __float_as_uint(probs[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 2, __float_as_uint(probs[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 3, __float_as_uint(probs[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 4, __float_as_uint(vsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // (s_waitcnt: this wave's outputs are out)
+        __syncthreads();                                                    // ... and everybody's
+        if (take) {
+            __hip_atomic_store(mb + 33, cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(mb + 32, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the walker goes on
+            served = r;
+        }
+        // the next round starts behind the last request served
+        if (take && rank == k - 1u) wcnt[7] = ((uint32_t)tid + 1u) & 255u;
+        __syncthreads();
+        rr = wcnt[7];
+        if ((uint32_t)tid < 16u && (uint32_t)tid >= k * cols) req[tid] = make_uint2((uint32_t)env.ident, (uint32_t)(env.ident >> 32));   // (unused columns hold a valid board)
+    }
+    (void)aborted;
+    eng.end();
+}
+
 // ---- launch ---------------------------------------------------------------------------------------------------------
 // The deep shape serves AlphaZero self-play of up to CUs x 8 episodes (short searches) .. CUs x 256 (from 100 searches on: 65,536 on
 // an MI355X; the reference's per-GPU batch is 4,096) on policies the 16- / 32-column engines support (128 or 256 hidden units); everything else
@@ -1004,7 +1188,21 @@ bool mcts_deep_applies(const MctsArgs &a)
 //   1,000 searches  512: 96 103 129 | 97 97 115 129    1,024: 126 123 130 | 127 115 116 136    2,048: 195 153 157 | 197 148 139 140
 //                   4,096: 324 241 197 | 330 225 174 187
 //   4,096 x 200: 94 70 58 | 97 67 51.9 47.3     3,072 x 200: 73 54 43 | 75 52 39.4 41.0     4,096 x 400: 157 114 91 | 160 110 84.0 82.5
-struct DeepShape { int walkers; bool wide; bool dec; };
+struct DeepShape { int walkers; bool wide; bool dec; bool split; int engines; };
+// The split shape's numbers (round 4, ms per collect, `profiles/r04_az_split_shape.txt`; E x S: engines 48 / 64 / 96 / 128 / 160 with 16 walkers per CU |
+// 128 engines with 2 x 12 walkers per CU | best shape inside one workgroup):
+//   4,096 x 1,000: - / 77.9 / 76.6 / 73.5 / 77.7 | 77.7 | 87.8      4,096 x 100: - / 15.4 / 13.7 / 13.4 / 15.7 | 13.0 | 17.4      4,096 x 400: 35.5 at 128 | 35.8 | 51.1
+//   8,192 x 100: 22.0 at 128 | 17.8 | 30.8      16,384 x 100: 36.5 / 35.3 / 37.0 at 64 / 96 / 128 | 30.6 (29.3 at 96) | 50.3      2,048 x 1,000: 70.7 at 96 | - | 75.6
+// Half of the CUs run engines: a forward costs its CU 17 us whatever it carries, a saturated engine packs up to sixteen demands into one,
+// and at 100 searches per move a walker spends more time waiting for outputs than walking (tree 43 k cycles per demand, wait 74 k).
+static int split_walkers_per_group(uint32_t num_searches)
+{
+#ifdef TW_ABLATE
+    if (const char *e = getenv("TW_SPLIT_WALKERS")) { const int n = atoi(e); if (n == 8 || n == 12 || n == 16) return n; }
+#endif
+    return num_searches >= 400 ? 16 : 12;              // 1 x 16 walker waves per CU for long searches, 2 x 12 for short ones
+}
+static int split_groups_per_cu(int walkers_per_group) { return walkers_per_group <= 12 ? 2 : 1; }
 static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false)
 {
     const int cus = device_cus();
@@ -1045,6 +1243,16 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     sh.dec = !solve && !sh.wide && sh.walkers >= 2 && sh.walkers <= 8;
     if (v & 256) sh.dec = false;
     if ((v & 128) && !solve && !sh.wide && sh.walkers >= 2) sh.dec = true;
+    // The split shape (walkers and engine as two kernels): from eight episodes per CU on.  Four engine workgroups per XCD serve the walker
+    // workgroups on the other CUs.  TW_OPT_AZ_VARIANT + 512 pins it on, + 1024 off.
+    sh.engines = (int)avail / 2;
+#ifdef TW_ABLATE
+    if (const char *e = getenv("TW_SPLIT_ENGINES")) { const int n = atoi(e); if (n >= 1 && n < (int)avail) sh.engines = n; }
+#endif
+    sh.split = !solve && !sh.wide && (v & 7) == 0 && avail >= 16 && num_episodes >= 8 * avail && !(v & 256);
+    if (v & 1024) sh.split = false;
+    if ((v & 512) && !solve && avail >= 16) { sh.split = true; sh.wide = false; }
+    if (sh.split) { sh.dec = true; sh.walkers = split_walkers_per_group(num_searches); }
     return sh;
 }
 static int deep_walkers_per_group(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false) { return deep_shape(num_episodes, reserve_cus, num_searches, solve).walkers; }
@@ -1053,10 +1261,87 @@ uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_
 {
     const int cus = device_cus();
     const int r = reserve_cus < 0 ? 0 : (reserve_cus > cus - 1 ? cus - 1 : reserve_cus);
-    const uint64_t nwk = (uint64_t)deep_walkers_per_group(num_episodes, reserve_cus, num_searches, solve);
+    const DeepShape sh = deep_shape(num_episodes, reserve_cus, num_searches, solve);
+    const uint64_t nwk = (uint64_t)sh.walkers;
     const uint64_t blocks = (num_episodes + nwk - 1) / nwk;
-    return (blocks < (uint64_t)(cus - r) ? blocks : (uint64_t)(cus - r)) * nwk;
+    // (split: the engine workgroups have CUs of their own; one or two walker workgroups on each of the others)
+    const uint64_t room = sh.split ? ((uint64_t)(cus - r) - (uint64_t)sh.engines) * (uint64_t)split_groups_per_cu(sh.walkers) : (uint64_t)(cus - r);
+    return (blocks < room ? blocks : room) * nwk;
 }
+bool mcts_deep_split(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve) { return deep_shape(num_episodes, reserve_cus, num_searches, solve).split; }
+
+// The split shape: mcts_engine_kernel on a side stream (first: its workgroups are resident before the walkers need them; it ends when every
+// walker has said it is done), mcts_deep_kernel<.., SPL> on the caller's stream, which then waits for the engine's end.  Walker workgroups
+// + engine workgroups <= CUs: every one of them is resident whatever the placement (neither kind fits twice beside the other: 127 KB and
+// ~150 KB of LDS), so no workgroup waits for one that cannot start.
+static std::mutex g_split_mutex;
+static hipStream_t g_split_stream[64] = {};
+static hipEvent_t g_split_ready[64] = {}, g_split_done[64] = {};
+template <int NT, int NC, int NWK>
+static int launch_deep_split(const MctsArgs &a, const DeepShape &sh, hipStream_t s, uint32_t *blocks, uint32_t *threads)
+{
+    using G = Geom<NT, NC, 0, -16>;
+    if (!a.mailbox) { set_error("mcts (deep, split): no mailboxes"); return TW_ERR_INVALID; }
+    const uint64_t walkers = mcts_deep_walkers(a.num_episodes, a.reserve_cus, a.num_searches, false);
+    const uint64_t nb = walkers / NWK;
+    uint64_t ne = (uint64_t)sh.engines;
+    if (ne > nb) ne = nb;                                   // (never more engines than walker workgroups)
+    const uint64_t wpe = (walkers + ne - 1) / ne;
+    if (nb == 0 || wpe > 256) { set_error("mcts (deep, split): %llu walkers for %llu engines", (unsigned long long)walkers, (unsigned long long)ne); return TW_ERR_INVALID; }
+    MctsArgs b = a;
+    const size_t budget = (size_t)159 * 1024 / sizeof(float) / (size_t)split_groups_per_cu(NWK);
+    size_t nl = (budget - deep_extra_floats(4 * NWK, 0, NWK, true)) / ((size_t)NWK * 6);
+    if (nl > a.node_cap) nl = a.node_cap;
+    b.lds_nodes = (uint32_t)nl;
+    b.split_walkers = (uint32_t)walkers; b.split_wpe = (uint32_t)wpe;
+    deep_tree_budgets(&b.tree_budget_min, &b.tree_budget);
+    const size_t lds_w = deep_extra_floats(4 * NWK, b.lds_nodes, NWK, true) * sizeof(float);
+    const size_t lds_e = (G::Eng::lds_floats(a.pol) + 80) * sizeof(float);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_deep_kernel<NT, NC, -16, NWK, false, true, true>), lds_w)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&mcts_engine_kernel<NT, NC>), lds_e)) return rc;
+    int dev = 0; TW_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("mcts (deep, split): device %d", dev); return TW_ERR_INVALID; }
+    hipStream_t es; hipEvent_t ready, done;
+    {
+        std::lock_guard<std::mutex> lk(g_split_mutex);
+        if (!g_split_stream[dev]) {
+            TW_HIP(hipStreamCreateWithFlags(&g_split_stream[dev], hipStreamNonBlocking));
+            TW_HIP(hipEventCreateWithFlags(&g_split_ready[dev], hipEventDisableTiming));
+            TW_HIP(hipEventCreateWithFlags(&g_split_done[dev], hipEventDisableTiming));
+        }
+        es = g_split_stream[dev]; ready = g_split_ready[dev]; done = g_split_done[dev];
+    }
+#ifdef TW_ABLATE
+    { unsigned long long zeros[16] = {0}; if (getenv("TW_STAMPS")) { TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros))); TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_extra), zeros, 32)); } }
+#endif
+    TW_HIP(hipEventRecord(ready, s));                       // tables, mailboxes, start boards: written on the caller's stream
+    TW_HIP(hipStreamWaitEvent(es, ready, 0));
+    hipLaunchKernelGGL((mcts_engine_kernel<NT, NC>), dim3((unsigned)ne), dim3(256), lds_e, es, b);
+    TW_HIP(hipGetLastError());
+    TW_HIP(hipEventRecord(done, es));
+    hipLaunchKernelGGL(split_gate_kernel, dim3(1), dim3(64), 0, s, (const uint32_t *)(b.mailbox + (size_t)walkers * 64), (uint32_t)ne, b.eval_count);
+    hipLaunchKernelGGL((mcts_deep_kernel<NT, NC, -16, NWK, false, true, true>), dim3((unsigned)nb), dim3(64 * NWK), lds_w, s, b);
+    TW_HIP(hipGetLastError());
+    TW_HIP(hipStreamWaitEvent(s, done, 0));                 // the collect goes on when both kernels have ended
+#ifdef TW_ABLATE
+    if (getenv("TW_STAMPS")) {
+        unsigned long long h[16];
+        TW_HIP(hipStreamSynchronize(s));
+        TW_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_deep_stamps), sizeof(h)));
+        const double w = (double)h[6], tr = (double)h[3];
+        fprintf(stderr, "split stamps: walkers %.0f (x %d per workgroup, %llu engines), lds nodes %u | per walker: tree %.0f, assembly %.0f, waiting for results %.0f cycles, trips %.1f | per trip: tree %.0f, wait %.0f | "
+                        "search-loop passes per trip %.2f, stored outputs consumed per trip %.2f\n",
+                w, NWK, (unsigned long long)ne, b.lds_nodes, h[1] / w, h[7] / w, h[2] / w, tr / w, h[1] / tr, h[2] / tr, (double)h[4] / tr, (double)h[5] / tr);
+        fprintf(stderr, "  tree phase per trip: store ahead-outputs + read demand %.0f | descents %.0f (%.2f levels per trip) | leaf phase incl. stored-output expansions %.0f | "
+                        "resume (expand demanded leaf) %.0f | backprops %.0f | move finish %.0f\n",
+                h[8] / tr, h[9] / tr, h[14] / tr, h[10] / tr, h[13] / tr, h[11] / tr, h[12] / tr);
+    }
+#endif
+    if (blocks) *blocks = (uint32_t)nb;
+    if (threads) *threads = 64 * NWK;
+    return TW_OK;
+}
+
 
 template <int NT, int NC, int NW, int NWK, bool SOLVE = false, bool DEC = false>
 static int launch_deep_nwk(const MctsArgs &a, hipStream_t s, uint32_t *blocks, uint32_t *threads)
@@ -1125,6 +1410,11 @@ static int launch_deep_geom(const MctsArgs &a, hipStream_t s, uint32_t *blocks, 
     }
     const DeepShape sh = deep_shape(a.num_episodes, a.reserve_cus, a.num_searches);
     if constexpr (NW == -16) {      // the decoupled shapes exist on the 16-column engine
+        if (sh.split) switch (sh.walkers) {
+            case 8:  return launch_deep_split<NT, NC, 8>(a, sh, s, blocks, threads);
+            case 12: return launch_deep_split<NT, NC, 12>(a, sh, s, blocks, threads);
+            default: return launch_deep_split<NT, NC, 16>(a, sh, s, blocks, threads);
+        }
         if (sh.dec) switch (sh.walkers) {
             case 2: return launch_deep_nwk<NT, NC, NW, 2, false, true>(a, s, blocks, threads);
             case 8: return launch_deep_nwk<NT, NC, NW, 8, false, true>(a, s, blocks, threads);
