@@ -89,7 +89,9 @@ enum {
                             /* two / one / four / eight walkers per workgroup, + 16 / + 32 = the 16- / 32-column engine,   */
                             /* + 64 = the walkers (and the PPO rollouts' persistent lanes) take the episodes by index      */
                             /*        instead of longest-looking first, + 128 / + 256 = the decoupled shape (engine-only   */
-                            /*        waves beside the walkers) pinned on / off                                            */
+                            /*        waves beside the walkers) pinned on / off, + 512 / + 1024 = the split shape (walkers */
+                            /*        and engine as two kernels; automatic from eight episodes per CU on) pinned on / off  */
+                            /*        -- + 1024 is what a run under a kernel-serialising profiler (rocprofv3 --pmc) needs  */
 };
 int tw_set_launch_option(int option, int value);
 /* Diagnostic counters of the last self-play launch of this process (MctsArgs::eval_count[0..15]); test hook. */

@@ -21,7 +21,8 @@ done
 echo "[profile_r04] self-play batches done"
 for S in 100 1000; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $out/az_stats_$S -o s -f csv -- python3 $OLDPWD/scripts/bench_az.py --envs 4096 --searches $S --steps 3 > $out/az_stats_$S.log 2>&1)
-  (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $out/az_pmc_$S -o p -f csv -- python3 $OLDPWD/scripts/bench_az.py --envs 4096 --searches $S --steps 1 > $out/az_pmc_$S.log 2>&1) || true
+  # (counter collection serialises kernels, and the split shape's two kernels need each other: the counters are those of the decoupled shape inside one workgroup, variant 1024)
+  (cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $out/az_pmc_$S -o p -f csv -- python3 $OLDPWD/scripts/bench_az.py --envs 4096 --searches $S --steps 1 --variant 1024 > $out/az_pmc_$S.log 2>&1) || true
   echo "[profile_r04] self-play counters x $S done"
 done
 python3 scripts/bench_generic_engine.py 2>/dev/null | grep policy > $out/generic_engine.jsonl || true

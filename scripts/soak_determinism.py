@@ -47,18 +47,25 @@ for E, rep in ((1024, 4 * n), (4096, 4 * n), (8000, 2 * n), (20000, 2 * n)):
 # (walker kernel: 256 episodes = one walker per workgroup, 800 / 1,024 two, 2,000 four on the 32-column engine, 4,096 and 6,000 x 100
 #  eight in eight-wave workgroups, 512 x 1,000 lone walkers on long streaks of searches, 1,100 x 400 four walkers + the episode queue in
 #  longest-first order; 20,000 and 70,000: lane-per-episode kernel)
-for E, S, rep, p in ((256, 60, n, pol0), (800, 40, n, pol), (1024, 50, n, pol0), (2000, 40, n, pol), (4096, 30, n, pol0), (4096, 100, n, pol),
+for cfg in ((256, 60, n, pol0), (800, 40, n, pol), (1024, 50, n, pol0), (2000, 40, n, pol), (4096, 30, n, pol0), (4096, 100, n, pol),
                      (6000, 100, max(2, n // 2), pol0), (512, 1000, max(2, n // 4), pol0), (1100, 400, max(2, n // 4), pol0),
-                     (20000, 16, n, pol0), (70000, 8, max(2, n // 3), pol0)):
+                     (20000, 16, n, pol0), (70000, 8, max(2, n // 3), pol0),
+                     # round 4: from 2,048 episodes on these run the SPLIT shape (walker kernel + engine kernel, mailboxes in device memory; which
+                     # engine serves which request when differs from run to run) -- and the same batches pinned to the decoupled shapes inside one workgroup
+                     (4096, 1000, max(2, n // 4), pol0), (16384, 100, max(2, n // 3), pol0), (8192, 200, max(2, n // 3), pol), (2048, 400, max(2, n // 3), pol0),
+                     (4096, 100, n, pol, 1024), (2000, 40, n, pol, 1024), (4096, 1000, max(2, n // 4), pol0, 1024), (1024, 1000, max(2, n // 4), pol0, 1024)):
+    (E, S, rep, p), variant = cfg[:4], (cfg[4] if len(cfg) > 4 else 0)
     env = twisterl.env.Puzzle(4, 4, 4 if S < 100 else 8, 2, 256)
     coll = twisterl.collector.AZCollector(E, S, 1.41, 1, 1)
     ref = None; bad = 0
-    for i in range(rep):
-        d = coll.collect(env, p, seed=7)
-        dg = digest(d)
-        if ref is None: ref = dg
-        elif dg != ref: bad += 1
-    print("self-play E", E, "searches", S, "twists" if p is pol else "no twists", "launch", d.stats["rollout_blocks"], "x", d.stats["rollout_threads"],
+    from twisterl_amd import _lib as _L
+    with _L.launch_option(_L.TW_OPT_AZ_VARIANT, variant):
+        for i in range(rep):
+            d = coll.collect(env, p, seed=7)
+            dg = digest(d)
+            if ref is None: ref = dg
+            elif dg != ref: bad += 1
+    print("self-play E", E, "searches", S, "twists" if p is pol else "no twists", "variant", variant, "launch", d.stats["rollout_blocks"], "x", d.stats["rollout_threads"],
           "repeats", rep, "mismatching repeats", bad, flush=True)
 # lane-per-episode kernel with the reused outputs active (>= 32 searches; hidden 32 / 64 / 256; plain, persistent, every pinned
 # geometry, deep trees whose search path outgrows the LDS levels)

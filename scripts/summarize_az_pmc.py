@@ -6,7 +6,8 @@ root = sys.argv[1]
 bench = json.loads(open(root + "/bench.json").read().strip().splitlines()[-1])
 print("# rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -- python scripts/bench_az.py --envs 4096 --searches S --steps 1")
 print("# (scripts/profile_r04.sh; tw::mcts_deep_kernel on the 16-column engine, the two launches of the run (warm-up + step) summed;")
-print("#  round 4: the decoupled shape -- four engine-only waves + the walkers; a forward runs only when a walker waits for one.")
+print("#  round 4: the decoupled shape inside one workgroup -- four engine-only waves + the walkers; a forward runs only when a walker waits for one -- pinned with")
+print("#  --variant 1024: counter collection serialises kernels, and the SPLIT shape the product takes at this size (walker kernel + engine kernel) needs both at once.")
 print("#  round 3, for comparison (profiles/r03_az_pmc_walker_kernel.txt): x 100: matrix pipe busy 0.107, useful fraction 0.20, SQ_WAIT_ANY / SQ_WAVE_CYCLES 0.67;")
 print("#  x 1,000: busy 0.061, useful fraction 0.12, wait 0.45)")
 for S, shape in ((100, "four engine-only waves + eight walkers x 2 columns"), (1000, "four engine-only waves + four walkers x 4 columns")):
@@ -15,7 +16,7 @@ for S, shape in ((100, "four engine-only waves + eight walkers x 2 columns"), (1
         if "mcts_deep" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"]); launches[r["Counter_Name"]] += 1
     n = max(launches.values())
-    side = bench[f"config5_az_4096x{S}"]
+    side = bench[f"config5_az_4096x{S}"]       # (the bench entry is the split shape's: its consumed / reused counts are the same searches)
     print(f"== 4,096 x {S} ({shape}): " + ", ".join(f"{k} {int(v)}" for k, v in sorted(tot.items())))
     busy = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * tot["GRBM_GUI_ACTIVE"] / 8)
     print(f"   matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1,024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = {busy:.3f}")

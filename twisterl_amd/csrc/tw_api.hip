@@ -1432,7 +1432,8 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
         return TW_ERR_HIP;
     }
     if (host_tot[1 + 13] != 0) {       // eval_count[13]: the decoupled walker shape's watchdog (a request / completion hand-shake that never completed)
-        set_error("az collect: the walker kernel's watchdog fired (%llu waves gave up waiting)", (unsigned long long)host_tot[1 + 13]);
+        set_error("az collect: the walker kernel's watchdog fired (%llu waves gave up waiting).  The split shape needs its two kernels to run at the same time: "
+                  "under a tool that serialises kernels (rocprofv3 --pmc) pin the shapes inside one workgroup, TW_OPT_AZ_VARIANT + 1024", (unsigned long long)host_tot[1 + 13]);
         return TW_ERR_HIP;
     }
     if (total == 0 || total > R) { set_error("az collect: inconsistent record count %llu (max %llu)", (unsigned long long)total, (unsigned long long)R); return TW_ERR_HIP; }
