@@ -1303,8 +1303,28 @@ extern "C" int tw_ppo_collect(const tw_puzzle_desc *env, const tw_policy *policy
     return TW_OK;
 }
 
+static int az_collect_once(const tw_puzzle_desc *env, const tw_policy *policy, const tw_az_params *prm, tw_collected **out, bool *split_watchdog);
+
+// The split shape of the walker kernel needs its two kernels on the chip at the same time.  Where something keeps them apart -- a tool that
+// serialises kernel launches (rocprofv3 --pmc), another process holding the CUs with persistent kernels of its own -- the first such collect
+// runs into its watchdog (seconds, never a hang); the library then says so once on stderr, stops using the split shape in this process and
+// runs the collect again on the shapes inside one workgroup: same bytes, the HIP path throughout.
 extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy, const tw_az_params *prm, tw_collected **out)
 {
+    bool split_watchdog = false;
+    int rc = az_collect_once(env, policy, prm, out, &split_watchdog);
+    if (rc != TW_OK && split_watchdog) {
+        fprintf(stderr, "[twisterl_hip] self-play: the split shape's kernels did not run side by side (a profiler that serialises kernels? a shared GPU?): "
+                        "%s -- retrying on the single-kernel shapes, which this process keeps from now on\n", tw_last_error());
+        mcts_deep_disable_split();
+        rc = az_collect_once(env, policy, prm, out, &split_watchdog);
+    }
+    return rc;
+}
+
+static int az_collect_once(const tw_puzzle_desc *env, const tw_policy *policy, const tw_az_params *prm, tw_collected **out, bool *split_watchdog)
+{
+    *split_watchdog = false;
     if (!env || !policy || !prm || !out) { set_error("tw_az_collect: null argument"); return TW_ERR_INVALID; }
     *out = nullptr;
     if (prm->num_episodes == 0) {
@@ -1432,6 +1452,7 @@ extern "C" int tw_az_collect(const tw_puzzle_desc *env, const tw_policy *policy,
         return TW_ERR_HIP;
     }
     if (host_tot[1 + 13] != 0) {       // eval_count[13]: the decoupled walker shape's watchdog (a request / completion hand-shake that never completed)
+        *split_watchdog = split;
         set_error("az collect: the walker kernel's watchdog fired (%llu waves gave up waiting).  The split shape needs its two kernels to run at the same time: "
                   "under a tool that serialises kernels (rocprofv3 --pmc) pin the shapes inside one workgroup, TW_OPT_AZ_VARIANT + 1024", (unsigned long long)host_tot[1 + 13]);
         return TW_ERR_HIP;

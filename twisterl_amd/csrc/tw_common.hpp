@@ -557,6 +557,7 @@ size_t mcts_node_bytes();
 bool     mcts_deep_applies(const MctsArgs &a);
 uint64_t mcts_deep_walkers(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false);   // tree arenas = episodes in flight
 bool     mcts_deep_split(uint64_t num_episodes, int reserve_cus, uint32_t num_searches, bool solve = false);     // the split form: MctsArgs::mailbox is needed (256 bytes per walker)
+void     mcts_deep_disable_split();        // this process stops taking the split form (after its watchdog fired: tw_az_collect)
 size_t   mcts_deep_node_bytes();
 // bytes of one walker's tree arena (72 per node, see tw_mcts_deep.hip), a multiple of 16
 __host__ __device__ inline size_t mcts_deep_arena_bytes(uint64_t node_cap) { return (size_t)((node_cap * 72 + 15) / 16 * 16); }

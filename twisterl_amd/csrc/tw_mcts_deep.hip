@@ -35,6 +35,7 @@
 // 4,096 x 100 collect with 64-byte node records, scripts/pmc_az_l2.sh).
 #include "tw_engine.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -1189,6 +1190,8 @@ bool mcts_deep_applies(const MctsArgs &a)
 //                   4,096: 324 241 197 | 330 225 174 187
 //   4,096 x 200: 94 70 58 | 97 67 51.9 47.3     3,072 x 200: 73 54 43 | 75 52 39.4 41.0     4,096 x 400: 157 114 91 | 160 110 84.0 82.5
 struct DeepShape { int walkers; bool wide; bool dec; bool split; int engines; };
+static std::atomic<int> g_split_disabled{0};
+void mcts_deep_disable_split() { g_split_disabled.store(1); }
 // The split shape's numbers (round 4, ms per collect, `profiles/r04_az_split_shape.txt`; E x S: engines 48 / 64 / 96 / 128 / 160 with 16 walkers per CU |
 // 128 engines with 2 x 12 walkers per CU | best shape inside one workgroup):
 //   4,096 x 1,000: - / 77.9 / 76.6 / 73.5 / 77.7 | 77.7 | 87.8      4,096 x 100: - / 15.4 / 13.7 / 13.4 / 15.7 | 13.0 | 17.4      4,096 x 400: 35.5 at 128 | 35.8 | 51.1
@@ -1250,8 +1253,8 @@ static DeepShape deep_shape(uint64_t num_episodes, int reserve_cus, uint32_t num
     if (const char *e = getenv("TW_SPLIT_ENGINES")) { const int n = atoi(e); if (n >= 1 && n < (int)avail) sh.engines = n; }
 #endif
     sh.split = !solve && !sh.wide && (v & 7) == 0 && avail >= 16 && num_episodes >= 8 * avail && !(v & 256);
-    if (v & 1024) sh.split = false;
-    if ((v & 512) && !solve && avail >= 16) { sh.split = true; sh.wide = false; }
+    if ((v & 1024) || g_split_disabled.load()) sh.split = false;
+    if ((v & 512) && !solve && avail >= 16 && !g_split_disabled.load()) { sh.split = true; sh.wide = false; }
     if (sh.split) { sh.dec = true; sh.walkers = split_walkers_per_group(num_searches); }
     return sh;
 }
