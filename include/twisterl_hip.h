@@ -91,7 +91,8 @@ enum {
                             /*        instead of longest-looking first, + 128 / + 256 = the decoupled shape (engine-only   */
                             /*        waves beside the walkers) pinned on / off, + 512 / + 1024 = the split shape (walkers */
                             /*        and engine as two kernels; automatic from eight episodes per CU on) pinned on / off  */
-                            /*        -- + 1024 is what a run under a kernel-serialising profiler (rocprofv3 --pmc) needs  */
+                            /*        -- + 1024 is what a run under a kernel-serialising profiler (rocprofv3 --pmc) needs; */
+                            /*        + 2048 (test hook) launches the split shape's two kernels one after the other        */
 };
 int tw_set_launch_option(int option, int value);
 /* Diagnostic counters of the last self-play launch of this process (MctsArgs::eval_count[0..15]); test hook. */

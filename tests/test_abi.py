@@ -43,7 +43,7 @@ def test_launch_options_are_validated():
     ok = [(_lib.TW_OPT_FORCE_GEOM, 8), (_lib.TW_OPT_FORCE_GEOM, 32), (_lib.TW_OPT_NO_PERSIST, 1), (_lib.TW_OPT_AZ_VARIANT, 2),
           (_lib.TW_OPT_AZ_VARIANT, 16 + 5), (_lib.TW_OPT_AZ_VARIANT, 32 + 6), (_lib.TW_OPT_AZ_VARIANT, 64), (_lib.TW_OPT_AZ_VARIANT, 64 + 2), (_lib.TW_OPT_AZ_VARIANT, 128 + 16 + 5), (_lib.TW_OPT_AZ_VARIANT, 256), (_lib.TW_OPT_AZ_VARIANT, 512), (_lib.TW_OPT_AZ_VARIANT, 1024), (_lib.TW_OPT_AZ_TREE_BUDGET, 72000), (_lib.TW_OPT_AZ_TREE_BUDGET_MIN, 8000),
           (_lib.TW_OPT_AZ_REUSE, 1), (_lib.TW_OPT_AZ_REUSE, 4)]
-    bad = [(_lib.TW_OPT_FORCE_GEOM, 5), (_lib.TW_OPT_AZ_VARIANT, 7), (_lib.TW_OPT_AZ_VARIANT, 48 + 3), (_lib.TW_OPT_AZ_VARIANT, 2048), (_lib.TW_OPT_AZ_VARIANT, 1536), (_lib.TW_OPT_AZ_VARIANT, 384), (_lib.TW_OPT_AZ_VARIANT, -1),
+    bad = [(_lib.TW_OPT_FORCE_GEOM, 5), (_lib.TW_OPT_AZ_VARIANT, 7), (_lib.TW_OPT_AZ_VARIANT, 48 + 3), (_lib.TW_OPT_AZ_VARIANT, 4096), (_lib.TW_OPT_AZ_VARIANT, 1536), (_lib.TW_OPT_AZ_VARIANT, 384), (_lib.TW_OPT_AZ_VARIANT, -1),
            (_lib.TW_OPT_AZ_TREE_BUDGET, 10), (_lib.TW_OPT_AZ_TREE_BUDGET_MIN, -5), (_lib.TW_OPT_AZ_REUSE, 5), (_lib.TW_OPT_AZ_REUSE, -1), (99, 0)]
     if not os.environ.get("TW_ABLATE"):
         bad.append((_lib.TW_OPT_AZ_REUSE, 2))      # the form that returns different bytes exists in the diagnostic build only

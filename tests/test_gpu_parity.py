@@ -573,6 +573,36 @@ def test_split_walker_shape_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hid
         assert np.array_equal(a[k], h2[k]), k
 
 
+def test_split_shape_falls_back_when_its_kernels_cannot_run_side_by_side(tw):
+    """The split shape's walker kernel and engine kernel need each other.  Launched one after the other (TW_OPT_AZ_VARIANT + 2048: what
+    `rocprofv3 --pmc` does to them) the collect must run into its watchdogs -- seconds, never a hang --, say so on stderr, and come back
+    with the bytes of the single-kernel shapes, which the process keeps afterwards."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import twisterl_amd
+    cus = twisterl_amd.device_info()["compute_units"]
+    E = 8 * cus + 100                                         # (eight episodes per CU: where the split shape starts)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "tests.tools.split_fallback_worker", str(E)], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "did not run side by side" in r.stderr and r.stderr.count("did not run side by side") == 1       # reported once
+    assert out["first"]["digest"] == out["again"]["digest"] == out["pinned_single_kernel"]
+    assert out["first"]["launch"][1] in (512, 768) and out["again"]["launch"] == out["first"]["launch"]      # the decoupled shapes inside one workgroup
+    # ... while this process, whose kernels do run side by side, takes the split shape for the same batch
+    from tests.util import make_policy_arrays
+    g = tw.collector.AZCollector(E, 16, 1.41, 1, 1).collect(tw.env.Puzzle(3, 3, 3, 2, 256), amd_policy(make_policy_arrays(9, seed=5, emb=64, hidden=128)), seed=3)
+    assert g.stats["rollout_threads"] == 768 and g.stats["rollout_blocks"] == min(-(-E // 12), (cus - cus // 2) * 2)
+    import hashlib
+    a = g.to_numpy(); h = hashlib.sha256()
+    for k in sorted(a):
+        h.update(k.encode()); h.update(a[k].tobytes())
+    assert h.hexdigest() == out["first"]["digest"]
+
+
 def test_solve_returns_the_solution_an_environment_tracks_itself(tw, oracle):
     """`Env::track_solution` / `Env::solution` through tw_env_vtable (rust/src/rl/env.rs:61-66): single_solve asks once, before
     the first move, and then returns the environment's own record instead of the actions it played (rust/src/rl/solve.rs:28,

@@ -246,7 +246,7 @@ extern "C" int tw_set_launch_option(int option, int value)
             g_force_geom.store(value); return TW_OK;
         case TW_OPT_NO_PERSIST: g_no_persist.store(value ? 1 : 0); return TW_OK;
         case TW_OPT_AZ_VARIANT:
-            if (value < 0 || (value & 7) > 6 || (value & ~2039) != 0 || (value & 48) == 48 || (value & 384) == 384 || (value & 1536) == 1536) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32) (+ 64) (+ 128 | 256) (+ 512 | 1024)", value); return TW_ERR_INVALID; }
+            if (value < 0 || (value & 7) > 6 || (value & ~4087) != 0 || (value & 48) == 48 || (value & 384) == 384 || (value & 1536) == 1536) { set_error("TW_OPT_AZ_VARIANT: value %d is not {0 .. 6} (+ 16 | 32) (+ 64) (+ 128 | 256) (+ 512 | 1024) (+ 2048)", value); return TW_ERR_INVALID; }
             g_az_variant.store(value); return TW_OK;
         case TW_OPT_AZ_TREE_BUDGET:
             if (value < 0 || (value != 0 && value < 1000)) { set_error("TW_OPT_AZ_TREE_BUDGET: %d cycles (0 = automatic, else >= 1000)", value); return TW_ERR_INVALID; }

@@ -1317,8 +1317,11 @@ static int launch_deep_split(const MctsArgs &a, const DeepShape &sh, hipStream_t
 #ifdef TW_ABLATE
     { unsigned long long zeros[16] = {0}; if (getenv("TW_STAMPS")) { TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_stamps), zeros, sizeof(zeros))); TW_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_deep_extra), zeros, 32)); } }
 #endif
+    // (TW_OPT_AZ_VARIANT + 2048, a test hook: both kernels on the caller's stream, ONE AFTER THE OTHER -- what a tool that serialises kernel
+    //  launches does to them; both then run into their watchdogs and tw_az_collect falls back to the single-kernel shapes)
+    if (launch_options().az_variant & 2048) es = s;
     TW_HIP(hipEventRecord(ready, s));                       // tables, mailboxes, start boards: written on the caller's stream
-    TW_HIP(hipStreamWaitEvent(es, ready, 0));
+    if (es != s) TW_HIP(hipStreamWaitEvent(es, ready, 0));
     hipLaunchKernelGGL((mcts_engine_kernel<NT, NC>), dim3((unsigned)ne), dim3(256), lds_e, es, b);
     TW_HIP(hipGetLastError());
     TW_HIP(hipEventRecord(done, es));
