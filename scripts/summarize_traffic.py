@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, sys
 root, out_path = sys.argv[1], sys.argv[2]
 KERNELS = {   # key -> (precision directory, substring of the kernel name)
     "tw::rollout_f32_kernel (persistent lanes) rollout_f32": ("fp32", "rollout_f32_kernel<8, 16, 0, 8, true>"),
-    "tw::finalize_ppo_kernel": ("fp32", "finalize_ppo_kernel"),
+    "tw::finalize_ppo_kernel": ("fp32", "finalize_ppo_"),          # (the grouped form or the wave-per-episode one)
     "tw::rollout_f16_kernel<EngineS> rollout_f16x2": ("fp16x2", "EngineS<8, 16>, 16, true>"),
     "tw::rollout_f16_kernel<Engine16> rollout_f16": ("fp16", "Engine16<8, 16>, 16, true>"),
 }

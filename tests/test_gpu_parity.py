@@ -109,6 +109,28 @@ def test_ppo_collect_bit_exact_vs_oracle(tw, oracle, w, h, diff, emb, hidden, E,
         _assert_same_collect(g, o, n2)
 
 
+@pytest.mark.parametrize("w,diff,slope,max_depth,E,form", [
+    (4, 100, 2, 256, 37, "16 episodes per workgroup, observations stored straight"),
+    (3, 3, 50, 256, 53, "16 per workgroup, observations staged (150 records)"),
+    (3, 100, 2, 256, 37, "8 per workgroup, staged (200 records)"),
+    (4, 300, 2, 1000, 21, "8 per workgroup (600 records)"),
+    (3, 200, 2, 600, 19, "a wave per episode, staged (400 records)"),
+    (4, 511, 2, 1022, 9, "8 per workgroup at the longest horizon the environment takes (1,022 records)"),
+])
+def test_gae_and_compaction_in_each_of_its_forms(tw, oracle, w, diff, slope, max_depth, E, form):
+    """tw_finalize.hip picks its kernel by the horizon (records per episode that fit an LDS tile): every form against the oracle's
+    GAE (ppo.rs:82-92), episode counts that fill no workgroup, both output orders."""
+    n2 = w * w
+    gp, op = _pair(oracle, n2, 4, 32, 32, twists=True)
+    genv = tw.env.Puzzle(w, w, diff, slope, max_depth)
+    oenv = oracle.Puzzle(w, w, diff, slope, max_depth)
+    for merge_order in (True, False):
+        coll = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.99, "lambda": 0.95, "num_cores": 32}, seed=5, merge_order=merge_order)
+        g = coll.collect(genv, gp, seed=5)
+        o = oracle.ppo_collect(oenv, op, E, 0.99, 0.95, seed=5, arith=oracle.ARITH_CHAIN, det_log=True, merge_order=merge_order)
+        _assert_same_collect(g, o, n2)
+
+
 def test_ppo_collect_within_1e5_of_reference_order(tw, oracle):
     """north_star tolerance: returns/advantages within 1e-5 of the reference arithmetic.  The
     reference order (un-fused, libm log) is replayed on the GPU's own trajectory: same boards and

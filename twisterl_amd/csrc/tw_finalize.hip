@@ -3,11 +3,12 @@
 //  * scan: exclusive prefix sum of the per-episode record counts in OUTPUT order.  With
 //    merge_order=1 the output order is the reference's merge() order: the LAST episode first,
 //    then episodes 0..E-2 (rust/src/collector/collector.rs:40-46).
-//  * finalize_ppo: one wave per episode.  Reads the episode's padded rewards/values, runs the
-//    GAE recurrence exactly as written in rust/src/collector/ppo.rs:82-92 (sequential in t,
-//    no contraction: the library is built with -ffp-contract=off), and copies every field of
-//    the episode into its compact slot with coalesced loads/stores.  HBM-bound byte moving;
-//    algorithmic traffic = N^2+34 B written + one 48-B padded record read per record (each record is read ONCE).
+//  * finalize_ppo: GAE + compaction.  Runs the GAE recurrence exactly as written in
+//    rust/src/collector/ppo.rs:82-92 (sequential in t, no contraction: the library is built with
+//    -ffp-contract=off) -- one LANE per episode, sixteen (eight) episodes per workgroup; a wave per
+//    episode beyond the horizons whose tile fits LDS -- and copies every field of the episode into
+//    its compact slot with coalesced loads/stores.  HBM-bound byte moving; algorithmic traffic =
+//    N^2+34 B written + one 48-B padded record read per record (each record is read ONCE).
 #include "tw_common.hpp"
 
 namespace tw {
@@ -139,7 +140,7 @@ static __host__ __device__ inline size_t fin_wave_bytes(int t_pad, int n_cells)
     return (((size_t)(n_cells == 16 ? 5 : 9) * (size_t)t_pad * 4) + 15) / 16 * 16;
 }
 
-// One wave per episode.  Every 48-byte padded record is FETCHED ONCE: a lane takes a whole record -- its three 16-byte words in three
+// One wave per episode (long horizons; the grouped form below serves the others).  Every 48-byte padded record is FETCHED ONCE: a lane takes a whole record -- its three 16-byte words in three
 // loads issued back to back, which cover the same cache lines -- and each word goes where it belongs: word 0 (the board as obs
 // bytes) and word 1 (the four logits) straight to their compact rows, word 2 (value, reward, action | twist) into LDS for the
 // GAE chain.  (Until round 4 the three words were read in three PASSES over the episode; with more episodes in flight than L2
@@ -211,10 +212,112 @@ __global__ void __launch_bounds__(FIN_WAVES * 64) finalize_ppo_kernel(const Padd
     }
 }
 
+// G episodes per workgroup of four waves (the short-horizon form).  The GAE recurrence is serial in t and must stay so (its sums in the
+// reference's order), but episodes are independent: LANE g of one wave walks the chain of episode g, so a workgroup pays one 257-step
+// loop for G episodes where the per-wave form above pays one per episode, replicated on 64 lanes (0.63 of its 1.82 ms at the headline
+// size were that loop: the same kernel without it ran 1.19 ms).  Phase A: wave w takes episodes w, w + 4, ... -- a lane per record, each
+// record fetched once; everything that needs no recurrence goes straight to its compact row, (value, reward) into LDS [episode][t].
+// Phase B: the chains, in place (advantage over reward, return over value).  Phase C: wave per episode again, the two columns out.
+template <int G>
+__global__ void __launch_bounds__(256) finalize_ppo_group_kernel(const PaddedTraj in, const uint64_t *ep_start, uint64_t E, int n_cells,
+                                                                  float gamma, float lambda, const CompactTraj out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t fin_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t_pad = in.t_pad, ts = t_pad | 1;                                              // (odd row stride: the chains' lanes spread over the banks)
+    float *sv = reinterpret_cast<float *>(fin_lds), *sr = sv + (size_t)G * ts;
+    uint4 *so = reinterpret_cast<uint4 *>(fin_lds + (size_t)G * ts * 8);                     // [G][t_pad] obs words (1..15 cells only)
+    uint4 *obs4 = reinterpret_cast<uint4 *>(out.obs), *logits4 = reinterpret_cast<uint4 *>(out.logits);
+    const uint64_t n_groups = (E + G - 1) / G;
+    for (uint64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint64_t e0 = grp * G;
+        for (int g = wave; g < G && e0 + g < E; g += 4) {
+            const uint64_t e = e0 + g;
+            const int n = (int)in.ep_len[e];
+            const uint64_t dst = ep_start[e];
+            const uint4 *rec4 = reinterpret_cast<const uint4 *>(in.rec + e * (uint64_t)t_pad);
+            float *v = sv + (size_t)g * ts, *r = sr + (size_t)g * ts;
+            for (int t = lane; t < n; t += 64) {
+                const uint4 w0 = rec4[3 * t], w1 = rec4[3 * t + 1], w2 = rec4[3 * t + 2];
+                const float val = __builtin_bit_cast(float, w2.x), rew = __builtin_bit_cast(float, w2.y);
+                v[t] = val; r[t] = rew;
+                out.values[dst + t] = val; out.rewards[dst + t] = rew;
+                out.actions[dst + t] = (uint8_t)(w2.z & 0xffu);
+                out.perms[dst + t]   = (int8_t)((w2.z >> 8) & 0xffu);
+                logits4[dst + t] = w1;
+                if (n_cells == 16) obs4[dst + t] = w0; else if (n_cells > 0) so[(size_t)g * t_pad + t] = w0;
+            }
+        }
+        __syncthreads();
+        // GAE (ppo.rs:82-92), lane = episode; the wave that runs the chains rotates with the group (the four SIMDs share the work)
+        if (wave == (int)(grp & 3u) && lane < G && e0 + lane < E) {
+            const int n = (int)in.ep_len[e0 + lane];
+            float *v = sv + (size_t)lane * ts, *r = sr + (size_t)lane * ts;
+            if (n > 0) {
+                float vnext = v[n - 1];
+                float ret = r[n - 1];
+                float adv = ret - vnext;
+                r[n - 1] = adv; v[n - 1] = ret;
+                for (int t = n - 2; t >= 0; --t) {
+                    const float rt = r[t], vt = v[t];
+                    float inner = lambda * adv;
+                    inner = vnext + inner;
+                    inner = gamma * inner;
+                    ret = rt + inner;
+                    adv = ret - vt;
+                    r[t] = adv; v[t] = ret;
+                    vnext = vt;
+                }
+            }
+        }
+        __syncthreads();
+        for (int g = wave; g < G && e0 + g < E; g += 4) {
+            const uint64_t e = e0 + g;
+            const int n = (int)in.ep_len[e];
+            const uint64_t dst = ep_start[e];
+            const float *v = sv + (size_t)g * ts, *r = sr + (size_t)g * ts;
+            for (int t = lane; t < n; t += 64) { out.advs[dst + t] = r[t]; out.rets[dst + t] = v[t]; }
+            if (n_cells > 0 && n_cells < 16) {         // compact rows of n_cells bytes out of the staged 16-byte ones
+                const uint8_t *sob = reinterpret_cast<const uint8_t *>(so + (size_t)g * t_pad);
+                const int nb = n * n_cells;
+                for (int i = lane; i < nb; i += 64) {
+                    const int t = i / n_cells, c = i - t * n_cells;
+                    out.obs[dst * n_cells + i] = sob[t * 16 + c];
+                }
+            }
+        }
+        __syncthreads();                               // (the next group overwrites the tile)
+    }
+}
+
+static size_t fin_group_bytes(int g, int t_pad, int n_cells)
+{
+    return (size_t)g * (size_t)(t_pad | 1) * 8 + ((n_cells == 16 || n_cells == 0) ? 0 : (size_t)g * (size_t)t_pad * 16);     // (0 cells: the obs ids have their own array)
+}
+
+template <int G>
+static int launch_fin_group(const PaddedTraj &in, const uint64_t *ep_start, uint64_t E, int n_cells, float gamma, float lambda,
+                            const CompactTraj &out, hipStream_t s)
+{
+    const size_t lds_bytes = fin_group_bytes(G, in.t_pad, n_cells);
+    uint64_t blocks = (E + G - 1) / G;
+    const uint64_t per_cu = (size_t)160 * 1024 / lds_bytes < 8 ? (size_t)160 * 1024 / lds_bytes : 8;
+    if (blocks > 256ull * per_cu * 2) blocks = 256ull * per_cu * 2;       // grid-stride the rest
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&finalize_ppo_group_kernel<G>), lds_bytes)) return rc;
+    hipLaunchKernelGGL(finalize_ppo_group_kernel<G>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, in, ep_start, E, n_cells, gamma, lambda, out);
+    TW_HIP(hipGetLastError());
+    return TW_OK;
+}
+
 int launch_finalize_ppo(const PaddedTraj &in, const uint64_t *ep_start, uint64_t E, int n_cells, float gamma,
                         float lambda, const CompactTraj &out, hipStream_t s)
 {
     if (E == 0) return TW_OK;
+    // horizons whose tile of 16 (8) episodes fits 64 KiB of LDS -- 511 (1,023: every horizon the Puzzle takes) records with 16-cell or
+    // id-array observations, 170 (341) with staged ones: the grouped form (headline size, 262,144 x 257: 1.21 ms with 16, 1.25 with 8 or 32, against 1.82 per wave;
+    // scripts/bench_finalize.py); longer ones: a wave per episode
+    if (fin_group_bytes(16, in.t_pad, n_cells) <= 64 * 1024) return launch_fin_group<16>(in, ep_start, E, n_cells, gamma, lambda, out, s);
+    if (fin_group_bytes(8, in.t_pad, n_cells) <= 64 * 1024) return launch_fin_group<8>(in, ep_start, E, n_cells, gamma, lambda, out, s);
     const size_t per_wave = fin_wave_bytes(in.t_pad, n_cells);
     int waves = FIN_WAVES;
     while (waves > 1 && waves * per_wave > 64 * 1024) waves >>= 1;           // long horizons: fewer episodes per workgroup
