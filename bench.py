@@ -323,10 +323,17 @@ def main():
     from twisterl_amd import _lib, twisterl
     if twisterl_amd.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP collector has no CPU fallback")
-    if local_rank >= twisterl_amd.device_count():
-        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, {twisterl_amd.device_count()} device(s) visible")
-    torch.cuda.set_device(local_rank)
-    _lib.check(_lib.lib().tw_set_device(local_rank))
+    # TW_BENCH_REHEARSAL=1 (tests/test_gpu_multirank.py): the N-rank job on ONE GPU -- every rank on cuda:0, gloo for the control
+    # collectives, the gather through the library's own exchange over the stand-in transport named by TW_RCCL_LIBRARY (RCCL refuses
+    # two ranks on a device).  It runs every line of the N > 1 path on device memory; its rate is not a measurement and the line says so.
+    rehearsal = os.environ.get("TW_BENCH_REHEARSAL") == "1"
+    if rehearsal and not os.environ.get("TW_RCCL_LIBRARY"):
+        raise SystemExit("bench.py: TW_BENCH_REHEARSAL needs TW_RCCL_LIBRARY (the stand-in transport)")
+    device_index = 0 if rehearsal else local_rank
+    if device_index >= twisterl_amd.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{device_index}, {twisterl_amd.device_count()} device(s) visible")
+    torch.cuda.set_device(device_index)
+    _lib.check(_lib.lib().tw_set_device(device_index))
     dist = None
     # under torchrun the distributed path runs even at N=1; strong scaling at N=1 needs the chunked path as well
     use_dist = world > 1 or under_launcher or args.scaling == "strong"
@@ -338,7 +345,10 @@ def main():
             with socket.socket() as so:
                 so.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         from twisterl_amd.dist import DEFAULT_RESERVE_CUS, Comm, TrajectoryGather, collect_sharded, pipeline_steps
 
     side = 4 if args.puzzle == 15 else 3
@@ -367,7 +377,7 @@ def main():
         gatherer = TrajectoryGather(dst=0, steps=K, max_records=E_total * t_max if K > 1 else None, max_episode_records=t_max)
         # transport of the gather: torch.distributed's point-to-point ops (default), or TW_GATHER=cabi: RCCL issued by the
         # library itself (tw_gather_*, what a non-Python host uses) -- same steps, same placement, same result
-        if os.environ.get("TW_GATHER", "torch") == "cabi":
+        if os.environ.get("TW_GATHER", "torch") == "cabi" or rehearsal:
             comm = Comm()
 
     def step(i):
@@ -405,8 +415,8 @@ def main():
     if trace is not None:
         print(f"[bench trace] rank {rank}: ms per step {trace}", file=sys.stderr)
 
-    rec_t = torch.tensor([float(records)], device="cuda")
-    dt_t = torch.tensor([dt], device="cuda")
+    rec_t = torch.tensor([float(records)], device="cpu" if rehearsal else "cuda")
+    dt_t = torch.tensor([dt], device="cpu" if rehearsal else "cuda")
     if dist is not None:
         dist.all_reduce(rec_t, op=dist.ReduceOp.SUM)
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
@@ -416,6 +426,8 @@ def main():
         gather_info = None if not use_dist else {"pipeline_steps": gatherer.steps, "episodes_per_rank_and_step": step_eps, "reserved_cus": reserve,
                                                  "transport": "RCCL send/recv at final offsets, issued by " + ("the library (tw_gather_*)" if comm is not None else "torch.distributed")}
         out = headline(args, world, use_dist, total_records, wall, records, ms_rollout, E_total, gather_info)
+        if rehearsal:
+            out["rehearsal"] = f"{world} ranks on ONE GPU over a stand-in transport (TW_BENCH_REHEARSAL): a run of the N > 1 code path, not a measurement"
         if world == 1 and args.precision == "fp32" and not use_dist:
             # side measurements, not the headline: the same workload in the two f16-matrix-core modes.
             #   fp16x2: every f32 operand as two f16 terms -- logits within 5e-8 of the reference f32 arithmetic on sampled

@@ -111,3 +111,36 @@ def test_killed_peer_in_the_middle_of_a_pipelined_gather(tmp_path, world):
     res = _run_ranks(tmp_path, world, "killed_mid_pipeline", timeout=120, expect_killed=(world - 1,))
     for r in res[:-1]:
         assert r["checks"][0] == "first_submit_ok" and r["checks"][-1] == "finish_raises_after_failure" and len(r["checks"]) == 3, r
+
+
+def test_bench_line_of_two_ranks_rehearsed_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` started the way the driver starts it (torch.distributed.run, one process per rank), on the ONE GPU of a test
+    box: TW_BENCH_REHEARSAL puts every rank on cuda:0 with gloo for the barriers and the library's exchange (tw_gather_*) over the
+    stand-in transport.  Every line of the N > 1 path runs on device memory -- shards of the seeded workload, pipeline steps with
+    reserved CUs, the gather at final offsets inside the timed region, MAX-over-ranks time, one JSON line from rank 0 -- which no
+    8-GPU node has run yet.  The rate it prints is not a measurement (two ranks share a GPU) and the line says so."""
+    import twisterl_amd
+    assert twisterl_amd.device_count() >= 1, "no GPU visible: the -m gpu tests need the MI355X box"
+    stub = build_stub_rccl()
+    env = dict(os.environ, TW_BENCH_REHEARSAL="1", TW_RCCL_LIBRARY=stub, MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TW_GATHER", "TW_STEP_EPISODES", "TW_RESERVE_CUS", "TWSTUB_DROP_SENDS"):
+        env.pop(k, None)
+    envs = 65536
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--envs", str(envs), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]                        # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and "rehearsal" in d
+    assert d["config"]["total_envs"] == 2 * envs and d["config"]["envs_per_gpu"] == envs
+    cus = twisterl_amd.device_info()["compute_units"]
+    g = d["config"]["gather"]
+    assert g["reserved_cus"] == 8 and g["episodes_per_rank_and_step"] == (cus - 8) * 256 and g["pipeline_steps"] == 2
+    assert "the library" in g["transport"]
+    # the untrained policy solves next to nothing at difficulty 128: close to 257 records per episode, from BOTH ranks
+    assert 0.98 * 257 * 2 * envs <= d["config"]["records_per_step"] <= 257 * 2 * envs
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - d["config"]["records_per_step"]) <= 1e-6 * d["config"]["records_per_step"]
