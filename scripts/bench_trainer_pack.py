@@ -14,11 +14,13 @@ pol = bench.build_policy(bench.synthetic_weights(16), op, ap_)
 env = twisterl.env.Puzzle(4, 4, 128, 2, 256)
 data = twisterl.collector.PPOCollector(args.envs, 0.995, 0.995, 1).collect(env, pol)
 n = min(args.rows, len(data))
-trainer.ppo_data_to_torch(data, 256, True, rows=(0, n))
-torch.cuda.synchronize(); t0 = time.perf_counter()
-reps = 5
+out = trainer.ppo_data_to_torch(data, 256, True, rows=(0, n))
+reps, ts = 5, []
 for _ in range(reps):
+    out = None                                   # (the previous result goes back to torch's allocator first: one result resident at a time)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     out = trainer.ppo_data_to_torch(data, 256, True, rows=(0, n))
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+dt = sorted(ts)[len(ts) // 2]                    # median
 bytes_written = n * (256 * 4 + 4 + 8 + 8 + 4 + 4)
 print(json.dumps({"rows": n, "ms": dt * 1e3, "GB_per_s_written": bytes_written / dt / 1e9, "frac_of_8TBps": bytes_written / dt / 8e12}))

@@ -1265,6 +1265,27 @@ def test_trainer_handoff_matches_reference_formulas(tw, oracle):
         trainer.ppo_data_to_torch(az, 81)
 
 
+@pytest.mark.parametrize("w,emb,hidden,E,diff", [(4, 64, 32, 301, 9), (2, 32, 32, 77, 3)])
+def test_trainer_one_hot_of_boards_whose_cells_own_multiples_of_four_ids(tw, oracle, w, emb, hidden, E, diff):
+    """PPO.data_to_torch's dense one-hot (src/twisterl/rl/ppo.py:37-39) for Puzzle-15 (16 x 16 ids) and the 2 x 2 board (4 x 4): the
+    form of the kernel that writes eight rows per wave and trip (tw_trainer.hip), whole collects and row ranges that start and end
+    inside such a group of rows."""
+    from twisterl_amd import trainer
+    n2 = w * w
+    gp, _ = _pair(oracle, n2, 6, emb, hidden, twists=True)
+    env = tw.env.Puzzle(w, w, diff, 2, 256)
+    data = tw.collector.PPOCollector(**{"num_episodes": E, "gamma": 0.99, "lambda": 0.95, "num_cores": 1}, seed=8).collect(env, gp)
+    a = data.to_numpy()
+    n = len(data)
+    want = np.zeros((n, n2 * n2), np.float32)
+    for i, o in enumerate(a["obs"].astype(int)):
+        want[i, o] = 1.0
+    assert np.array_equal(trainer.ppo_data_to_torch(data, n2 * n2)[0].cpu().numpy(), want)
+    for lo, hi in ((0, 1), (5, 5 + 33), (n - 13, n), (17, n - 3)):
+        got = trainer.ppo_data_to_torch(data, n2 * n2, rows=(lo, hi))[0].cpu().numpy()
+        assert got.shape == (hi - lo, n2 * n2) and np.array_equal(got, want[lo:hi]), (lo, hi)
+
+
 # ------------------------------------------------------------------------------ policy sync (SURVEY §8f rank 3)
 @pytest.mark.parametrize("n2,emb,hidden,twists", [(9, 64, 32, True), (16, 512, 256, True), (4, 96, 128, False)])
 def test_policy_update_from_torch_equals_rebuilding(tw, oracle, n2, emb, hidden, twists):
