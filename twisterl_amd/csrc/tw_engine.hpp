@@ -1020,7 +1020,9 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             const int oc = o < 4 ? o : 4;
             lds_cfloat *wp = (lds_cfloat *)this->lds_wn + oc * H;
             float a = 0.0f;
-#pragma unroll
+            // (EB -- the decoupled walker shapes, workgroups of 384 .. 768 threads, 256 registers per lane at most: fully unrolled, the
+            //  scheduler requests all 2 x 64 quads of the chain up front and the kernel spills ~450 bytes per lane to scratch)
+#pragma unroll EB ? 8 : H / 4
             for (int m = 0; m < H / 4; ++m) {
                 const f32x4 w = *reinterpret_cast<lds_cf4 *>(wp + 4 * m);
                 const f32x4 x = *reinterpret_cast<const f32x4 *>(hid + m * 64 + jj * 4);
