@@ -812,6 +812,9 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
     __device__ __forceinline__ void stream() const
     {
         constexpr int HALF = OP / TOPS, K = OP % TOPS;
+#ifdef TW_KNOCK
+        if (TW_KNOCK & 4) return;                 // timing-only knock-outs (a variant build with -DTW_KNOCK=bits): 1 no row reads, 2 no A-operand loads, 4 no table streams, 8 no MFMAs, 16 no closing wait
+#endif
         const uint8_t *src = stp; uint32_t mk = mT[K];
         if constexpr (FS) {
             const uint64_t u = (uint64_t)(uintptr_t)stp;
@@ -948,6 +951,9 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             constexpr int P = decltype(pc)::value, Q = P ^ 1;
             constexpr int M = 8 * TPW;
             // A operands of the NEXT pair, requested first: they land during this step (the closing wait covers them)
+#ifdef TW_KNOCK
+            if (!(TW_KNOCK & 2))
+#endif
             {
                 const float *ap = agl + aoff;
 #pragma unroll
@@ -966,8 +972,14 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
                     const int g = m / TPW, t = m % TPW;
                     // (the builtin: the inline-asm form of rounds 1 to 3 measured no faster in round 4 -- config 1 1.052 ms against 1.072,
                     //  self-play equal, profiles/r04_mfma_intrinsic_vs_asm.txt -- and sat outside hipcc's hazard padding)
+#ifdef TW_KNOCK
+                    if (!(TW_KNOCK & 8))
+#endif
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[P][g][t], g < 4 ? bq0[g & 3] : bq1[g & 3], acc[t], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef TW_KNOCK
+                    if (!(TW_KNOCK & 1))
+#endif
 #pragma unroll
                     for (int r = m * 2 * (NC + 1) / M; r < (m + 1) * 2 * (NC + 1) / M; ++r)         // the next pair, complete in pair-slot Q
                         gr[r / (NC + 1)][r % (NC + 1)] = ga[r % (NC + 1)][(2 * Q + r / (NC + 1)) * R3_TSLOT];
@@ -979,6 +991,9 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
                 stream_pair<P>();
             }
             advance();
+#ifdef TW_KNOCK
+            if (!(TW_KNOCK & 16))
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             this->template fsync<EB>();
         };
