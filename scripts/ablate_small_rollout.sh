@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing-only knock-outs of the 16-column engine's step (Engine3T, tw_engine.hpp: -DTW_KNOCK=bits -- 1 no row reads, 2 no A-operand loads,
-# 4 no table streams, 8 no MFMAs, 16 no closing wait; results are wrong, only the times mean something), as variants of the PRODUCT build:
+# 4 no table streams, 8 no MFMAs, 16 no closing wait, 32 no barrier at the end of a step, 64 no add chains; results are wrong, only the times mean something), as variants of the PRODUCT build:
 #   here:        for k in 8 6 9 31; do TW_VARIANT=knock$k TW_EXTRA_FLAGS=-DTW_KNOCK=$k python -m twisterl_amd.build; done
 #                (twisterl_amd/lib/variants/ is in .gpurunignore: take that line out for the call, and delete the variants' asm/ and objects first)
 #   GPU box:     bash scripts/ablate_small_rollout.sh

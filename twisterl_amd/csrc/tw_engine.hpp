@@ -939,6 +939,9 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 float sm = gr[hf][0];                                             // bias row, then the cells in order
+#ifdef TW_KNOCK
+                if (!(TW_KNOCK & 64))                                             // 64: no add chains
+#endif
 #pragma unroll
                 for (int c = 1; c <= NC; ++c) sm = sm + gr[hf][c];
                 xb[(buf * 64 + this->lane) * 8 + hf * 4 + wave] = relu_lim_v(sm, this->emb_lim);
@@ -995,6 +998,9 @@ struct Engine3T : Engine3<NT, NC, 0, 4> {
             if (!(TW_KNOCK & 16))
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TW_KNOCK
+            if (!(TW_KNOCK & 32))                                                 // 32: no barrier at the end of a step
+#endif
             this->template fsync<EB>();
         };
 
